@@ -1,0 +1,41 @@
+"""Shared helpers for the parity tests: golden-case loading and tolerance checks."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["ndc_relu", "ndc_relu_long", "ndc_softplus", "contract_relu_te", "contract_softplus_te"]
+
+# north_star tolerance: 1e-4 relative fp32. "Relative" is taken per tensor against its max
+# magnitude (a per-element relative error is meaningless for values that are exactly 0).
+RTOL = 1e-4
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    t = lambda k: torch.from_numpy(np.array(g[k]))
+    sd_s = {k[2:]: t(k) for k in g if k.startswith("s.")}
+    sd_d = {k[2:]: t(k) for k in g if k.startswith("d.")}
+    aabb = t("aabb")
+    base = dict(aabb=aabb, act=str(g["meta.act"]), density_shift=float(g["meta.density_shift"]),
+                distance_scale=25.0, weight_thres=1e-4, view_pe=0)
+    cfg_s = dict(base, head=str(g["meta.static_head"]), fea_pe=2)
+    cfg_d = dict(base, head="MLP_Fea_late_view", fea_pe=0)
+    return g, sd_s, cfg_s, sd_d, cfg_d
+
+
+def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    if mask is not None:
+        a = a[mask]
+        b = b[mask]
+    if a.numel() == 0:
+        return
+    scale = max(float(b.abs().max()), 1e-30)
+    err = float((a - b).abs().max())
+    assert err <= rtol * scale * atol_scale + 1e-30, (
+        f"{name}: max abs err {err:.3e} > {rtol * atol_scale:.1e} * max|ref| ({scale:.3e})")

@@ -1,0 +1,256 @@
+"""Generate golden input/output vectors by importing the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, read-only). Nothing of the reference
+is copied: this script imports it (with stub modules for never-executed imports and a CPU
+``get_device`` shim), runs its ``TensorVMSplit`` /
+``TensorVMSplit_TimeEmbedding`` / ``renderer.sampleXYZ`` / ``renderer.raw2outputs`` /
+ray-generation functions on seeded inputs, and stores inputs, weights, outputs and autograd
+gradients as ``tests/golden/*.npz``.  Those fixtures (data only) travel to the GPU box.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import types
+import io
+import contextlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("RODYNRF_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    def stub(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+
+    stub("imageio")
+    stub("plyfile")
+    stub("cv2", COLORMAP_JET=2)
+    stub("kornia").create_meshgrid = lambda H, W, normalized_coordinates=False: torch.stack(
+        torch.meshgrid(torch.arange(W, dtype=torch.float32), torch.arange(H, dtype=torch.float32),
+                       indexing="xy"), -1)[None]
+    tv = stub("torchvision")
+    tv.transforms = stub("torchvision.transforms")
+    sk = stub("skimage")
+    sk.measure = stub("skimage.measure")
+    sk.morphology = stub("skimage.morphology")
+
+    class _E(dict):
+        __getattr__ = dict.__getitem__
+
+    stub("easydict", EasyDict=_E)
+    _gd = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda t: t.device if not t.is_cuda else _gd(t)
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.tensoRF import TensorVMSplit, TensorVMSplit_TimeEmbedding
+        import renderer
+        from dataLoader import ray_utils
+        import camera
+    return TensorVMSplit, TensorVMSplit_TimeEmbedding, renderer, ray_utils, camera
+
+
+def build_fields(TS, TD, aabb, grid, act, static_head, density_shift, seed):
+    common = dict(density_n_comp=[16, 4, 4], appearance_n_comp=[48, 12, 12], app_dim=27,
+                  near_far=[0.0, 1.0], alphaMask_thres=1e-4, density_shift=density_shift,
+                  distance_scale=25, pos_pe=6, view_pe=0, featureC=128, step_ratio=2.0,
+                  fea2denseAct=act)
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        st = TS(aabb, grid, 12, "cpu", shadingMode=static_head, fea_pe=2, **common)
+        dy = TD(aabb, grid, 12, "cpu", shadingMode="MLP_Fea_late_view", fea_pe=0, **common)
+    return st, dy
+
+
+def to_np(d, prefix, out):
+    for k, v in d.items():
+        out[prefix + k] = v.detach().cpu().numpy()
+
+
+def gen_case(name, mods, ray_type, act, static_head, grid, N, S, seed, density_shift, jitter):
+    TS, TD, renderer, _, _ = mods
+    if ray_type == "ndc":
+        aabb = torch.tensor([[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]])
+    else:
+        aabb = torch.tensor([[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]])
+    st, dy = build_fields(TS, TD, aabb, grid, act, static_head, density_shift, seed)
+    if ray_type == "contract":
+        st.near_far = [0.0, 256.0]
+        dy.near_far = [0.0, 256.0]
+    # boost the dynamic density head a little so relu leaves a healthy mix of zero / non-zero sigma
+    g = torch.Generator().manual_seed(seed + 1)
+    if ray_type == "ndc":
+        o = torch.stack([torch.empty(N).uniform_(-1.45, 1.45, generator=g),
+                         torch.empty(N).uniform_(-1.6, 1.6, generator=g), -torch.ones(N)], -1)
+        d = torch.stack([torch.randn(N, generator=g) * 0.15, torch.randn(N, generator=g) * 0.15,
+                         2 * torch.ones(N)], -1)
+    else:
+        o = torch.randn(N, 3, generator=g) * 0.3
+        d = torch.randn(N, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True) * torch.empty(N, 1).uniform_(0.8, 1.2, generator=g)
+    rays = torch.cat([o, d], -1).requires_grad_(True)
+    ts = (torch.randint(0, 12, (N,), generator=g).float() * 2 / 11 - 1)
+
+    out = {}
+    out["meta.ray_type"] = np.array(ray_type)
+    out["meta.act"] = np.array(act)
+    out["meta.static_head"] = np.array(static_head)
+    out["meta.grid"] = np.array(grid)
+    out["meta.density_shift"] = np.array(density_shift, dtype=np.float32)
+    out["meta.near_far"] = np.array(dy.near_far, dtype=np.float32)
+    out["aabb"] = aabb.numpy()
+    out["rays"] = rays.detach().numpy()
+    out["ts"] = ts.numpy()
+
+    # sampler (jitter reproduced by replaying the generator: the reference calls torch.rand_like
+    # on a (1,S) / (1,inner+1) fp32 tensor)
+    jseed = seed + 7
+    if jitter:
+        torch.manual_seed(jseed)
+        if ray_type == "ndc":
+            out["jitter"] = torch.rand(1, S).numpy()
+        else:
+            inner = S - S // 2
+            out["jitter"] = torch.rand(1, inner + 1).numpy()
+            out["jitter_outer"] = torch.rand(1, S // 2 + 1).numpy()
+        torch.manual_seed(jseed)
+    xyz, z, valid = renderer.sampleXYZ(dy, rays, N_samples=S, ray_type=ray_type, is_train=jitter)
+    out["xyz"] = xyz.detach().numpy()
+    out["z"] = z.detach().numpy()
+    out["valid"] = valid.numpy()
+
+    o_s = st(rays, ts, None, xyz, z, valid, is_train=True, white_bg=True, ray_type=ray_type,
+             N_samples=S)
+    o_d = dy(rays, ts, None, xyz, z, valid, is_train=True, white_bg=True, ray_type=ray_type,
+             N_samples=S)
+    names = ["_0", "_1", "blending", "pts_ref", "weight", "xyz_prime", "rgb", "sigma", "z", "dists"]
+    for k, v in zip(names, o_s):
+        if v is not None:
+            out["fs." + k] = v.detach().numpy()
+    for k, v in zip(names, o_d):
+        if v is not None:
+            out["fd." + k] = v.detach().numpy()
+
+    onames = ["rgb_map_full", "depth_map_full", "acc_map_full", "weights_full", "rgb_map_s",
+              "depth_map_s", "acc_map_s", "weights_s", "rgb_map_d", "depth_map_d", "acc_map_d",
+              "weights_d", "dynamicness_map"]
+
+    def comp(is_train, want_white):
+        if is_train:
+            sd_ = 0
+            while True:
+                torch.manual_seed(sd_)
+                if (torch.rand((1,)) < 0.5).item() == want_white:
+                    break
+                sd_ += 1
+            torch.manual_seed(sd_)
+        return renderer.raw2outputs(o_s[6], o_s[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], rays,
+                                    is_train=is_train, ray_type=ray_type)
+
+    c_eval = comp(False, False)
+    c0 = comp(True, False)
+    c1 = comp(True, True)
+    for k, a, b, c in zip(onames, c_eval, c0, c1):
+        out["ce." + k] = a.detach().numpy()
+        out["c0." + k] = b.detach().numpy()
+        out["c1." + k] = c.detach().numpy()
+    assert np.allclose(out["ce.rgb_map_full"], out["c0.rgb_map_full"])
+
+    sf_f, sf_b = dy.get_forward_backward_scene_flow(o_d[3], ts)
+    out["sf.f"] = sf_f.detach().numpy()
+    out["sf.b"] = sf_b.detach().numpy()
+
+    # fixed scalar loss over everything the trainer consumes, all paths live (pass-E-like)
+    gl = torch.Generator().manual_seed(seed + 3)
+    L = 0.0
+    for k, v in zip(onames, c1):
+        r = torch.randn(v.shape, generator=gl)
+        out["lw.c1." + k] = r.numpy()
+        L = L + (v * r).sum()
+    for k, v in (("blending", o_d[2]), ("weight", o_d[4]), ("xyz_prime", o_d[5]),
+                 ("weight_s", o_s[4])):
+        r = torch.randn(v.shape, generator=gl)
+        out["lw.f." + k] = r.numpy()
+        L = L + (v * r).sum()
+    for k, v in (("sf_f", sf_f), ("sf_b", sf_b)):
+        r = torch.randn(v.shape, generator=gl)
+        out["lw." + k] = r.numpy()
+        L = L + (v * r).sum()
+    out["loss"] = L.detach().numpy()
+    ps = [p for p in st.parameters()]
+    pd = [p for p in dy.parameters()]
+    grads = torch.autograd.grad(L, ps + pd + [rays], allow_unused=True)
+    for (k, _), gv in zip(st.named_parameters(), grads[: len(ps)]):
+        out["gs." + k] = (gv if gv is not None else torch.zeros(())).numpy()
+    for (k, _), gv in zip(dy.named_parameters(), grads[len(ps): len(ps) + len(pd)]):
+        out["gd." + k] = (gv if gv is not None else torch.zeros(())).numpy()
+    out["g.rays"] = grads[-1].numpy()
+
+    to_np(st.state_dict(), "s.", out)
+    to_np(dy.state_dict(), "d.", out)
+
+    # function-level vectors incl. out-of-range coordinates (zero padding)
+    M = 96
+    xn = torch.empty(M, 3).uniform_(-1.3, 1.3, generator=g)
+    xn[:8] = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [1.0, -1.0, 0.0], [0.0, 0.0, 0.0],
+                           [1.0001, 0.5, -0.5], [-1.0001, 0.5, 0.5], [0.999999, -0.999999, 1.0],
+                           [2.5, -3.0, 0.1]])
+    tf = (torch.randint(0, 12, (M,), generator=g).float() * 2 / 11 - 1)
+    out["fn.xn"] = xn.numpy()
+    out["fn.t"] = tf.numpy()
+    with torch.no_grad():
+        out["fn.s_density"] = st.compute_densityfeature(xn, tf, None).numpy()
+        out["fn.s_app"] = st.compute_appfeature(xn, tf, None).numpy()
+        out["fn.d_density"] = dy.compute_densityfeature(xn, tf, None).numpy()
+        out["fn.d_blending"] = dy.compute_blendingfeature(xn, tf, None).numpy()
+        out["fn.d_app"] = dy.compute_appfeature(xn, tf, None).numpy()
+        out["fn.d_warp"] = dy.warp_coordinate(dy.unnormalize_coord(xn), tf).numpy()
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    fa = float(((o_d[4] > 1e-4).float().mean()))
+    print(f"{name}: loss {float(L):.5f} valid {float(valid.float().mean()):.3f} "
+          f"app_mask_d {fa:.3f} app_mask_s {float((o_s[4] > 1e-4).float().mean()):.3f} "
+          f"sigma_d>0 {float((o_d[7] > 0).float().mean()):.3f}")
+
+
+def gen_raygen(mods):
+    _, _, _, ru, camera = mods
+    g = torch.Generator().manual_seed(99)
+    T, H, W = 5, 27, 48
+    poses = torch.zeros(T, 9)
+    poses[:, 0] = 1
+    poses[:, 4] = 1
+    poses = poses + 0.05 * torch.randn(T, 9, generator=g)
+    poses.requires_grad_(True)
+    focal = torch.tensor(max(H, W) / 2.0 * 1.7320508, requires_grad=True)
+    ids = torch.randint(0, T * H * W, (64,), generator=g)
+    col, row, view = ids % W, (ids // W) % H, ids // (W * H)
+    mtx = camera.pose_to_mtx(poses)
+    dirs = ru.get_ray_directions_lean(col, row, [focal, focal], [W / 2, H / 2])
+    ro, rd = ru.get_rays_lean(dirs, mtx[view])
+    ro_n, rd_n = ru.ndc_rays_blender2(H, W, [focal, focal], 1.0, ro, rd)
+    rays = torch.cat([ro_n, rd_n], -1)
+    r = torch.randn(rays.shape, generator=g)
+    gp, gf = torch.autograd.grad((rays * r).sum(), [poses, focal])
+    np.savez(os.path.join(HERE, "raygen.npz"), poses=poses.detach().numpy(),
+             focal=focal.detach().numpy(), ids=ids.numpy(), H=H, W=W,
+             rays_world=torch.cat([ro, rd], -1).detach().numpy(), rays=rays.detach().numpy(),
+             lw=r.numpy(), g_poses=gp.numpy(), g_focal=gf.numpy(), mtx=mtx.detach().numpy())
+    print("raygen: ok")
+
+
+if __name__ == "__main__":
+    mods = import_reference()
+    gen_case("ndc_relu", mods, "ndc", "relu", "MLP_Fea", [18, 19, 11], 32, 13, 20211202, -10.0, False)
+    gen_case("ndc_relu_long", mods, "ndc", "relu", "MLP_Fea", [10, 11, 7], 6, 130, 20211203, -10.0, True)
+    gen_case("ndc_softplus", mods, "ndc", "softplus", "MLP_Fea", [10, 12, 7], 16, 13, 20211204, -1.0, True)
+    gen_case("contract_relu_te", mods, "contract", "relu", "MLP_Fea_TimeEmbedding", [9, 9, 9], 16, 14,
+             20211205, -10.0, True)
+    gen_case("contract_softplus_te", mods, "contract", "softplus", "MLP_Fea_TimeEmbedding", [8, 8, 8],
+             12, 13, 20211206, -1.0, False)
+    gen_raygen(mods)
