@@ -1,0 +1,196 @@
+/* rodynrf.h -- C ABI of the MI355X-native RoDynRF ray-batch hot path (librodynrf.so).
+ *
+ * The reference (facebookresearch/robust-dynrf) is pure Python: it has no FFI.  Its boundary for
+ * this path is the Python call surface of three objects:
+ *
+ *   TensorVMSplit.forward / TensorVMSplit_TimeEmbedding.forward   models/tensorBase.py:704-850
+ *   renderer.sampleXYZ                                            renderer.py:147-170
+ *   renderer.raw2outputs                                          renderer.py:173-315
+ *   TensorVMSplit_TimeEmbedding.get_forward_backward_scene_flow   models/tensoRF.py:446-462
+ *   ray generation (ids2pixel .. ndc_rays_blender2)               train.py:96-103, 1062-1077
+ *
+ * Each entry point below replaces one of those calls (cited per function).  The host-side mirror
+ * (robust-dynrf_amd/*.py) binds them with ctypes and re-exposes the reference signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; all tensors fp32, row major;
+ *     masks are uint8; indices int32/int64 as stated.
+ *   - return 0 on success, a negative code on failure; rdrf_last_error() gives the message
+ *     (thread local). No entry point throws, allocates device memory, or synchronises: outputs and
+ *     the workspace are caller-allocated, work is enqueued on `stream`.
+ *   - VM factors are CHANNEL-LAST: plane i is [H_i][W_i][C_i] (the reference's (1,C,H,W) tensor
+ *     with channels_last strides), line i is [L_i][C_i].  plane 0/1/2 = XY/XZ/YZ,
+ *     line 0/1/2 = Z/Y/X (matMode/vecMode, models/tensorBase.py:326-327).
+ *   - gradients are ACCUMULATED (+=) into the caller's (zero-initialised) buffers.
+ */
+#ifndef RODYNRF_H
+#define RODYNRF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDRF_ABI_VERSION 1
+
+typedef void* rdrf_stream_t; /* hipStream_t */
+
+enum { RDRF_RAY_NDC = 0, RDRF_RAY_CONTRACT = 1, RDRF_RAY_OTHER = 2 };
+enum { RDRF_ACT_RELU = 0, RDRF_ACT_SOFTPLUS = 1 };
+enum { RDRF_HEAD_MLP_FEA = 0, RDRF_HEAD_MLP_FEA_TIMEEMBEDDING = 1 };
+
+/* One vector-matrix factor set (3 planes + 3 lines), channel-last. */
+typedef struct {
+  float* plane[3]; /* [H][W][C] */
+  float* line[3];  /* [L][C]    */
+  int C[3];        /* components per plane/line pair: {16,4,4} or {48,12,12} */
+  int H[3], W[3];  /* plane i: H = grid[matMode[i][1]], W = grid[matMode[i][0]] */
+  int L[3];        /* line i:  L = grid[vecMode[i]] */
+} RdrfVM;
+
+/* Scalars the path reads from the field object (models/tensorBase.py:282-339, get_kwargs). */
+typedef struct {
+  float aabb[6];        /* min xyz, max xyz */
+  float distance_scale; /* 25 */
+  float weight_thres;   /* rayMarch_weight_thres, 1e-4 */
+  float density_shift;  /* softplus shift */
+  int act;              /* RDRF_ACT_* (fea2denseAct) */
+  int ray_type;         /* RDRF_RAY_* */
+  int static_head;      /* RDRF_HEAD_* (static field only) */
+} RdrfFieldCfg;
+
+/* Static TensorVMSplit parameters (state_dict names in comments). Used for values AND, with the
+ * same struct filled with gradient buffers, for gradients. */
+typedef struct {
+  RdrfVM density, app;  /* density_plane/line.{0,1,2}, app_plane/line.{0,1,2} */
+  float* basis;         /* basis_mat.weight (27,72) */
+  float *w1, *b1;       /* renderModule.mlp.0 (128,138) | (128,135) */
+  float *w2, *b2;       /* renderModule.mlp.2 (128,128) */
+  float *w3, *b3;       /* renderModule.mlp.4 (3,128) | renderModule.mlp_view.0 (3,131) */
+} RdrfStaticParams;
+
+/* Dynamic TensorVMSplit_TimeEmbedding parameters. */
+typedef struct {
+  RdrfVM density, blending, app;
+  float* basis;                 /* basis_mat.weight (27,216) */
+  float *rw1, *rb1;             /* renderModule.mlp.0 (128,107) */
+  float *rw2, *rb2;             /* renderModule.mlp.2 (128,128) */
+  float *rwv, *rbv;             /* renderModule.mlp_view.0 (3,131) */
+  float *l1w, *l1b;             /* layer1 (64,17) */
+  float *l2w, *l2b;             /* layer2 (30,64) */
+  float *l3w, *l3b;             /* layer3 (64,93) */
+  float *l4w, *l4b;             /* layer4 (64,64) */
+  float *l5w, *l5b;             /* layer5 (3,64) */
+  float *dw1, *db1, *dw2, *db2; /* density_layer1 (64,152), density_layer2 (1,64) */
+  float *bw1, *bb1, *bw2, *bb2; /* blending_layer1/2 */
+  float *sfw[4], *sfb[4];       /* scene_flow_mlp.{0,2,4,6}: (64,36)(64,64)(64,64)(6,64) */
+} RdrfDynamicParams;
+
+int rdrf_abi_version(void);
+const char* rdrf_last_error(void);
+
+/* Bytes of workspace a forward/backward call of either field needs for N rays x S samples. */
+size_t rdrf_workspace_bytes(int N, int S);
+
+/* ---- ray generation: train.py:96-103 + dataLoader/ray_utils.py:53-140 + camera.py:8-15 -------
+ * ids[N] int64 flat ray ids over (T,H,W); poses9[T][9] 6-D rotation + translation; focal scalar.
+ * rays[N][6]; if ndc != 0 the NDC warp with near = `near` is applied (ndc_rays_blender2). */
+int rdrf_generate_rays(const int64_t* ids, const float* poses9, const float* focal, int N, int T,
+                       int H, int W, int ndc, float near, float* rays, rdrf_stream_t stream);
+/* grad_rays[N][6] -> grad_poses9[T][9] (+=), grad_focal[1] (+=) */
+int rdrf_generate_rays_bwd(const int64_t* ids, const float* poses9, const float* focal, int N,
+                           int T, int H, int W, int ndc, float near, const float* grad_rays,
+                           float* grad_poses9, float* grad_focal, rdrf_stream_t stream);
+
+/* ---- renderer.sampleXYZ (renderer.py:147-170) ------------------------------------------------
+ * NDC: models/tensorBase.py:487-499. jitter[S] (uniform [0,1), shared by all rays) or NULL. */
+int rdrf_sample_ndc(const float* rays, int N, int S, float near, float far, const float* jitter,
+                    const float aabb_host[6], float* xyz, float* z, uint8_t* valid,
+                    rdrf_stream_t stream);
+/* contract: models/tensorBase.py:524-559. jitter_inner[S-S/2+1], jitter_outer[S/2+1] or NULL. */
+int rdrf_sample_contract(const float* rays, int N, int S, float near, float far,
+                         const float* jitter_inner, const float* jitter_outer, float* xyz,
+                         float* z, uint8_t* valid, rdrf_stream_t stream);
+/* grad_xyz[N][S][3], grad_z[N][S] -> grad_rays[N][6] (+=). z_row[S] are the sample depths. */
+int rdrf_sample_bwd(const float* rays, const float* z_row, int N, int S, int ray_type,
+                    const float* grad_xyz, float* grad_rays, rdrf_stream_t stream);
+
+/* ---- TensorVMSplit.forward (models/tensorBase.py:704-850, models/tensoRF.py:118-196) ---------
+ * outputs: rgb[N][S][3], sigma[N][S], weight[N][S], dists[N][S] (= dists*distance_scale). */
+int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
+                    const float* ts, const float* xyz, const float* z, const uint8_t* valid, int N,
+                    int S, float* rgb, float* sigma, float* weight, float* dists, void* ws,
+                    size_t ws_bytes, rdrf_stream_t stream);
+/* g_* are gradients wrt the four outputs (any may be NULL = zero). G receives parameter
+ * gradients (+=); g_xyz[N][S][3], g_z[N][S], g_rays[N][6] (+=, each may be NULL). */
+int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
+                    const float* ts, const float* xyz, const float* z, const uint8_t* valid, int N,
+                    int S, const float* g_rgb, const float* g_sigma, const float* g_weight,
+                    const float* g_dists, const RdrfStaticParams* G, float* g_xyz, float* g_z,
+                    float* g_rays, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
+/* ---- TensorVMSplit_TimeEmbedding.forward (models/tensorBase.py:704-850,
+ *      models/tensoRF.py:521-811) -- adds blending[N][S], xyz_prime[N][S][3]. */
+int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* rays,
+                     const float* ts, const float* xyz, const float* z, const uint8_t* valid,
+                     int N, int S, float* blending, float* weight, float* xyz_prime, float* rgb,
+                     float* sigma, float* dists, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* rays,
+                     const float* ts, const float* xyz, const float* z, const uint8_t* valid,
+                     int N, int S, const float* g_blending, const float* g_weight,
+                     const float* g_xyz_prime, const float* g_rgb, const float* g_sigma,
+                     const float* g_dists, const RdrfDynamicParams* G, float* g_xyz, float* g_z,
+                     float* g_rays, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
+/* ---- get_forward_backward_scene_flow (models/tensoRF.py:446-462) -----------------------------
+ * pts[N][S][3] un-normalised, ts[N] -> sf_f[N][S][3], sf_b[N][S][3]. */
+int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* pts,
+                        const float* ts, int N, int S, float* sf_f, float* sf_b, void* ws,
+                        size_t ws_bytes, rdrf_stream_t stream);
+int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* pts,
+                        const float* ts, int N, int S, const float* g_sf_f, const float* g_sf_b,
+                        const RdrfDynamicParams* G, float* g_pts, void* ws, size_t ws_bytes,
+                        rdrf_stream_t stream);
+
+/* ---- renderer.raw2outputs (renderer.py:173-315) ----------------------------------------------
+ * add_white_bg: the caller draws the train-time coin (renderer.py:269). out13: pointers to the 13
+ * outputs in the reference's order: rgb_map_full[N][3], depth_map_full[N], acc_map_full[N],
+ * weights_full[N][S], rgb_map_s, depth_map_s, acc_map_s, weights_s, rgb_map_d, depth_map_d,
+ * acc_map_d, weights_d, dynamicness_map[N]. */
+int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
+                       const float* sigma_d, const float* dists, const float* blending,
+                       const float* z, const float* rays, int N, int S, int ray_type,
+                       int add_white_bg, float* const out13[13], rdrf_stream_t stream);
+/* g_out13: gradients wrt the 13 outputs (entries may be NULL). g_in8: gradient buffers (+=) for
+ * rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z, rays (entries may be NULL). */
+int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
+                       const float* sigma_d, const float* dists, const float* blending,
+                       const float* z, const float* rays, int N, int S, int ray_type,
+                       int add_white_bg, const float* const g_out13[13], float* const g_in8[8],
+                       rdrf_stream_t stream);
+
+/* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
+ * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].
+ * scratch for the per-sample tensors comes out of ws (rdrf_render_workspace_bytes). */
+size_t rdrf_render_workspace_bytes(int N, int S);
+int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
+                    const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
+                    const float* ts, int N, int S, float near, float far, float* rgb_map,
+                    float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
+/* ---- kernel self-tests (used by tests/ only): run the MFMA layer chain on a synthetic input
+ * and return it for comparison with a numpy matmul. x[M][K] -> y[M][OUT] = relu(x W^T + b). */
+int rdrf_selftest_mlp(const float* x, const float* w, const float* b, int M, int K, int OUT,
+                      float* y, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
+/* timing hook: average device time (ms) of the dominant kernel launches recorded with HIP events
+ * since the last reset; used by bench.py for the roofline figure. */
+void rdrf_prof_reset(void);
+int rdrf_prof_enable(int on);
+int rdrf_prof_get(const char* kernel, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,18 @@
+"""rodynrf (robust-dynrf_amd): the MI355X-native ray-batch hot path of RoDynRF.
+
+Hand-written HIP kernels for gfx950 behind a C ABI (include/rodynrf.h, librodynrf.so), exposed
+through the reference's own call surface:
+
+    TensorVMSplit, TensorVMSplit_TimeEmbedding     (models/tensoRF.py)
+    sampleXYZ, raw2outputs, OctreeRender_trilinear_fast   (renderer.py)
+    generate_rays                                  (train.py ray-generation block)
+
+Importing this package loads librodynrf.so and raises if it is missing: there is no fallback.
+"""
+from . import _lib
+from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding, TensorBase
+from .renderer import sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays
+from .ray_utils import generate_rays, ids2pixel
+
+__all__ = ["TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
+           "OctreeRender_trilinear_fast", "sample_rays", "generate_rays", "ids2pixel"]

@@ -1,0 +1,119 @@
+"""ctypes binding of librodynrf.so (C ABI declared in include/rodynrf.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to load the import
+raises, and every op raises if the tensors are not on a HIP device.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librodynrf.so")
+
+RAY_TYPES = {"ndc": 0, "contract": 1}
+ACTS = {"relu": 0, "softplus": 1}
+HEADS = {"MLP_Fea": 0, "MLP_Fea_TimeEmbedding": 1}
+
+fp = C.POINTER(C.c_float)
+
+
+class RdrfVM(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("line", C.c_void_p * 3), ("C", C.c_int * 3),
+                ("H", C.c_int * 3), ("W", C.c_int * 3), ("L", C.c_int * 3)]
+
+
+class RdrfFieldCfg(C.Structure):
+    _fields_ = [("aabb", C.c_float * 6), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
+                ("density_shift", C.c_float), ("act", C.c_int), ("ray_type", C.c_int),
+                ("static_head", C.c_int)]
+
+
+class RdrfStaticParams(C.Structure):
+    _fields_ = [("density", RdrfVM), ("app", RdrfVM), ("basis", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class RdrfDynamicParams(C.Structure):
+    _fields_ = [("density", RdrfVM), ("blending", RdrfVM), ("app", RdrfVM), ("basis", C.c_void_p),
+                ("rw1", C.c_void_p), ("rb1", C.c_void_p), ("rw2", C.c_void_p), ("rb2", C.c_void_p),
+                ("rwv", C.c_void_p), ("rbv", C.c_void_p),
+                ("l1w", C.c_void_p), ("l1b", C.c_void_p), ("l2w", C.c_void_p), ("l2b", C.c_void_p),
+                ("l3w", C.c_void_p), ("l3b", C.c_void_p), ("l4w", C.c_void_p), ("l4b", C.c_void_p),
+                ("l5w", C.c_void_p), ("l5b", C.c_void_p),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
+                ("bw1", C.c_void_p), ("bb1", C.c_void_p), ("bw2", C.c_void_p), ("bb2", C.c_void_p),
+                ("sfw", C.c_void_p * 4), ("sfb", C.c_void_p * 4)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C robust-dynrf_amd/csrc)")
+    lib = C.CDLL(LIB_PATH)
+    lib.rdrf_last_error.restype = C.c_char_p
+    lib.rdrf_workspace_bytes.restype = C.c_size_t
+    lib.rdrf_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.rdrf_render_workspace_bytes.restype = C.c_size_t
+    lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    if lib.rdrf_abi_version() != 1:
+        raise ImportError("librodynrf.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+# every symbol include/rodynrf.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "rdrf_abi_version", "rdrf_last_error", "rdrf_workspace_bytes", "rdrf_generate_rays",
+    "rdrf_generate_rays_bwd", "rdrf_sample_ndc", "rdrf_sample_contract", "rdrf_sample_bwd",
+    "rdrf_static_fwd", "rdrf_static_bwd", "rdrf_dynamic_fwd", "rdrf_dynamic_bwd",
+    "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
+    "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
+    "rdrf_prof_enable", "rdrf_prof_get",
+]
+
+
+class RdrfError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RdrfError(f"{what} failed (rc={rc}): {lib.rdrf_last_error().decode()}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RdrfError("rodynrf ops run on the MI355X only: got a CPU tensor "
+                            "(there is no CPU fallback; the oracle lives under oracle/ for tests)")
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_of(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+_ws = {}
+
+
+def workspace(device, nbytes):
+    buf = _ws.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws[device] = buf
+    return buf
+
+
+def f32c(t):
+    """contiguous fp32 view (no copy when already so)"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

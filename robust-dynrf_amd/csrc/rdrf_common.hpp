@@ -1,0 +1,457 @@
+// rdrf_common.hpp -- device-side building blocks shared by every kernel of the RoDynRF hot path.
+//
+// Design (gfx950 / CDNA4, wave64):
+//  * MLPs run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) in the TRANSPOSED form
+//        out[neuron][sample] = sum_k W[neuron][k] * in[k][sample]
+//    with i = neuron (A operand = weights), j = sample (B operand = activations).  One wave owns a
+//    tile of 32 samples; lane l = (h = l>>5, s = l&31) holds HALF of sample s' activation vector.
+//  * Canonical activation layout: element e of any per-sample vector lives in lane half
+//    h = (e>>2)&1, register slot kk = (e>>3)*4 + (e&3)  (elem_of() below is the inverse).  This is
+//    exactly the C/D layout the MFMA produces (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so the
+//    accumulator of one layer is consumed as the B operand of the next with NO transpose and no
+//    LDS round trip: k-step kk multiplies elements elem_of(kk,0) / elem_of(kk,1), and the weight
+//    columns are permuted to match when they are packed (rdrf_pack.hip).
+//  * VM factors are channel-last, so one bilinear tap of 4 components is one 16-byte load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rodynrf.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RDRF_HD __host__ __device__ __forceinline__
+#define RDRF_D __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// canonical layout
+// ---------------------------------------------------------------------------------------------
+RDRF_HD int elem_of(int kk, int h) { return ((kk >> 2) << 3) + (h << 2) + (kk & 3); }
+
+// ---------------------------------------------------------------------------------------------
+// input segments of the first layers: element index (our order) -> column of the reference weight
+// matrix (or -1 = structural zero).  Shared by the pack kernel and documented in DESIGN.md.
+// X0 = [xn0,xn1,xn2,t | 15 quads (sin q_2k, cos q_2k, sin q_2k+1, cos q_2k+1)], q_j = xn[j/10]*2^(j%10)
+// X1 = 8 pairs (sin t2^f, cos t2^f)
+// ---------------------------------------------------------------------------------------------
+enum SegId {
+  SEG_IDENT = 0,     // hidden layer / plain feature block: e -> e (bounded by in_dim)
+  SEG_WARP3_X0,      // layer3 (64,93): [xn3, sin30, cos30, tout30]
+  SEG_WARP3_T,       // tout block -> cols 63..92
+  SEG_DEN1_X0,       // density/blending layer1 (64,152): [feat72, xn3, sin30, cos30, t, sin8, cos8]
+  SEG_DEN1_X1,
+  SEG_RGB1_F,        // dyn rgb layer1 (128,107): [feat27, xn3, sin30, cos30, t, sin8, cos8]
+  SEG_RGB1_X0,
+  SEG_RGB1_X1,
+  SEG_STAT1_F_FEA,   // static MLP_Fea layer1 (128,138): [feat27, view3, sin54, cos54]
+  SEG_STAT1_P_FEA,
+  SEG_STAT1_F_TE,    // static MLP_Fea_TimeEmbedding layer1 (128,135): [feat27, sin54, cos54]
+  SEG_STAT1_P_TE,
+  SEG_SF_X,          // scene flow layer0 (64,36): [xn3, sin12, cos12, t, sin4, cos4]
+  SEG_COUNT
+};
+
+RDRF_HD int x0_col(int e, int base_xn, int base_sin, int base_cos, int col_t) {
+  if (e < 3) return base_xn + e;
+  if (e == 3) return col_t;
+  int k = (e - 4) >> 2, m = (e - 4) & 3;
+  int j = 2 * k + (m >> 1);
+  if (j >= 30) return -1;
+  return ((m & 1) ? base_cos : base_sin) + j;
+}
+
+RDRF_HD int seg_imap(int seg, int e, int in_dim) {
+  switch (seg) {
+    case SEG_IDENT: return e < in_dim ? e : -1;
+    case SEG_WARP3_X0: return e < 64 ? x0_col(e, 0, 3, 33, -1) : -1;
+    case SEG_WARP3_T: return e < 30 ? 63 + e : -1;
+    case SEG_DEN1_X0: return e < 64 ? x0_col(e, 72, 75, 105, 135) : -1;
+    case SEG_DEN1_X1: return e < 16 ? ((e & 1) ? 144 : 136) + (e >> 1) : -1;
+    case SEG_RGB1_F: return e < 27 ? e : -1;
+    case SEG_RGB1_X0: return e < 64 ? x0_col(e, 27, 30, 60, 90) : -1;
+    case SEG_RGB1_X1: return e < 16 ? ((e & 1) ? 99 : 91) + (e >> 1) : -1;
+    case SEG_STAT1_F_FEA: return e < 30 ? e : -1;
+    case SEG_STAT1_F_TE: return e < 27 ? e : -1;
+    case SEG_STAT1_P_FEA:
+    case SEG_STAT1_P_TE: {
+      // PE block: lane half h, slot 4r+m holds (sin f, cos f, sin 2f, cos 2f)[m] of feature
+      // w = elem_of(r, h);  element index e = elem_of(4r+m, h) = 8r + 4h + m
+      if (e >= 128) return -1;
+      int r = e >> 3, h = (e >> 2) & 1, m = e & 3;
+      int w = elem_of(r, h);
+      if (w >= 27) return -1;
+      int base = (seg == SEG_STAT1_P_FEA) ? 30 : 27;
+      // reference order: sin(feat*2^k) at d*2+k, then cos
+      return base + ((m & 1) ? 54 : 0) + w * 2 + (m >> 1);
+    }
+    case SEG_SF_X: {
+      if (e < 3) return e;
+      if (e == 3) return 27;
+      int p = 2 * ((e - 4) >> 2) + (((e - 4) & 3) >> 1);  // pair index
+      int c = (e - 4) & 1;
+      if (p < 12) return (c ? 15 : 3) + p;
+      if (p < 16) return (c ? 32 : 28) + (p - 12);
+      return -1;
+    }
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed-weight addressing.  MFMA segment: [NBO][KK/4][64 lanes][4];  small (VALU) layer:
+// [OUT][2 halves][KK].
+// ---------------------------------------------------------------------------------------------
+RDRF_HD int pk_mfma_size(int nbo, int kk) { return nbo * kk * 64; }
+RDRF_HD int pk_small_size(int out, int kk) { return out * 2 * kk; }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA layer segment: acc[nb] += W[nb-block][seg cols] * in
+// ---------------------------------------------------------------------------------------------
+template <int NBO, int KK>
+RDRF_D void mfma_seg(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __restrict__ wp,
+                     int lane) {
+  static_assert(KK % 4 == 0, "segments are octet padded");
+  constexpr int K4 = KK / 4;
+  // explicit 1-deep software pipeline on the weight fetch: the scheduling barriers stop hipcc
+  // from hoisting every load of the (fully unrolled) layer to the top and spilling.
+  f32x4 wc[NBO], wn[NBO];
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) wc[nb] = *(const f32x4*)(wp + (((nb * K4) * 64 + lane) << 2));
+#pragma unroll
+  for (int k4 = 0; k4 < K4; ++k4) {
+    if (k4 + 1 < K4) {
+#pragma unroll
+      for (int nb = 0; nb < NBO; ++nb)
+        wn[nb] = *(const f32x4*)(wp + (((nb * K4 + k4 + 1) * 64 + lane) << 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < NBO; ++nb) {
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[nb].x, in[k4 * 4 + 0], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[nb].y, in[k4 * 4 + 1], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[nb].z, in[k4 * 4 + 2], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[nb].w, in[k4 * 4 + 3], acc[nb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k4 + 1 < K4) {
+#pragma unroll
+      for (int nb = 0; nb < NBO; ++nb) wc[nb] = wn[nb];
+    }
+  }
+}
+
+// accumulator init from a PACKED bias ([2 halves][NBO*16] in canonical order; nullptr = zero)
+template <int NBO>
+RDRF_D void acc_bias(f32x16 (&acc)[NBO], const float* __restrict__ bpk, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (bpk != nullptr) v = *(const f32x4*)(bpk + h * (NBO * 16) + nb * 16 + r4 * 4);
+      acc[nb][r4 * 4 + 0] = v.x; acc[nb][r4 * 4 + 1] = v.y;
+      acc[nb][r4 * 4 + 2] = v.z; acc[nb][r4 * 4 + 3] = v.w;
+    }
+}
+
+// cooperative copy of one kernel's weight image into LDS
+RDRF_D void lds_fill(float* __restrict__ lds, const float* __restrict__ src, int nfloats) {
+  for (int i = threadIdx.x * 4; i < nfloats; i += blockDim.x * 4)
+    *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
+  __syncthreads();
+}
+
+template <int NBO>
+RDRF_D void acc_relu(float (&out)[NBO * 16], const f32x16 (&acc)[NBO]) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[nb * 16 + r] = fmaxf(acc[nb][r], 0.0f);
+}
+
+template <int NBO>
+RDRF_D void acc_copy(float (&out)[NBO * 16], const f32x16 (&acc)[NBO]) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[nb * 16 + r] = acc[nb][r];
+}
+
+// small output layer on the VALU: returns sum_e W[o][e]*in[e] over BOTH lane halves (no bias)
+template <int KK>
+RDRF_D float dot_small(const float (&in)[KK], const float* __restrict__ ws /* [2][KK] */, int h) {
+  const float* w = ws + h * KK;
+  float a = 0.f;
+#pragma unroll
+  for (int k4 = 0; k4 < KK / 4; ++k4) {
+    f32x4 v = *(const f32x4*)(w + k4 * 4);
+    a = fmaf(v.x, in[k4 * 4 + 0], a);
+    a = fmaf(v.y, in[k4 * 4 + 1], a);
+    a = fmaf(v.z, in[k4 * 4 + 2], a);
+    a = fmaf(v.w, in[k4 * 4 + 3], a);
+  }
+  return a + __shfl_xor(a, 32, 64);
+}
+
+// ---------------------------------------------------------------------------------------------
+// coordinates.  Written with contraction OFF so that they round exactly like the reference's
+// separate ATen ops (models/tensorBase.py:425-433): valid / app masks depend on these bits.
+// ---------------------------------------------------------------------------------------------
+struct Box {
+  float lo[3], hi[3], inv[3];
+};
+
+RDRF_D float norm_c(float x, float lo, float inv) {
+#pragma clang fp contract(off)
+  float a = x - lo;
+  float b = a * inv;
+  return b - 1.0f;
+}
+RDRF_D float unnorm_c(float xn, float lo, float inv) {
+#pragma clang fp contract(off)
+  float a = xn + 1.0f;
+  float b = a / inv;
+  return b + lo;
+}
+RDRF_D float mul_add_nc(float a, float b, float c) {  // a*b + c, two roundings
+#pragma clang fp contract(off)
+  float m = a * b;
+  return m + c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VM gather: one quad (4 consecutive components) of plane_tap * line_tap, align_corners=True,
+// zero padding, stride level `level` (sub-array plane[::s, ::s], s = 1<<level), following
+// models/tensoRF.py:118-154 / 646-723 and ATen's grid_sampler_2d.
+// ---------------------------------------------------------------------------------------------
+struct Tap1 {
+  int i0;
+  float w0, w1;
+  bool ok0, ok1;
+};
+RDRF_D Tap1 tap1d(float c, int Ls) {
+#pragma clang fp contract(off)
+  Tap1 t;
+  float f = ((c + 1.0f) / 2.0f) * (float)(Ls - 1);
+  float fl = floorf(f);
+  t.w1 = f - fl;
+  t.w0 = (fl + 1.0f) - f;
+  // clamp before the int conversion so wild coordinates cannot overflow
+  float flc = fminf(fmaxf(fl, -2.0f), (float)Ls + 1.0f);
+  t.i0 = (int)flc;
+  t.ok0 = (fl >= 0.0f) && (fl <= (float)(Ls - 1));
+  t.ok1 = (fl >= -1.0f) && (fl <= (float)(Ls - 2));
+  return t;
+}
+
+template <int C0Q, int C1Q>
+struct QuadSel {
+  int level, pi, q, C;
+};
+template <int C0Q, int C1Q>
+RDRF_D QuadSel<C0Q, C1Q> quad_sel(int g) {
+  constexpr int QPL = C0Q + 2 * C1Q;
+  QuadSel<C0Q, C1Q> s;
+  s.level = g / QPL;
+  int w = g - s.level * QPL;
+  s.pi = w < C0Q ? 0 : (w < C0Q + C1Q ? 1 : 2);
+  s.q = w - (s.pi == 0 ? 0 : (s.pi == 1 ? C0Q : C0Q + C1Q));
+  s.C = 4 * (s.pi == 0 ? C0Q : C1Q);
+  return s;
+}
+
+struct QuadTaps {  // everything the backward needs as well
+  f32x4 pv;        // interpolated plane quad
+  f32x4 lv;        // interpolated line quad
+};
+
+RDRF_D f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+
+template <int C0Q, int C1Q>
+RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, float x2) {
+  QuadSel<C0Q, C1Q> s = quad_sel<C0Q, C1Q>(g);
+  const int pi = s.pi;
+  const float cx = pi == 2 ? x1 : x0;
+  const float cy = pi == 0 ? x1 : x2;
+  const float cl = pi == 0 ? x2 : (pi == 1 ? x1 : x0);
+  const float* P = pi == 0 ? vm.plane[0] : (pi == 1 ? vm.plane[1] : vm.plane[2]);
+  const float* Lp = pi == 0 ? vm.line[0] : (pi == 1 ? vm.line[1] : vm.line[2]);
+  const int H = pi == 0 ? vm.H[0] : (pi == 1 ? vm.H[1] : vm.H[2]);
+  const int W = pi == 0 ? vm.W[0] : (pi == 1 ? vm.W[1] : vm.W[2]);
+  const int L = pi == 0 ? vm.L[0] : (pi == 1 ? vm.L[1] : vm.L[2]);
+  const int lv = s.level, st = 1 << lv;
+  const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
+  Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
+  const int C = s.C, qo = 4 * s.q;
+  QuadTaps r;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int xa = tx.i0 << lv, xb = (tx.i0 + 1) << lv, ya = ty.i0 << lv, yb = (ty.i0 + 1) << lv;
+    if (ty.ok0 && tx.ok0) acc += ld4(P + (size_t)(ya * W + xa) * C + qo) * (tx.w0 * ty.w0);
+    if (ty.ok0 && tx.ok1) acc += ld4(P + (size_t)(ya * W + xb) * C + qo) * (tx.w1 * ty.w0);
+    if (ty.ok1 && tx.ok0) acc += ld4(P + (size_t)(yb * W + xa) * C + qo) * (tx.w0 * ty.w1);
+    if (ty.ok1 && tx.ok1) acc += ld4(P + (size_t)(yb * W + xb) * C + qo) * (tx.w1 * ty.w1);
+  }
+  r.pv = acc;
+  f32x4 l = {0.f, 0.f, 0.f, 0.f};
+  if (tl.ok0) l += ld4(Lp + (size_t)(tl.i0 << lv) * C + qo) * tl.w0;
+  if (tl.ok1) l += ld4(Lp + (size_t)((tl.i0 + 1) << lv) * C + qo) * tl.w1;
+  r.lv = l;
+  return r;
+}
+
+template <int C0Q, int C1Q>
+RDRF_D f32x4 gather_quad(const RdrfVM& vm, int g, float x0, float x1, float x2) {
+  QuadTaps t = gather_quad_taps<C0Q, C1Q>(vm, g, x0, x1, x2);
+  return t.pv * t.lv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared input blocks X0 (xn, t, PE10(xn)) and X1 (PE8(t)) in canonical layout
+// (models/tensorBase.py:13-19 positional_encoding: q[d*F+k] = p[d]*2^k; [sin(q), cos(q)])
+// ---------------------------------------------------------------------------------------------
+RDRF_D void fill_x0(float (&X0)[32], float xn0, float xn1, float xn2, float t, int h) {
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o == 0 && h == 0) {
+      X0[0] = xn0; X0[1] = xn1; X0[2] = xn2; X0[3] = t;
+    } else {
+      const int k = 2 * o + h - 1;  // quad index 0..14
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int j = 2 * k + p;
+        const int d = j / 10, f = j - d * 10;
+        const float x = d == 0 ? xn0 : (d == 1 ? xn1 : xn2);
+        float sv, cv;
+        sincosf(ldexpf(x, f), &sv, &cv);
+        X0[o * 4 + 2 * p] = sv;
+        X0[o * 4 + 2 * p + 1] = cv;
+      }
+    }
+  }
+}
+RDRF_D void fill_x1(float (&X1)[8], float t, int h) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int f = 4 * o + 2 * h + p;
+      float sv, cv;
+      sincosf(ldexpf(t, f), &sv, &cv);
+      X1[o * 4 + 2 * p] = sv;
+      X1[o * 4 + 2 * p + 1] = cv;
+    }
+}
+
+// raw2alpha's per-sample factor 1 - alpha + 1e-10 (models/tensorBase.py:28, renderer.py:220)
+RDRF_D float one_minus_alpha_eps(float alpha) {
+#pragma clang fp contract(off)
+  float a = 1.0f - alpha;
+  return a + 1e-10f;
+}
+RDRF_D float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+RDRF_D float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // F.softplus, beta 1, threshold 20
+
+// inclusive product scan over each 32-lane half (both halves carry identical data)
+RDRF_D float scan_mul32(float v, int s) {
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    float o = __shfl_up(v, d, 32);
+    if (s >= d) v *= o;
+  }
+  return v;
+}
+RDRF_D float scan_mul64(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+RDRF_D float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed-weight plan: constant offsets (floats) into the pack buffer.  Dimensions are fixed by
+// the architecture every shipped config uses (featureC=128, app_dim=27, comps 16/4/4, 48/12/12).
+// ---------------------------------------------------------------------------------------------
+namespace pk {
+// Every kernel's weights (MFMA fragments, small layers, biases) form ONE contiguous region of the
+// pack buffer, copied verbatim into LDS by the persistent workgroup that uses it.
+// ---- dynamic field, density/blending phase (k_dyn_density) --------------------------------
+constexpr int K1_W3_X0 = 0;                                   // 2 x 32
+constexpr int K1_W3_T = K1_W3_X0 + 2 * 32 * 64;               // 2 x 16
+constexpr int K1_W4 = K1_W3_T + 2 * 16 * 64;                  // 2 x 32
+constexpr int K1_W5 = K1_W4 + 2 * 32 * 64;                    // small 3 x 32
+constexpr int K1_DEN1_F = K1_W5 + 3 * 2 * 32;                 // 2 x 36
+constexpr int K1_DEN1_X0 = K1_DEN1_F + 2 * 36 * 64;           // 2 x 32
+constexpr int K1_DEN1_X1 = K1_DEN1_X0 + 2 * 32 * 64;          // 2 x 8
+constexpr int K1_DEN2 = K1_DEN1_X1 + 2 * 8 * 64;              // small 1 x 32
+constexpr int K1_BLE1_F = K1_DEN2 + 1 * 2 * 32;
+constexpr int K1_BLE1_X0 = K1_BLE1_F + 2 * 36 * 64;
+constexpr int K1_BLE1_X1 = K1_BLE1_X0 + 2 * 32 * 64;
+constexpr int K1_BLE2 = K1_BLE1_X1 + 2 * 8 * 64;
+constexpr int K1_B3 = K1_BLE2 + 1 * 2 * 32;                   // biases [2][32]
+constexpr int K1_B4 = K1_B3 + 64;
+constexpr int K1_BD1 = K1_B4 + 64;
+constexpr int K1_BB1 = K1_BD1 + 64;
+constexpr int K1_SIZE = K1_BB1 + 64;
+// ---- dynamic field, appearance phase (k_dyn_app) -------------------------------------------
+constexpr int K3_BASIS = 0;                                   // 1 x 108
+constexpr int K3_RGB1_F = K3_BASIS + 1 * 108 * 64;            // 4 x 16
+constexpr int K3_RGB1_X0 = K3_RGB1_F + 4 * 16 * 64;           // 4 x 32
+constexpr int K3_RGB1_X1 = K3_RGB1_X0 + 4 * 32 * 64;          // 4 x 8
+constexpr int K3_RGB2 = K3_RGB1_X1 + 4 * 8 * 64;              // 4 x 64
+constexpr int K3_RGBV = K3_RGB2 + 4 * 64 * 64;                // small 3 x 64
+constexpr int K3_B1 = K3_RGBV + 3 * 2 * 64;                   // biases [2][64]
+constexpr int K3_B2 = K3_B1 + 128;
+constexpr int K3_SIZE = K3_B2 + 128;
+// ---- scene flow (k_scene_flow) -------------------------------------------------------------
+constexpr int SF_W0 = 0;                                      // 2 x 20
+constexpr int SF_W2 = SF_W0 + 2 * 20 * 64;                    // 2 x 32
+constexpr int SF_W4 = SF_W2 + 2 * 32 * 64;
+constexpr int SF_W6 = SF_W4 + 2 * 32 * 64;                    // small 6 x 32
+constexpr int SF_B0 = SF_W6 + 6 * 2 * 32;
+constexpr int SF_B2 = SF_B0 + 64;
+constexpr int SF_B4 = SF_B2 + 64;
+constexpr int SF_SIZE = SF_B4 + 64;
+// ---- static field, appearance phase (k_static_app) -----------------------------------------
+constexpr int S3_BASIS = 0;                                   // 1 x 36
+constexpr int S3_W1_F = S3_BASIS + 1 * 36 * 64;               // 4 x 16
+constexpr int S3_W1_P = S3_W1_F + 4 * 16 * 64;                // 4 x 64
+constexpr int S3_W2 = S3_W1_P + 4 * 64 * 64;                  // 4 x 64
+constexpr int S3_W3 = S3_W2 + 4 * 64 * 64;                    // small 3 x 64
+constexpr int S3_B1 = S3_W3 + 3 * 2 * 64;
+constexpr int S3_B2 = S3_B1 + 128;
+constexpr int S3_SIZE = S3_B2 + 128;
+// region bases inside the pack buffer (floats)
+constexpr int REG_K1 = 0;
+constexpr int REG_K3 = REG_K1 + K1_SIZE;
+constexpr int REG_SF = REG_K3 + K3_SIZE;
+constexpr int REG_DYN_END = REG_SF + SF_SIZE;
+constexpr int REG_S3 = 0;
+constexpr int REG_STAT_END = REG_S3 + S3_SIZE;
+static_assert(K1_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
+              "each kernel's weight image must fit the 160 KiB LDS");
+}  // namespace pk
+
+// descriptor of one packing job (rdrf_pack.hip)
+struct PackJob {
+  const float* src;  // natural [out_dim][ld]
+  int ld, out_dim, in_dim;
+  int seg;    // SegId of the input segment
+  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias
+  int nb;     // NBO (mode 0) / OUT (mode 1) / NBI (mode 2)
+  int kk;     // k-steps of the segment (mode 0/1) or of the OUT dimension (mode 2)
+  int dst;    // float offset into the pack buffer
+};
+#define RDRF_MAX_PACK_JOBS 48
+struct PackJobs {
+  PackJob j[RDRF_MAX_PACK_JOBS];
+  int n;
+};

@@ -1,0 +1,676 @@
+// rdrf_fwd.hip -- forward kernels of the two fields (TensorBase.forward,
+// /root/reference/models/tensorBase.py:704-850) for gfx950.
+//
+//   static  field: k_static_density (wave per ray: VM gather -> sigma -> wave scan -> weight ->
+//                  app-mask compaction) ; k_static_app (32-sample MFMA tiles over the compacted
+//                  list: VM gather -> basis -> PE -> 138|135->128->128->3 MLP -> sigmoid)
+//   dynamic field: k_time_branch (per ray 17->64->30), k_dyn_density (wave per ray, 32-sample
+//                  tiles: warp MLP -> 3-stride VM gathers at the warped point -> density and
+//                  blending MLPs -> scan -> weight/compaction), k_dyn_app (MFMA tiles over the
+//                  compacted list: 216-feature gather -> basis -> 107->128->128->(131)->3)
+//   scene flow   : k_scene_flow (36->64->64->64->6, models/tensoRF.py:446-462)
+#include "rdrf_host.hpp"
+
+// ------------------------------------------------------------------------------------------------
+struct FieldArgs {
+  // inputs
+  const float* rays;
+  const float* ts;
+  const float* xyz;
+  const float* z;
+  const uint8_t* valid;
+  int N, S;
+  Box box;
+  float distance_scale, weight_thres, density_shift;
+  int act, ray_type, static_head;
+  // outputs
+  float *rgb, *sigma, *weight, *dists, *blending, *xyz_prime;
+  // workspace
+  const float* pk;   // packed weights
+  float* tout;       // [N][32]
+  float* xw;         // [N][S][3] warped normalised coordinate
+  int* list;         // compacted sample ids
+  int* counter;
+};
+
+struct StaticW {
+  RdrfVM density, app;
+  const float *b1, *b2, *b3, *w3;
+};
+struct DynW {
+  RdrfVM density, blending, app;
+  const float *l1w, *l1b, *l2w, *l2b;
+  const float *l3b, *l4b, *l5b, *db1, *db2, *bb1, *bb2, *rb1, *rb2, *rbv, *rwv;
+  const float *sfb0, *sfb2, *sfb4, *sfb6;
+};
+
+RDRF_D float density_act(float f, int act, float shift) {
+  return act == RDRF_ACT_RELU ? fmaxf(f, 0.0f) : softplusf_(f + shift);
+}
+
+RDRF_D float ray_norm(const float* rays, int n, int ray_type, float& vx, float& vy, float& vz) {
+  vx = rays[n * 6 + 3];
+  vy = rays[n * 6 + 4];
+  vz = rays[n * 6 + 5];
+  float nrm = 1.0f;
+  if (ray_type != RDRF_RAY_OTHER) {
+    nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+    vx /= nrm;
+    vy /= nrm;
+    vz /= nrm;
+  }
+  return nrm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// static field, density phase: one wave per ray, one lane per sample (64 per step)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x;
+  if (n >= a.N) return;
+  float vx, vy, vz;
+  const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float carry = 1.0f;
+  for (int j0 = 0; j0 < a.S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool act = j < a.S;
+    const int idx = n * a.S + (act ? j : 0);
+    const bool vld = act && a.valid[idx] != 0;
+    float f = 0.0f;
+    if (vld) {
+      const float x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) {  // quads 0..3 plane 0, 4 plane 1, 5 plane 2
+        float sp = 0.f;
+#pragma unroll
+        for (int g = (pi == 0 ? 0 : 3 + pi); g < (pi == 0 ? 4 : 4 + pi); ++g) {
+          f32x4 v = gather_quad<4, 1>(w.density, g, x0, x1, x2);
+          sp += v.x + v.y + v.z + v.w;
+        }
+        f += sp;
+      }
+    }
+    const float sigma = vld ? density_act(f, a.act, a.density_shift) : 0.0f;
+    const float zj = act ? a.z[idx] : 0.f;
+    const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+    const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+    const float alpha = 1.0f - expf(-sigma * ds);
+    const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+    const float incl = scan_mul64(p, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float T = carry * excl;
+    const float wt = alpha * T;
+    carry *= __shfl(incl, 63, 64);
+    const bool m = act && wt > a.weight_thres;
+    if (act) {
+      a.sigma[idx] = sigma;
+      a.weight[idx] = wt;
+      a.dists[idx] = ds;
+    }
+    const unsigned long long bal = __ballot(m);
+    if (bal) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// static field, appearance phase: 32-sample MFMA tiles over the compacted list
+// ------------------------------------------------------------------------------------------------
+template <int HEAD>
+__global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
+  __shared__ __attribute__((aligned(16))) float lds[pk::S3_SIZE];
+  lds_fill(lds, a.pk + pk::REG_S3, pk::S3_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = *a.counter;
+  const int ntiles = (count + 31) >> 5;
+  const float* pkw = lds;
+  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < count;
+    const int idx = act ? a.list[li] : 0;
+    const int n = idx / a.S;
+    float vx, vy, vz;
+    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    const float x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+    const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+    const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    float G[36];
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, x0, x1, x2);
+      G[o * 4 + 0] = v.x; G[o * 4 + 1] = v.y; G[o * 4 + 2] = v.z; G[o * 4 + 3] = v.w;
+    }
+    f32x16 accF[1];
+    acc_bias<1>(accF, nullptr, h);
+    mfma_seg<1, 36>(accF, G, pkw + pk::S3_BASIS, lane);
+    float F[16];
+    acc_copy<1>(F, accF);
+    float P[64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s1, c1, s2, c2;
+      sincosf(F[r], &s1, &c1);
+      sincosf(F[r] * 2.0f, &s2, &c2);
+      P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+    }
+    if (HEAD == RDRF_HEAD_MLP_FEA) {  // viewdirs ride in the pad slots 27..29 of the feature block
+      if (h == 0) F[15] = vx;
+      else { F[12] = vy; F[13] = vz; }
+    }
+    f32x16 acc[4];
+    acc_bias<4>(acc, pkw + pk::S3_B1, h);
+    mfma_seg<4, 16>(acc, F, pkw + pk::S3_W1_F, lane);
+    mfma_seg<4, 64>(acc, P, pkw + pk::S3_W1_P, lane);
+    float H1[64];
+    acc_relu<4>(H1, acc);
+    acc_bias<4>(acc, pkw + pk::S3_B2, h);
+    mfma_seg<4, 64>(acc, H1, pkw + pk::S3_W2, lane);
+    acc_relu<4>(H1, acc);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small<64>(H1, pkw + pk::S3_W3 + o * 128, h) + w.b3[o];
+      if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING)
+        v += w.w3[o * 131 + 128] * vx + w.w3[o * 131 + 129] * vy + w.w3[o * 131 + 130] * vz;
+      if (act && h == 0) a.rgb[(size_t)idx * 3 + o] = sigmoidf_(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic field: per-ray time branch  [t, PE8(t)] -> 64 -> relu -> 30  (models/tensoRF.py:522-525)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_time_branch(const float* __restrict__ ts, DynW w, int N, float* __restrict__ tout) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float t = ts[n];
+  float tin[17];
+  tin[0] = t;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) sincosf(ldexpf(t, f), &tin[1 + f], &tin[9 + f]);
+  float out[30];
+#pragma unroll
+  for (int o = 0; o < 30; ++o) out[o] = w.l2b[o];
+  for (int k = 0; k < 64; ++k) {  // hidden neuron k, folded straight into the 30 outputs
+    float hk = w.l1b[k];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) hk = fmaf(w.l1w[k * 17 + i], tin[i], hk);
+    hk = fmaxf(hk, 0.0f);
+#pragma unroll
+    for (int o = 0; o < 30; ++o) out[o] = fmaf(w.l2w[o * 64 + k], hk, out[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < 30; ++o) tout[n * 32 + o] = out[o];
+  tout[n * 32 + 30] = 0.f;
+  tout[n * 32 + 31] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic field, density/blending phase: one wave per ray, tiles of 32 samples, 2 lanes / sample
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
+  __shared__ __attribute__((aligned(16))) float lds[pk::K1_SIZE];
+  lds_fill(lds, a.pk + pk::REG_K1, pk::K1_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const float* pkw = lds;
+  for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
+  const float t = a.ts[n];
+  float vx, vy, vz;
+  const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float T[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = ld4(a.tout + n * 32 + 8 * q + 4 * h);
+    T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
+  }
+  float X1[8];
+  fill_x1(X1, t, h);
+  float carry = 1.0f;
+  for (int j0 = 0; j0 < a.S; j0 += 32) {
+    const int j = j0 + s;
+    const bool act = j < a.S;
+    const int idx = n * a.S + (act ? j : 0);
+    const bool vld = act && a.valid[idx] != 0;
+    const float px = a.xyz[idx * 3 + 0], py = a.xyz[idx * 3 + 1], pz = a.xyz[idx * 3 + 2];
+    const float xn0 = norm_c(px, a.box.lo[0], a.box.inv[0]);
+    const float xn1 = norm_c(py, a.box.lo[1], a.box.inv[1]);
+    const float xn2 = norm_c(pz, a.box.lo[2], a.box.inv[2]);
+    float X0[32];
+    fill_x0(X0, xn0, xn1, xn2, t, h);
+    // ---- warp MLP: [xn, PE10(xn), tout] -> 64 -> 64 -> 3  (models/tensoRF.py:521-541)
+    float d0, d1, d2;
+    {
+      f32x16 acc[2];
+      acc_bias<2>(acc, pkw + pk::K1_B3, h);
+      mfma_seg<2, 32>(acc, X0, pkw + pk::K1_W3_X0, lane);
+      mfma_seg<2, 16>(acc, T, pkw + pk::K1_W3_T, lane);
+      float H3[32];
+      acc_relu<2>(H3, acc);
+      acc_bias<2>(acc, pkw + pk::K1_B4, h);
+      mfma_seg<2, 32>(acc, H3, pkw + pk::K1_W4, lane);
+      acc_relu<2>(H3, acc);
+      d0 = dot_small<32>(H3, pkw + pk::K1_W5 + 0 * 64, h) + w.l5b[0];
+      d1 = dot_small<32>(H3, pkw + pk::K1_W5 + 1 * 64, h) + w.l5b[1];
+      d2 = dot_small<32>(H3, pkw + pk::K1_W5 + 2 * 64, h) + w.l5b[2];
+    }
+    // compute_* warp the un-normalised round trip of xn (models/tensoRF.py:647-649)
+    const float xw0 = norm_c(unnorm_c(xn0, a.box.lo[0], a.box.inv[0]) + d0, a.box.lo[0], a.box.inv[0]);
+    const float xw1 = norm_c(unnorm_c(xn1, a.box.lo[1], a.box.inv[1]) + d1, a.box.lo[1], a.box.inv[1]);
+    const float xw2 = norm_c(unnorm_c(xn2, a.box.lo[2], a.box.inv[2]) + d2, a.box.lo[2], a.box.inv[2]);
+    if (act && h == 0) {
+      a.xyz_prime[(size_t)idx * 3 + 0] = px + d0;
+      a.xyz_prime[(size_t)idx * 3 + 1] = py + d1;
+      a.xyz_prime[(size_t)idx * 3 + 2] = pz + d2;
+      a.xw[(size_t)idx * 3 + 0] = xw0;
+      a.xw[(size_t)idx * 3 + 1] = xw1;
+      a.xw[(size_t)idx * 3 + 2] = xw2;
+    }
+    // ---- density and blending heads: 3-stride VM features (72) + X0 + X1 -> 64 -> 1
+    float fd, fb;
+    {
+      float Fv[36];
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.density, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
+      f32x16 acc[2];
+      acc_bias<2>(acc, pkw + pk::K1_BD1, h);
+      mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_DEN1_F, lane);
+      mfma_seg<2, 32>(acc, X0, pkw + pk::K1_DEN1_X0, lane);
+      mfma_seg<2, 8>(acc, X1, pkw + pk::K1_DEN1_X1, lane);
+      float Hd[32];
+      acc_relu<2>(Hd, acc);
+      fd = dot_small<32>(Hd, pkw + pk::K1_DEN2, h) + w.db2[0];
+    }
+    {
+      float Fv[36];
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.blending, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
+      f32x16 acc[2];
+      acc_bias<2>(acc, pkw + pk::K1_BB1, h);
+      mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_BLE1_F, lane);
+      mfma_seg<2, 32>(acc, X0, pkw + pk::K1_BLE1_X0, lane);
+      mfma_seg<2, 8>(acc, X1, pkw + pk::K1_BLE1_X1, lane);
+      float Hd[32];
+      acc_relu<2>(Hd, acc);
+      fb = dot_small<32>(Hd, pkw + pk::K1_BLE2, h) + w.bb2[0];
+    }
+    const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.0f;
+    const float blend = vld ? sigmoidf_(fb) : 0.0f;
+    const float zj = act ? a.z[idx] : 0.f;
+    const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+    const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+    const float alpha = 1.0f - expf(-sigma * ds);
+    const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+    const float incl = scan_mul32(p, s);
+    float excl = __shfl_up(incl, 1, 32);
+    if (s == 0) excl = 1.0f;
+    const float Tr = carry * excl;
+    const float wt = alpha * Tr;
+    carry *= __shfl(incl, 31, 32);
+    const bool m = act && h == 0 && wt > a.weight_thres;
+    if (act && h == 0) {
+      a.sigma[idx] = sigma;
+      a.weight[idx] = wt;
+      a.dists[idx] = ds;
+      a.blending[idx] = blend;
+    }
+    const unsigned long long bal = __ballot(m);
+    if (bal) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+    }
+  }
+  }  // ray loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic field, appearance phase (models/tensoRF.py:734-811 + MLPRender_Fea_late_view)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
+  __shared__ __attribute__((aligned(16))) float lds[pk::K3_SIZE];
+  lds_fill(lds, a.pk + pk::REG_K3, pk::K3_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = *a.counter;
+  const int ntiles = (count + 31) >> 5;
+  const float* pkw = lds;
+  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < count;
+    const int idx = act ? a.list[li] : 0;
+    const int n = idx / a.S;
+    const float t = a.ts[n];
+    float vx, vy, vz;
+    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    const float xn0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+    const float xn1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+    const float xn2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    const float xw0 = a.xw[(size_t)idx * 3 + 0], xw1 = a.xw[(size_t)idx * 3 + 1],
+                xw2 = a.xw[(size_t)idx * 3 + 2];
+    float F[16];
+    {
+      float A[108];
+#pragma unroll
+      for (int o = 0; o < 27; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, xw0, xw1, xw2);
+        A[o * 4 + 0] = v.x; A[o * 4 + 1] = v.y; A[o * 4 + 2] = v.z; A[o * 4 + 3] = v.w;
+      }
+      f32x16 accF[1];
+      acc_bias<1>(accF, nullptr, h);
+      mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
+      acc_copy<1>(F, accF);
+    }
+    float X0[32], X1[8];
+    fill_x0(X0, xn0, xn1, xn2, t, h);
+    fill_x1(X1, t, h);
+    f32x16 acc[4];
+    acc_bias<4>(acc, pkw + pk::K3_B1, h);
+    mfma_seg<4, 16>(acc, F, pkw + pk::K3_RGB1_F, lane);
+    mfma_seg<4, 32>(acc, X0, pkw + pk::K3_RGB1_X0, lane);
+    mfma_seg<4, 8>(acc, X1, pkw + pk::K3_RGB1_X1, lane);
+    float H1[64];
+    acc_relu<4>(H1, acc);
+    acc_bias<4>(acc, pkw + pk::K3_B2, h);
+    mfma_seg<4, 64>(acc, H1, pkw + pk::K3_RGB2, lane);
+    acc_relu<4>(H1, acc);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small<64>(H1, pkw + pk::K3_RGBV + o * 128, h) + w.rbv[o];
+      v += w.rwv[o * 131 + 128] * vx + w.rwv[o * 131 + 129] * vy + w.rwv[o * 131 + 130] * vz;
+      if (act && h == 0) a.rgb[(size_t)idx * 3 + o] = sigmoidf_(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene flow MLP over all N*S samples (models/tensoRF.py:446-462)
+// ------------------------------------------------------------------------------------------------
+RDRF_D void fill_sf_x(float (&X)[20], float xn0, float xn1, float xn2, float t, int h) {
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    if (o == 0 && h == 0) {
+      X[0] = xn0; X[1] = xn1; X[2] = xn2; X[3] = t;
+    } else {
+      const int k = 2 * o + h - 1;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pr = 2 * k + p;
+        float sv = 0.f, cv = 0.f;
+        if (pr < 16) {
+          const int d = pr >> 2, f = pr & 3;
+          const float x = pr < 12 ? (d == 0 ? xn0 : (d == 1 ? xn1 : xn2)) : t;
+          sincosf(ldexpf(x, f), &sv, &cv);
+        }
+        X[o * 4 + 2 * p] = sv;
+        X[o * 4 + 2 * p + 1] = cv;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_scene_flow(const float* __restrict__ pts,
+                                                   const float* __restrict__ ts, int N, int S,
+                                                   Box box, const float* __restrict__ pkg, DynW w,
+                                                   float* __restrict__ sf_f,
+                                                   float* __restrict__ sf_b) {
+  __shared__ __attribute__((aligned(16))) float lds[pk::SF_SIZE];
+  lds_fill(lds, pkg + pk::REG_SF, pk::SF_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const float* pkw = lds;
+  const int total = N * S;
+  const int ntiles = (total + 31) >> 5;
+  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < total;
+    const int idx = act ? li : 0;
+    const float t = ts[idx / S];
+    const float xn0 = norm_c(pts[(size_t)idx * 3 + 0], box.lo[0], box.inv[0]);
+    const float xn1 = norm_c(pts[(size_t)idx * 3 + 1], box.lo[1], box.inv[1]);
+    const float xn2 = norm_c(pts[(size_t)idx * 3 + 2], box.lo[2], box.inv[2]);
+    float X[20];
+    fill_sf_x(X, xn0, xn1, xn2, t, h);
+    f32x16 acc[2];
+    acc_bias<2>(acc, pkw + pk::SF_B0, h);
+    mfma_seg<2, 20>(acc, X, pkw + pk::SF_W0, lane);
+    float H[32];
+    acc_relu<2>(H, acc);
+    acc_bias<2>(acc, pkw + pk::SF_B2, h);
+    mfma_seg<2, 32>(acc, H, pkw + pk::SF_W2, lane);
+    acc_relu<2>(H, acc);
+    acc_bias<2>(acc, pkw + pk::SF_B4, h);
+    mfma_seg<2, 32>(acc, H, pkw + pk::SF_W4, lane);
+    acc_relu<2>(H, acc);
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+      const float v = dot_small<32>(H, pkw + pk::SF_W6 + o * 64, h) + w.sfb6[o];
+      if (act && h == 0) {
+        if (o < 3) sf_f[(size_t)idx * 3 + o] = v;
+        else sf_b[(size_t)idx * 3 + (o - 3)] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void fill_common(FieldArgs& a, const RdrfFieldCfg* cfg, const float* rays, const float* ts,
+                        const float* xyz, const float* z, const uint8_t* valid, int N, int S) {
+  memset(&a, 0, sizeof(a));
+  a.rays = rays; a.ts = ts; a.xyz = xyz; a.z = z; a.valid = valid;
+  a.N = N; a.S = S;
+  a.box = make_box(cfg);
+  a.distance_scale = cfg->distance_scale;
+  a.weight_thres = cfg->weight_thres;
+  a.density_shift = cfg->density_shift;
+  a.act = cfg->act;
+  a.ray_type = cfg->ray_type;
+  a.static_head = cfg->static_head;
+}
+
+void dyn_pack_jobs_fwd(PackJobs& J, const RdrfDynamicParams* P) {
+  using namespace pk;
+  J.n = 0;
+  const int k1 = REG_K1, k3 = REG_K3, sf = REG_SF;
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_X0, 0, 2, 32, k1 + K1_W3_X0);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, 0, 2, 16, k1 + K1_W3_T);
+  pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, 0, 2, 32, k1 + K1_W4);
+  pack_add(J, P->l5w, 64, 3, 64, SEG_IDENT, 1, 3, 32, k1 + K1_W5);
+  pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, 0, 2, 36, k1 + K1_DEN1_F);
+  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, 0, 2, 32, k1 + K1_DEN1_X0);
+  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X1, 0, 2, 8, k1 + K1_DEN1_X1);
+  pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_DEN2);
+  pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, 0, 2, 36, k1 + K1_BLE1_F);
+  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, 0, 2, 32, k1 + K1_BLE1_X0);
+  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X1, 0, 2, 8, k1 + K1_BLE1_X1);
+  pack_add(J, P->bw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_BLE2);
+  pack_add(J, P->l3b, 0, 64, 0, 0, 3, 0, 32, k1 + K1_B3);
+  pack_add(J, P->l4b, 0, 64, 0, 0, 3, 0, 32, k1 + K1_B4);
+  pack_add(J, P->db1, 0, 64, 0, 0, 3, 0, 32, k1 + K1_BD1);
+  pack_add(J, P->bb1, 0, 64, 0, 0, 3, 0, 32, k1 + K1_BB1);
+  pack_add(J, P->basis, 216, 27, 216, SEG_IDENT, 0, 1, 108, k3 + K3_BASIS);
+  pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 0, 4, 16, k3 + K3_RGB1_F);
+  pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_X0, 0, 4, 32, k3 + K3_RGB1_X0);
+  pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_X1, 0, 4, 8, k3 + K3_RGB1_X1);
+  pack_add(J, P->rw2, 128, 128, 128, SEG_IDENT, 0, 4, 64, k3 + K3_RGB2);
+  pack_add(J, P->rwv, 131, 3, 128, SEG_IDENT, 1, 3, 64, k3 + K3_RGBV);
+  pack_add(J, P->rb1, 0, 128, 0, 0, 3, 0, 64, k3 + K3_B1);
+  pack_add(J, P->rb2, 0, 128, 0, 0, 3, 0, 64, k3 + K3_B2);
+  pack_add(J, P->sfw[0], 36, 64, 36, SEG_SF_X, 0, 2, 20, sf + SF_W0);
+  pack_add(J, P->sfw[1], 64, 64, 64, SEG_IDENT, 0, 2, 32, sf + SF_W2);
+  pack_add(J, P->sfw[2], 64, 64, 64, SEG_IDENT, 0, 2, 32, sf + SF_W4);
+  pack_add(J, P->sfw[3], 64, 6, 64, SEG_IDENT, 1, 6, 32, sf + SF_W6);
+  pack_add(J, P->sfb[0], 0, 64, 0, 0, 3, 0, 32, sf + SF_B0);
+  pack_add(J, P->sfb[1], 0, 64, 0, 0, 3, 0, 32, sf + SF_B2);
+  pack_add(J, P->sfb[2], 0, 64, 0, 0, 3, 0, 32, sf + SF_B4);
+}
+
+void static_pack_jobs_fwd(PackJobs& J, const RdrfStaticParams* P, int head) {
+  using namespace pk;
+  J.n = 0;
+  const bool fea = head == RDRF_HEAD_MLP_FEA;
+  const int in1 = fea ? 138 : 135;
+  pack_add(J, P->basis, 72, 27, 72, SEG_IDENT, 0, 1, 36, REG_S3 + S3_BASIS);
+  pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 0, 4, 16, REG_S3 + S3_W1_F);
+  pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 0, 4, 64, REG_S3 + S3_W1_P);
+  pack_add(J, P->w2, 128, 128, 128, SEG_IDENT, 0, 4, 64, REG_S3 + S3_W2);
+  pack_add(J, P->w3, fea ? 128 : 131, 3, 128, SEG_IDENT, 1, 3, 64, REG_S3 + S3_W3);
+  pack_add(J, P->b1, 0, 128, 0, 0, 3, 0, 64, REG_S3 + S3_B1);
+  pack_add(J, P->b2, 0, 128, 0, 0, 3, 0, 64, REG_S3 + S3_B2);
+}
+
+void fill_static_w(StaticW& w, const RdrfStaticParams* P) {
+  w.density = P->density; w.app = P->app;
+  w.b1 = P->b1; w.b2 = P->b2; w.b3 = P->b3; w.w3 = P->w3;
+}
+void fill_dyn_w(DynW& w, const RdrfDynamicParams* P) {
+  w.density = P->density; w.blending = P->blending; w.app = P->app;
+  w.l1w = P->l1w; w.l1b = P->l1b; w.l2w = P->l2w; w.l2b = P->l2b;
+  w.l3b = P->l3b; w.l4b = P->l4b; w.l5b = P->l5b;
+  w.db1 = P->db1; w.db2 = P->db2; w.bb1 = P->bb1; w.bb2 = P->bb2;
+  w.rb1 = P->rb1; w.rb2 = P->rb2; w.rbv = P->rbv; w.rwv = P->rwv;
+  w.sfb0 = P->sfb[0]; w.sfb2 = P->sfb[1]; w.sfb4 = P->sfb[2]; w.sfb6 = P->sfb[3];
+}
+
+#define PACK_AREA_FLOATS (1 << 20) /* 4 MiB: forward + transposed packs of either field */
+
+extern "C" size_t rdrf_workspace_bytes(int N, int S) {
+  size_t ns = (size_t)N * (size_t)S;
+  // pack area + counter + tout + xw + list (+ slack for alignment)
+  return (size_t)PACK_AREA_FLOATS * 4 + 256 + (size_t)N * 32 * 4 + ns * 3 * 4 + ns * 4 + (1 << 12);
+}
+
+int ws_carve_fwd(FieldArgs& a, void* ws, size_t ws_bytes, int N, int S) {
+  WsCarver c(ws, ws_bytes);
+  size_t ns = (size_t)N * S;
+  a.pk = c.take<float>(PACK_AREA_FLOATS);
+  a.counter = c.take<int>(64);
+  a.tout = c.take<float>((size_t)N * 32);
+  a.xw = c.take<float>(ns * 3);
+  a.list = c.take<int>(ns);
+  RDRF_CHECK(c.ok(), -3, "workspace too small: need %zu have %zu", c.off, ws_bytes);
+  return 0;
+}
+
+// persistent launch geometry: one workgroup per CU (its LDS holds the kernel's weight image),
+// up to 8 waves per workgroup, each wave walking its own rays / tiles.
+struct Geo {
+  int grid, block;
+};
+static Geo geo_for_units(long units) {
+  Geo g;
+  const int ncu = 256;
+  int waves = (int)((units + ncu - 1) / ncu);
+  waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
+  g.block = waves * 64;
+  long blocks = (units + waves - 1) / waves;
+  g.grid = (int)(blocks < 1 ? 1 : (blocks > ncu ? ncu : blocks));
+  return g;
+}
+static Geo geo_for_tiles(int N, int S) { return geo_for_units(((long)N * S + 31) / 32); }
+
+extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
+                               const float* ts, const float* xyz, const float* z,
+                               const uint8_t* valid, int N, int S, float* rgb, float* sigma,
+                               float* weight, float* dists, void* ws, size_t ws_bytes,
+                               rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "static_fwd: bad arguments");
+  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
+             "static_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+  FieldArgs a;
+  fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
+  a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
+  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S);
+  if (rc) return rc;
+  StaticW w;
+  fill_static_w(w, P);
+  PackJobs J;
+  static_pack_jobs_fwd(J, P, cfg->static_head);
+  rc = pack_launch(J, (float*)a.pk, stream);
+  if (rc) return rc;
+  RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
+  RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
+  RDRF_LAUNCH("static_density", k_static_density, dim3(N), dim3(64), stream, a, w);
+  const Geo g = geo_for_tiles(N, S);
+  if (cfg->static_head == RDRF_HEAD_MLP_FEA)
+    RDRF_LAUNCH("static_app", k_static_app<RDRF_HEAD_MLP_FEA>, dim3(g.grid), dim3(g.block), stream,
+                a, w);
+  else
+    RDRF_LAUNCH("static_app", k_static_app<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING>, dim3(g.grid),
+                dim3(g.block), stream, a, w);
+  return 0;
+}
+
+extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg,
+                                const float* rays, const float* ts, const float* xyz,
+                                const float* z, const uint8_t* valid, int N, int S,
+                                float* blending, float* weight, float* xyz_prime, float* rgb,
+                                float* sigma, float* dists, void* ws, size_t ws_bytes,
+                                rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "dynamic_fwd: bad arguments");
+  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
+             "dynamic_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+  FieldArgs a;
+  fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
+  a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
+  a.blending = blending; a.xyz_prime = xyz_prime;
+  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S);
+  if (rc) return rc;
+  DynW w;
+  fill_dyn_w(w, P);
+  PackJobs J;
+  dyn_pack_jobs_fwd(J, P);
+  rc = pack_launch(J, (float*)a.pk, stream);
+  if (rc) return rc;
+  RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
+  RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
+  RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 63) / 64), dim3(64), stream, ts, w, N, a.tout);
+  const Geo g1 = geo_for_units(N), g3 = geo_for_tiles(N, S);
+  RDRF_LAUNCH("dyn_density", k_dyn_density, dim3(g1.grid), dim3(g1.block), stream, a, w);
+  RDRF_LAUNCH("dyn_app", k_dyn_app, dim3(g3.grid), dim3(g3.block), stream, a, w);
+  return 0;
+}
+
+extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg,
+                                   const float* pts, const float* ts, int N, int S, float* sf_f,
+                                   float* sf_b, void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "scene_flow_fwd: bad arguments");
+  FieldArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S);
+  if (rc) return rc;
+  DynW w;
+  fill_dyn_w(w, P);
+  PackJobs J;
+  dyn_pack_jobs_fwd(J, P);
+  rc = pack_launch(J, (float*)a.pk, stream);
+  if (rc) return rc;
+  const Geo g = geo_for_tiles(N, S);
+  RDRF_LAUNCH("scene_flow", k_scene_flow, dim3(g.grid), dim3(g.block), stream, pts, ts, N, S,
+              make_box(cfg), a.pk, w, sf_f, sf_b);
+  return 0;
+}

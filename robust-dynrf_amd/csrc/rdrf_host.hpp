@@ -1,0 +1,73 @@
+// rdrf_host.hpp -- host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "rdrf_common.hpp"
+
+void rdrf_set_error(const char* fmt, ...);
+
+#define RDRF_CHECK(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      rdrf_set_error(__VA_ARGS__);   \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+#define RDRF_HIP(expr)                                                             \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      rdrf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -5;                                                                   \
+    }                                                                              \
+  } while (0)
+
+// optional per-kernel timing with HIP events on the launch stream (bench.py roofline figure)
+void rdrf_prof_begin(const char* name, hipStream_t s);
+void rdrf_prof_end(const char* name, hipStream_t s);
+
+#define RDRF_LAUNCH(name, kernel, grid, block, stream, ...)            \
+  do {                                                                 \
+    rdrf_prof_begin(name, stream);                                     \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);   \
+    rdrf_prof_end(name, stream);                                       \
+    RDRF_HIP(hipGetLastError());                                       \
+  } while (0)
+
+static inline Box make_box(const RdrfFieldCfg* cfg) {
+  Box b;
+  for (int i = 0; i < 3; ++i) {
+    b.lo[i] = cfg->aabb[i];
+    b.hi[i] = cfg->aabb[3 + i];
+    b.inv[i] = 2.0f / (cfg->aabb[3 + i] - cfg->aabb[i]);  // models/tensorBase.py:377
+  }
+  return b;
+}
+
+// workspace carving (all offsets 256-byte aligned)
+struct WsCarver {
+  char* base;
+  size_t off, cap;
+  WsCarver(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    T* r = (T*)(base + off);
+    off += bytes;
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+static inline bool vm_ok(const RdrfVM& v, int c0, int c1) {
+  return v.C[0] == c0 && v.C[1] == c1 && v.C[2] == c1;
+}
+
+// pack-job builders (rdrf_pack.hip)
+void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int mode,
+              int nb, int kk, int dst);
+int pack_launch(const PackJobs& J, float* dst, hipStream_t stream);

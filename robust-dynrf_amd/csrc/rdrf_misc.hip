@@ -1,0 +1,299 @@
+// rdrf_misc.hip -- ray generation, ray samplers and the three-way alpha compositor.
+//   ray generation : /root/reference/train.py:96-103,1062-1077; dataLoader/ray_utils.py:53-140;
+//                    camera.py:8-15
+//   samplers       : models/tensorBase.py:487-499 (ndc), 524-559 (contract); renderer.py:147-170
+//   compositor     : renderer.py:173-315 (raw2outputs) -- one wave per ray, three exclusive
+//                    transmittance scans done as wave-level multiplicative scans with a carry.
+#include "rdrf_host.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// ray generation
+// ------------------------------------------------------------------------------------------------
+__global__ void k_generate_rays(const int64_t* __restrict__ ids, const float* __restrict__ poses9,
+                                const float* __restrict__ focal_p, int N, int T, int H, int W,
+                                int ndc, float near, float* __restrict__ rays) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const long id = ids[n];
+  const int col = (int)(id % W), row = (int)((id / W) % H);
+  int view = (int)(id / ((long)W * H));
+  view = view < 0 ? 0 : (view >= T ? T - 1 : view);
+  const float focal = focal_p[0];
+  const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+  const float cx = (float)((double)W / 2), cy = (float)((double)H / 2);
+  const float dir0 = (i - cx) / focal, dir1 = -(j - cy) / focal, dir2 = -1.0f;
+  const float* p = poses9 + view * 9;
+  // pose_to_mtx: Gram-Schmidt on the 6-D rotation
+  float b1[3] = {p[0], p[1], p[2]};
+  const float n1 = sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
+  b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
+  const float dt = b1[0] * p[3] + b1[1] * p[4] + b1[2] * p[5];
+  float b2[3] = {p[3] - dt * b1[0], p[4] - dt * b1[1], p[5] - dt * b1[2]};
+  const float n2 = sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
+  b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2],
+                       b1[0] * b2[1] - b1[1] * b2[0]};
+  float d[3], o[3] = {p[6], p[7], p[8]};
+  for (int r = 0; r < 3; ++r) d[r] = dir0 * b1[r] + dir1 * b2[r] + dir2 * b3[r];
+  if (ndc) {  // ndc_rays_blender2
+    const float t = -(near + o[2]) / d[2];
+    o[0] = o[0] + t * d[0]; o[1] = o[1] + t * d[1]; o[2] = o[2] + t * d[2];
+    const float kw = -1.0f / ((float)W / (2.0f * focal)), kh = -1.0f / ((float)H / (2.0f * focal));
+    const float o0 = kw * o[0] / o[2];
+    const float o1 = kh * o[1] / o[2];
+    const float o2 = 1.0f + 2.0f * near / o[2];
+    const float d0 = kw * (d[0] / d[2] - o[0] / o[2]);
+    const float d1 = kh * (d[1] / d[2] - o[1] / o[2]);
+    const float d2 = -2.0f * near / o[2];
+    o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
+  }
+  float* r = rays + (size_t)n * 6;
+  r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+}
+
+extern "C" int rdrf_generate_rays(const int64_t* ids, const float* poses9, const float* focal,
+                                  int N, int T, int H, int W, int ndc, float near, float* rays,
+                                  rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && T > 0 && H > 0 && W > 0, -1, "generate_rays: bad arguments");
+  RDRF_LAUNCH("generate_rays", k_generate_rays, dim3((N + 255) / 256), dim3(256), stream, ids,
+              poses9, focal, N, T, H, W, ndc, near, rays);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// samplers
+// ------------------------------------------------------------------------------------------------
+RDRF_D float linspace_at(float start, float end, int steps, int i) {  // ATen linspace, fp32
+#pragma clang fp contract(off)
+  if (steps <= 1) return start;
+  const float step = (end - start) / (float)(steps - 1);
+  if (i < steps / 2) return start + step * (float)i;
+  return end - step * (float)(steps - i - 1);
+}
+
+__global__ void k_sample_ndc(const float* __restrict__ rays, int N, int S, float near, float far,
+                             const float* __restrict__ jitter, Box box, float* __restrict__ xyz,
+                             float* __restrict__ z, uint8_t* __restrict__ valid) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * S) return;
+  const int n = (int)(i / S), j = (int)(i - (long)n * S);
+  float t = linspace_at(near, far, S, j);
+  if (jitter) {
+    const float c = (float)(((double)far - (double)near) / (double)S);
+    const float jj = jitter[j] * c;
+    t = t + jj;
+  }
+  const float* r = rays + (size_t)n * 6;
+  bool out = false;
+  for (int k = 0; k < 3; ++k) {
+    const float m = r[3 + k] * t;
+    const float p = r[k] + m;
+    xyz[i * 3 + k] = p;
+    out = out || (box.lo[k] > p) || (p > box.hi[k]);
+  }
+  z[i] = t;
+  valid[i] = out ? 0 : 1;
+}
+
+__global__ void k_sample_contract(const float* __restrict__ rays, int N, int S, float near,
+                                  float far, const float* __restrict__ jin,
+                                  const float* __restrict__ jout, float* __restrict__ xyz,
+                                  float* __restrict__ z, uint8_t* __restrict__ valid) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * S) return;
+  const int n = (int)(i / S), j = (int)(i - (long)n * S);
+  const int inner = S - S / 2, outer = S / 2;
+  float t;
+  if (j < inner) {
+    float a = linspace_at(near, 2.0f, inner + 1, j);
+    float b = linspace_at(near, 2.0f, inner + 1, j + 1);
+    if (jin) {
+      const float c = (float)((2.0 - (double)near) / (double)inner);
+      a = a + jin[j] * c;
+      if (j + 1 < inner) b = b + jin[j + 1] * c;
+    }
+    t = (b + a) * 0.5f;
+  } else {
+    const int k = j - inner;  // flipped: rng'[k] = rng[outer-k]
+    float r0 = (float)(outer - k), r1 = (float)(outer - k - 1);
+    if (jout) {
+      if (outer - k < outer) r0 = r0 + jout[outer - k];
+      r1 = r1 + jout[outer - k - 1];
+    }
+    const float mid = (r1 + r0) * 0.5f;
+    const float c2 = (float)(1.0 / 2.0 - 1.0 / (double)far);
+    const float inv_far = (float)(1.0 / (double)far);
+    const float den = inv_far + (c2 * mid) / (float)outer;
+    t = 1.0f / den;
+  }
+  const float* r = rays + (size_t)n * 6;
+  float p[3];
+  float nrm = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    const float m = r[3 + k] * t;
+    p[k] = r[k] + m;
+    nrm = fmaxf(nrm, fabsf(p[k]));
+  }
+  if (nrm > 1.0f) {
+    const float sc = 2.0f - 1.0f / nrm;
+    for (int k = 0; k < 3; ++k) p[k] = sc * (p[k] / nrm);
+  }
+  for (int k = 0; k < 3; ++k) xyz[i * 3 + k] = p[k];
+  z[i] = t;
+  valid[i] = 1;
+}
+
+extern "C" int rdrf_sample_ndc(const float* rays, int N, int S, float near, float far,
+                               const float* jitter, const float aabb_host[6], float* xyz, float* z,
+                               uint8_t* valid, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 0 && aabb_host, -1, "sample_ndc: bad arguments");
+  Box b;
+  for (int i = 0; i < 3; ++i) {
+    b.lo[i] = aabb_host[i];
+    b.hi[i] = aabb_host[3 + i];
+    b.inv[i] = 2.0f / (b.hi[i] - b.lo[i]);
+  }
+  const long total = (long)N * S;
+  RDRF_LAUNCH("sample_ndc", k_sample_ndc, dim3((unsigned)((total + 255) / 256)), dim3(256), stream,
+              rays, N, S, near, far, jitter, b, xyz, z, valid);
+  return 0;
+}
+
+extern "C" int rdrf_sample_contract(const float* rays, int N, int S, float near, float far,
+                                    const float* jitter_inner, const float* jitter_outer,
+                                    float* xyz, float* z, uint8_t* valid, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 1, -1, "sample_contract: bad arguments");
+  const long total = (long)N * S;
+  RDRF_LAUNCH("sample_contract", k_sample_contract, dim3((unsigned)((total + 255) / 256)),
+              dim3(256), stream, rays, N, S, near, far, jitter_inner, jitter_outer, xyz, z, valid);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compositor (raw2outputs)
+// ------------------------------------------------------------------------------------------------
+struct CompArgs {
+  const float *rgb_s, *sigma_s, *rgb_d, *sigma_d, *dists, *blending, *z, *rays;
+  int N, S, ray_type, add_white_bg;
+  float* out[13];
+};
+
+RDRF_D float alpha_of(float sigma, float dist) { return 1.0f - expf(-sigma * dist); }
+RDRF_D float tfull_factor(float ad, float as, float b) {
+#pragma clang fp contract(off)
+  const float u = 1.0f - ad * b;
+  const float v = 1.0f - as * (1.0f - b);
+  return u * v + 1e-10f;
+}
+
+__global__ __launch_bounds__(64) void k_composite(CompArgs a) {
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x;
+  if (n >= a.N) return;
+  const int S = a.S;
+  float cd = 1.f, cs = 1.f, cf = 1.f;  // scan carries
+  float sum_wd = 0.f;
+  float rs[3] = {0, 0, 0}, rf[3] = {0, 0, 0};
+  float acc_s = 0.f, acc_f = 0.f, dep_s = 0.f, dep_f = 0.f, dyn = 0.f;
+  float* w_full = a.out[3];
+  float* w_s = a.out[7];
+  float* w_d = a.out[11];
+  for (int j0 = 0; j0 < S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool act = j < S;
+    const size_t idx = (size_t)n * S + (act ? j : 0);
+    const float di = a.dists[idx], b = a.blending[idx], zz = a.z[idx];
+    const float ad = act ? alpha_of(a.sigma_d[idx], di) : 0.f;
+    const float as = act ? alpha_of(a.sigma_s[idx], di) : 0.f;
+    const float pd = act ? one_minus_alpha_eps(ad) : 1.f;
+    const float ps = act ? one_minus_alpha_eps(as) : 1.f;
+    const float pf = act ? tfull_factor(ad, as, b) : 1.f;
+    const float id = scan_mul64(pd, lane), is = scan_mul64(ps, lane), ifl = scan_mul64(pf, lane);
+    float ed = __shfl_up(id, 1, 64), es = __shfl_up(is, 1, 64), ef = __shfl_up(ifl, 1, 64);
+    if (lane == 0) { ed = 1.f; es = 1.f; ef = 1.f; }
+    const float Td = cd * ed, Ts = cs * es, Tf = cf * ef;
+    cd *= __shfl(id, 63, 64);
+    cs *= __shfl(is, 63, 64);
+    cf *= __shfl(ifl, 63, 64);
+    if (act) {
+      const float wd = ad * Td, ws = as * Ts;
+      const float wf = (ad * b + as * (1.0f - b)) * Tf;
+      const float fd = Tf * ad * b, fs = Tf * as * (1.0f - b);
+      sum_wd += wd;
+      w_d[idx] = wd;  // raw; normalised in pass 2
+      w_s[idx] = ws;
+      w_full[idx] = wf;
+      for (int c = 0; c < 3; ++c) {
+        const float cs_ = a.rgb_s[idx * 3 + c], cd_ = a.rgb_d[idx * 3 + c];
+        rs[c] += ws * cs_;
+        rf[c] += fd * cd_ + fs * cs_;
+      }
+      acc_s += ws; acc_f += wf;
+      dep_s += ws * zz; dep_f += wf * zz;
+      dyn += wf * b;
+    }
+  }
+  sum_wd = wave_sum(sum_wd);
+  const float denom = sum_wd + 1e-10f;
+  float rd[3] = {0, 0, 0}, acc_d = 0.f, dep_d = 0.f;
+  for (int j0 = 0; j0 < S; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < S) {
+      const size_t idx = (size_t)n * S + j;
+      const float wd = w_d[idx] / denom;
+      w_d[idx] = wd;
+      for (int c = 0; c < 3; ++c) rd[c] += wd * a.rgb_d[idx * 3 + c];
+      acc_d += wd;
+      dep_d += wd * a.z[idx];
+    }
+  }
+  for (int c = 0; c < 3; ++c) { rs[c] = wave_sum(rs[c]); rf[c] = wave_sum(rf[c]); rd[c] = wave_sum(rd[c]); }
+  acc_s = wave_sum(acc_s); acc_f = wave_sum(acc_f); acc_d = wave_sum(acc_d);
+  dep_s = wave_sum(dep_s); dep_f = wave_sum(dep_f); dep_d = wave_sum(dep_d);
+  dyn = wave_sum(dyn);
+  if (lane == 0) {
+    const float rl = fmaxf(1.0f - acc_f, 0.0f);
+    if (a.add_white_bg) {
+      for (int c = 0; c < 3; ++c) { rd[c] += 1.0f - acc_d; rs[c] += 1.0f - acc_s; rf[c] += rl; }
+    }
+    if (a.ray_type == RDRF_RAY_NDC) {
+      const float far = a.rays[(size_t)n * 6 + 2] + a.rays[(size_t)n * 6 + 5];
+      dep_d += (1.0f - acc_d) * far; dep_s += (1.0f - acc_s) * far; dep_f += rl * far;
+    } else if (a.ray_type == RDRF_RAY_CONTRACT) {
+      dep_d += (1.0f - acc_d) * 256.0f; dep_s += (1.0f - acc_s) * 256.0f; dep_f += rl * 256.0f;
+    }
+    for (int c = 0; c < 3; ++c) {
+      a.out[0][(size_t)n * 3 + c] = fminf(fmaxf(rf[c], 0.f), 1.f);
+      a.out[4][(size_t)n * 3 + c] = fminf(fmaxf(rs[c], 0.f), 1.f);
+      a.out[8][(size_t)n * 3 + c] = fminf(fmaxf(rd[c], 0.f), 1.f);
+    }
+    a.out[1][n] = dep_f; a.out[2][n] = acc_f;
+    a.out[5][n] = dep_s; a.out[6][n] = acc_s;
+    a.out[9][n] = dep_d; a.out[10][n] = acc_d;
+    a.out[12][n] = dyn + rl * 0.0f;
+  }
+}
+
+extern "C" int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
+                                  const float* sigma_d, const float* dists, const float* blending,
+                                  const float* z, const float* rays, int N, int S, int ray_type,
+                                  int add_white_bg, float* const out13[13], rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 0 && out13, -1, "composite_fwd: bad arguments");
+  CompArgs a;
+  a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
+  a.dists = dists; a.blending = blending; a.z = z; a.rays = rays;
+  a.N = N; a.S = S; a.ray_type = ray_type; a.add_white_bg = add_white_bg;
+  for (int i = 0; i < 13; ++i) {
+    RDRF_CHECK(out13[i] != nullptr, -1, "composite_fwd: output %d is NULL", i);
+    a.out[i] = out13[i];
+  }
+  RDRF_LAUNCH("composite", k_composite, dim3(N), dim3(64), stream, a);
+  return 0;
+}

@@ -1,0 +1,141 @@
+// rdrf_pack.hip -- weight packing into MFMA-fragment order, error string, profiling hooks.
+//
+// The parameters stay in the reference's state_dict layout (nn.Linear weight [out][in]); before a
+// forward/backward launch sequence one kernel permutes every MLP weight into the order the MFMA
+// A operand is read in: [out block][k-step/4][lane][4] with lane = (h<<5)|neuron and the k-step ->
+// input-column map of rdrf_common.hpp (seg_imap o elem_of).  Each MFMA then needs ONE coalesced
+// 16-byte load per lane for four k-steps.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rdrf_host.hpp"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void rdrf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* rdrf_last_error(void) { return g_err; }
+extern "C" int rdrf_abi_version(void) { return RDRF_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+struct ProfRec {
+  std::string name;
+  hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::map<std::string, std::pair<double, int>> g_prof_acc;
+
+void rdrf_prof_begin(const char* name, hipStream_t s) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  r.name = name;
+  hipEventCreate(&r.a);
+  hipEventCreate(&r.b);
+  hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+}
+void rdrf_prof_end(const char* name, hipStream_t s) {
+  if (!g_prof_on) return;
+  hipEventRecord(g_prof.back().b, s);
+}
+static void prof_drain() {
+  for (auto& r : g_prof) {
+    hipEventSynchronize(r.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    auto& acc = g_prof_acc[r.name];
+    acc.first += ms;
+    acc.second += 1;
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+}
+extern "C" void rdrf_prof_reset(void) {
+  prof_drain();
+  g_prof_acc.clear();
+}
+extern "C" int rdrf_prof_enable(int on) {
+  prof_drain();
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int rdrf_prof_get(const char* kernel, double* total_ms, int* launches) {
+  prof_drain();
+  auto it = g_prof_acc.find(kernel);
+  if (it == g_prof_acc.end()) {
+    *total_ms = 0;
+    *launches = 0;
+    return -1;
+  }
+  *total_ms = it->second.first;
+  *launches = it->second.second;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
+  const PackJob J = jobs.j[blockIdx.y];
+  const int stride = gridDim.x * blockDim.x;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (J.mode == 0 || J.mode == 2) {
+    const int total = J.nb * J.kk * 64;
+    const int k4n = J.kk >> 2;
+    for (int i = tid; i < total; i += stride) {
+      const int q = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+      const int k4 = rest % k4n, nb = rest / k4n;
+      const int kk = k4 * 4 + q, h = lane >> 5, li = lane & 31;
+      float v = 0.f;
+      if (J.mode == 0) {
+        const int o = nb * 32 + li;
+        const int col = seg_imap(J.seg, elem_of(kk, h), J.in_dim);
+        if (o < J.out_dim && col >= 0) v = J.src[(size_t)o * J.ld + col];
+      } else {
+        const int o = elem_of(kk, h);
+        const int col = seg_imap(J.seg, nb * 32 + li, J.in_dim);
+        if (o < J.out_dim && col >= 0) v = J.src[(size_t)o * J.ld + col];
+      }
+      dst[J.dst + i] = v;
+    }
+  } else if (J.mode == 3) {  // bias: [2][kk] canonical
+    const int total = 2 * J.kk;
+    for (int i = tid; i < total; i += stride) {
+      const int kk = i % J.kk, h = i / J.kk;
+      const int o = elem_of(kk, h);
+      dst[J.dst + i] = (J.src != nullptr && o < J.out_dim) ? J.src[o] : 0.f;
+    }
+  } else {
+    const int total = J.nb * 2 * J.kk;
+    for (int i = tid; i < total; i += stride) {
+      const int kk = i % J.kk, h = (i / J.kk) & 1, o = i / (2 * J.kk);
+      const int col = seg_imap(J.seg, elem_of(kk, h), J.in_dim);
+      dst[J.dst + i] = (o < J.out_dim && col >= 0) ? J.src[(size_t)o * J.ld + col] : 0.f;
+    }
+  }
+}
+
+void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int mode,
+              int nb, int kk, int dst) {
+  PackJob& j = J.j[J.n++];
+  j.src = src;
+  j.ld = ld;
+  j.out_dim = out_dim;
+  j.in_dim = in_dim;
+  j.seg = seg;
+  j.mode = mode;
+  j.nb = nb;
+  j.kk = kk;
+  j.dst = dst;
+}
+
+int pack_launch(const PackJobs& J, float* dst, hipStream_t stream) {
+  RDRF_CHECK(J.n > 0 && J.n <= RDRF_MAX_PACK_JOBS, -2, "pack: bad job count %d", J.n);
+  RDRF_LAUNCH("pack", k_pack, dim3(16, J.n), dim3(256), stream, J, dst);
+  return 0;
+}

@@ -1,0 +1,580 @@
+"""Host-side mirror of the reference field objects for the ray-batch hot path.
+
+``TensorVMSplit`` / ``TensorVMSplit_TimeEmbedding`` keep the reference's constructor kwargs,
+attribute names, ``state_dict`` keys/shapes, ``get_optparam_groups`` and the
+``forward(rays_chunk, ts_chunk, timeembeddings_chunk, xyz_sampled, z_vals, ray_valid, ...)``
+10-tuple (/root/reference/models/tensorBase.py:281-339, 704-850; models/tensoRF.py:11-61,
+277-376), but every per-sample computation runs in the HIP kernels behind the C ABI
+(include/rodynrf.h).  The nn.Linear / nn.Sequential objects here are parameter containers only.
+
+VM factors are stored channel-last: a plane parameter has the reference's logical shape
+(1,C,H,W) with strides of an [H][W][C] array, so state_dicts interchange with the reference while
+one bilinear tap of 4 components is a single 16-byte load on the GPU.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]
+VEC_MODE = [2, 1, 0]
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers (same attribute / key structure as models/tensorBase.py:81-183)
+# --------------------------------------------------------------------------------------------
+class _Head(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("the RGB head is fused into the HIP appearance kernel; call the field")
+
+
+class MLPRender_Fea(_Head):
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 2 * feape * inChanel + 3 + inChanel
+        self.viewpe, self.feape = viewpe, feape
+        self.mlp = nn.Sequential(nn.Linear(self.in_mlpC, featureC), nn.ReLU(inplace=True),
+                                 nn.Linear(featureC, featureC), nn.ReLU(inplace=True),
+                                 nn.Linear(featureC, 3))
+        nn.init.constant_(self.mlp[-1].bias, 0)
+
+
+class MLPRender_Fea_TimeEmbedding(_Head):
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * feape * inChanel + inChanel
+        self.in_view = 2 * viewpe * 3 + 3
+        self.viewpe, self.feape = viewpe, feape
+        layer1 = nn.Linear(self.in_mlpC, featureC)
+        layer2 = nn.Linear(featureC, featureC)
+        layer3 = nn.Linear(featureC + self.in_view, 3)
+        self.mlp = nn.Sequential(layer1, nn.ReLU(inplace=True), layer2, nn.ReLU(inplace=True))
+        self.mlp_view = nn.Sequential(layer3)
+        nn.init.constant_(self.mlp_view[-1].bias, 0)
+
+
+class MLPRender_Fea_late_view(_Head):
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * feape * inChanel + inChanel + 2 * 10 * 3 + 3 + 2 * 8 * 1 + 1
+        self.in_view = 2 * viewpe * 3 + 3
+        self.viewpe, self.feape = viewpe, feape
+        layer1 = nn.Linear(self.in_mlpC, featureC)
+        layer2 = nn.Linear(featureC, featureC)
+        layer3 = nn.Linear(featureC + self.in_view, 3)
+        self.mlp = nn.Sequential(layer1, nn.ReLU(inplace=True), layer2, nn.ReLU(inplace=True))
+        self.mlp_view = nn.Sequential(layer3)
+        nn.init.constant_(self.mlp_view[-1].bias, 0)
+
+
+def channel_last_(t):
+    """Re-stride a (1,C,H,W) tensor as an [H][W][C] array (values preserved)."""
+    _, c, h, w = t.shape
+    out = torch.empty_strided(t.shape, (c * h * w, 1, w * c, c), dtype=t.dtype, device=t.device)
+    out.copy_(t)
+    return out
+
+
+def _is_channel_last(t):
+    _, c, h, w = t.shape
+    return t.stride()[1:] == (1, w * c, c) or (t.numel() == 0)
+
+
+# --------------------------------------------------------------------------------------------
+# autograd bridges
+# --------------------------------------------------------------------------------------------
+def _vm_struct(planes, lines):
+    vm = L.RdrfVM()
+    for i in range(3):
+        p, l = planes[i], lines[i]
+        vm.plane[i] = p.data_ptr()
+        vm.line[i] = l.data_ptr()
+        vm.C[i] = p.shape[1]
+        vm.H[i] = p.shape[2]
+        vm.W[i] = p.shape[3]
+        vm.L[i] = l.shape[2]
+    return vm
+
+
+def _cfg_struct(field, ray_type, weight_thres=None):
+    c = L.RdrfFieldCfg()
+    ab = field._aabb_host
+    for i in range(6):
+        c.aabb[i] = ab[i]
+    c.distance_scale = float(field.distance_scale)
+    c.weight_thres = float(field.rayMarch_weight_thres if weight_thres is None else weight_thres)
+    c.density_shift = float(field.density_shift)
+    c.act = L.ACTS[field.fea2denseAct]
+    c.ray_type = L.RAY_TYPES.get(ray_type, 2)
+    c.static_head = L.HEADS.get(field.shadingMode, 0)
+    return c
+
+
+STATIC_KEYS = (["density_plane.%d" % i for i in range(3)] + ["density_line.%d" % i for i in range(3)]
+               + ["app_plane.%d" % i for i in range(3)] + ["app_line.%d" % i for i in range(3)]
+               + ["basis_mat.weight"])
+DYN_VM = (["density_plane.%d" % i for i in range(3)] + ["density_line.%d" % i for i in range(3)]
+          + ["blending_plane.%d" % i for i in range(3)] + ["blending_line.%d" % i for i in range(3)]
+          + ["app_plane.%d" % i for i in range(3)] + ["app_line.%d" % i for i in range(3)])
+
+
+def _static_struct(t):
+    """t: list of tensors in TensorVMSplit._param_list() order."""
+    P = L.RdrfStaticParams()
+    P.density = _vm_struct(t[0:3], t[3:6])
+    P.app = _vm_struct(t[6:9], t[9:12])
+    for name, ten in zip(("basis", "w1", "b1", "w2", "b2", "w3", "b3"), t[12:19]):
+        setattr(P, name, ten.data_ptr())
+    return P
+
+
+def _dynamic_struct(t):
+    P = L.RdrfDynamicParams()
+    P.density = _vm_struct(t[0:3], t[3:6])
+    P.blending = _vm_struct(t[6:9], t[9:12])
+    P.app = _vm_struct(t[12:15], t[15:18])
+    names = ("basis", "rw1", "rb1", "rw2", "rb2", "rwv", "rbv", "l1w", "l1b", "l2w", "l2b", "l3w",
+             "l3b", "l4w", "l4b", "l5w", "l5b", "dw1", "db1", "dw2", "db2", "bw1", "bb1", "bw2", "bb2")
+    for name, ten in zip(names, t[18:43]):
+        setattr(P, name, ten.data_ptr())
+    for i in range(4):
+        P.sfw[i] = t[43 + 2 * i].data_ptr()
+        P.sfb[i] = t[44 + 2 * i].data_ptr()
+    return P
+
+
+def _prep_inputs(rays, ts, xyz, z, valid):
+    L.require_device(rays, ts, xyz, z, valid)
+    rays, ts, xyz, z = L.f32c(rays), L.f32c(ts), L.f32c(xyz), L.f32c(z)
+    valid = valid.contiguous()
+    if valid.dtype == torch.bool:
+        valid = valid.view(torch.uint8)
+    return rays, ts, xyz, z, valid
+
+
+class _StaticFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, field, ray_type, rays, ts, xyz, z, valid, *params):
+        rays, ts, xyz, z, valid = _prep_inputs(rays, ts, xyz, z, valid)
+        N, S = z.shape
+        dev = z.device
+        rgb = torch.empty(N, S, 3, device=dev)
+        sigma = torch.empty(N, S, device=dev)
+        weight = torch.empty(N, S, device=dev)
+        dists = torch.empty(N, S, device=dev)
+        ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
+        P = _static_struct(params)
+        cfg = _cfg_struct(field, ray_type)
+        L.check(L.lib.rdrf_static_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
+                                      L.ptr(z), L.ptr(valid), N, S, L.ptr(rgb), L.ptr(sigma),
+                                      L.ptr(weight), L.ptr(dists), L.ptr(ws), C.c_size_t(ws.numel()),
+                                      L.stream_of(z)), "rdrf_static_fwd")
+        ctx.field, ctx.ray_type = field, ray_type
+        ctx.save_for_backward(rays, ts, xyz, z, valid, *params)
+        return rgb, sigma, weight, dists
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma, g_weight, g_dists):
+        rays, ts, xyz, z, valid, *params = ctx.saved_tensors
+        N, S = z.shape
+        dev = z.device
+        grads = [torch.zeros_like(p) for p in params]
+        G = _static_struct(grads)
+        P = _static_struct(params)
+        cfg = _cfg_struct(ctx.field, ctx.ray_type)
+        need = ctx.needs_input_grad
+        g_rays = torch.zeros_like(rays) if need[2] else None
+        g_xyz = torch.zeros_like(xyz) if need[4] else None
+        g_z = torch.zeros_like(z) if need[5] else None
+        cont = lambda g: None if g is None else L.f32c(g)
+        g_rgb, g_sigma, g_weight, g_dists = cont(g_rgb), cont(g_sigma), cont(g_weight), cont(g_dists)
+        ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
+        L.check(L.lib.rdrf_static_bwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
+                                      L.ptr(z), L.ptr(valid), N, S, L.ptr(g_rgb), L.ptr(g_sigma),
+                                      L.ptr(g_weight), L.ptr(g_dists), C.byref(G), L.ptr(g_xyz),
+                                      L.ptr(g_z), L.ptr(g_rays), L.ptr(ws), C.c_size_t(ws.numel()),
+                                      L.stream_of(z)), "rdrf_static_bwd")
+        return (None, None, g_rays, None, g_xyz, g_z, None, *grads)
+
+
+class _DynamicFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, field, ray_type, rays, ts, xyz, z, valid, *params):
+        rays, ts, xyz, z, valid = _prep_inputs(rays, ts, xyz, z, valid)
+        N, S = z.shape
+        dev = z.device
+        rgb = torch.empty(N, S, 3, device=dev)
+        xyz_prime = torch.empty(N, S, 3, device=dev)
+        sigma, weight, dists, blending = (torch.empty(N, S, device=dev) for _ in range(4))
+        ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
+        P = _dynamic_struct(params)
+        cfg = _cfg_struct(field, ray_type)
+        L.check(L.lib.rdrf_dynamic_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
+                                       L.ptr(z), L.ptr(valid), N, S, L.ptr(blending), L.ptr(weight),
+                                       L.ptr(xyz_prime), L.ptr(rgb), L.ptr(sigma), L.ptr(dists),
+                                       L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(z)),
+                "rdrf_dynamic_fwd")
+        ctx.field, ctx.ray_type = field, ray_type
+        ctx.save_for_backward(rays, ts, xyz, z, valid, *params)
+        return blending, weight, xyz_prime, rgb, sigma, dists
+
+    @staticmethod
+    def backward(ctx, g_blending, g_weight, g_xyz_prime, g_rgb, g_sigma, g_dists):
+        rays, ts, xyz, z, valid, *params = ctx.saved_tensors
+        N, S = z.shape
+        dev = z.device
+        grads = [torch.zeros_like(p) for p in params]
+        G = _dynamic_struct(grads)
+        P = _dynamic_struct(params)
+        cfg = _cfg_struct(ctx.field, ctx.ray_type)
+        need = ctx.needs_input_grad
+        g_rays = torch.zeros_like(rays) if need[2] else None
+        g_xyz = torch.zeros_like(xyz) if need[4] else None
+        g_z = torch.zeros_like(z) if need[5] else None
+        cont = lambda g: None if g is None else L.f32c(g)
+        gb, gw, gxp, gr, gs, gd = (cont(g) for g in (g_blending, g_weight, g_xyz_prime, g_rgb,
+                                                      g_sigma, g_dists))
+        ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
+        L.check(L.lib.rdrf_dynamic_bwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
+                                       L.ptr(z), L.ptr(valid), N, S, L.ptr(gb), L.ptr(gw),
+                                       L.ptr(gxp), L.ptr(gr), L.ptr(gs), L.ptr(gd), C.byref(G),
+                                       L.ptr(g_xyz), L.ptr(g_z), L.ptr(g_rays), L.ptr(ws),
+                                       C.c_size_t(ws.numel()), L.stream_of(z)), "rdrf_dynamic_bwd")
+        return (None, None, g_rays, None, g_xyz, g_z, None, *grads)
+
+
+class _SceneFlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, field, pts, ts, *params):
+        L.require_device(pts, ts)
+        pts, ts = L.f32c(pts), L.f32c(ts)
+        N, S, _ = pts.shape
+        sf_f = torch.empty(N, S, 3, device=pts.device)
+        sf_b = torch.empty(N, S, 3, device=pts.device)
+        ws = L.workspace(pts.device, L.lib.rdrf_workspace_bytes(N, S))
+        P = _dynamic_struct(params)
+        cfg = _cfg_struct(field, "ndc")
+        L.check(L.lib.rdrf_scene_flow_fwd(C.byref(P), C.byref(cfg), L.ptr(pts), L.ptr(ts), N, S,
+                                          L.ptr(sf_f), L.ptr(sf_b), L.ptr(ws),
+                                          C.c_size_t(ws.numel()), L.stream_of(pts)),
+                "rdrf_scene_flow_fwd")
+        ctx.field = field
+        ctx.save_for_backward(pts, ts, *params)
+        return sf_f, sf_b
+
+    @staticmethod
+    def backward(ctx, g_f, g_b):
+        pts, ts, *params = ctx.saved_tensors
+        N, S, _ = pts.shape
+        grads = [torch.zeros_like(p) for p in params]
+        G = _dynamic_struct(grads)
+        P = _dynamic_struct(params)
+        cfg = _cfg_struct(ctx.field, "ndc")
+        g_pts = torch.zeros_like(pts) if ctx.needs_input_grad[1] else None
+        g_f = None if g_f is None else L.f32c(g_f)
+        g_b = None if g_b is None else L.f32c(g_b)
+        ws = L.workspace(pts.device, L.lib.rdrf_workspace_bytes(N, S))
+        L.check(L.lib.rdrf_scene_flow_bwd(C.byref(P), C.byref(cfg), L.ptr(pts), L.ptr(ts), N, S,
+                                          L.ptr(g_f), L.ptr(g_b), C.byref(G), L.ptr(g_pts), L.ptr(ws),
+                                          C.c_size_t(ws.numel()), L.stream_of(pts)),
+                "rdrf_scene_flow_bwd")
+        return (None, g_pts, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------
+# TensorBase (models/tensorBase.py:281-559)
+# --------------------------------------------------------------------------------------------
+class TensorBase(nn.Module):
+    def __init__(self, aabb, gridSize, tSize, device, density_n_comp=8, appearance_n_comp=24,
+                 app_dim=27, shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0],
+                 density_shift=-10, alphaMask_thres=0.001, distance_scale=25,
+                 rayMarch_weight_thres=0.0001, pos_pe=6, view_pe=6, fea_pe=6, featureC=128,
+                 step_ratio=2.0, fea2denseAct="softplus"):
+        super().__init__()
+        self.density_n_comp = list(density_n_comp)
+        self.app_n_comp = list(appearance_n_comp)
+        self.app_dim = app_dim
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).to(device)
+        self._aabb_host = [float(v) for v in self.aabb.detach().cpu().reshape(-1)]
+        self.alphaMask = alphaMask
+        self.device = device
+        self.density_shift = density_shift
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.fea2denseAct = fea2denseAct
+        self.near_far = near_far
+        self.step_ratio = step_ratio
+        self.tSizeFixed = tSize
+        self.update_stepSize(gridSize, tSize)
+        self.matMode = MAT_MODE
+        self.vecMode = VEC_MODE
+        self.comp_w = [1, 1, 1]
+        if self.density_n_comp != [16, 4, 4] or self.app_n_comp != [48, 12, 12] or app_dim != 27 \
+                or featureC != 128 or view_pe != 0:
+            raise NotImplementedError(
+                "the HIP kernels are built for the shipped configs: density comps [16,4,4], "
+                "appearance comps [48,12,12], app_dim 27, featureC 128, view_pe 0")
+        self.init_svd_volume(gridSize[0], device)
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = (
+            shadingMode, pos_pe, view_pe, fea_pe, featureC)
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
+
+    # ---- construction ------------------------------------------------------------------
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        if shadingMode == "MLP_Fea":
+            self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        elif shadingMode == "MLP_Fea_TimeEmbedding":
+            self.renderModule = MLPRender_Fea_TimeEmbedding(self.app_dim, view_pe, fea_pe,
+                                                            featureC).to(device)
+        elif shadingMode == "MLP_Fea_late_view":
+            self.renderModule = MLPRender_Fea_late_view(self.app_dim, view_pe, fea_pe,
+                                                        featureC).to(device)
+        else:
+            raise NotImplementedError(f"shadingMode {shadingMode} is not reachable from the shipped "
+                                      "configs and is not built")
+
+    def update_stepSize(self, gridSize, tSize):
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor(list(gridSize)).to(self.device)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        self.tSize = torch.unsqueeze(torch.tensor(tSize), 0).to(self.device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        plane_coef, line_coef = [], []
+        gs = [int(g) for g in gridSize]
+        for i in range(3):
+            vec_id = VEC_MODE[i]
+            m0, m1 = MAT_MODE[i]
+            p = scale * torch.randn((1, n_component[i], gs[m1], gs[m0]))
+            l = scale * torch.randn((1, n_component[i], gs[vec_id], 1))
+            plane_coef.append(nn.Parameter(channel_last_(p.to(device))))
+            line_coef.append(nn.Parameter(channel_last_(l.to(device))))
+        return nn.ParameterList(plane_coef), nn.ParameterList(line_coef)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # accept planes at a different resolution (checkpoints saved after upsampling)
+        for name, p in list(self.named_parameters(recurse=True)):
+            key = prefix + name
+            if key in state_dict and ("_plane." in name or "_line." in name) \
+                    and state_dict[key].shape != p.shape:
+                new = channel_last_(state_dict[key].to(p.device).float())
+                mod, attr = name.split(".")
+                getattr(self, mod)[int(attr)] = nn.Parameter(new)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    # ---- helpers kept from the reference API ---------------------------------------------
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invaabbSize - 1
+
+    def unnormalize_coord(self, xyz_sampled):
+        return (xyz_sampled + 1) / self.invaabbSize + self.aabb[0]
+
+    def feature2density(self, density_features):
+        if self.fea2denseAct == "softplus":
+            return F.softplus(density_features + self.density_shift)
+        return F.relu(density_features)
+
+    def get_kwargs(self):
+        return {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), "tSize": self.tSize.item(),
+                "density_n_comp": self.density_n_comp, "appearance_n_comp": self.app_n_comp,
+                "app_dim": self.app_dim, "density_shift": self.density_shift,
+                "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
+                "rayMarch_weight_thres": self.rayMarch_weight_thres,
+                "fea2denseAct": self.fea2denseAct, "near_far": self.near_far,
+                "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
+                "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe,
+                "featureC": self.featureC}
+
+    def save(self, se3_poses, focal_ratio_refine, path):
+        kwargs = self.get_kwargs()
+        kwargs["se3_poses"] = se3_poses
+        kwargs["focal_ratio_refine"] = focal_ratio_refine
+        torch.save({"kwargs": kwargs, "state_dict": self.state_dict()}, path)
+
+    def load(self, ckpt):
+        self.load_state_dict(ckpt["state_dict"])
+
+    # ---- samplers (models/tensorBase.py:487-559): device kernels, RNG stays in torch ----------
+    def sample_ray_ndc(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        from .renderer import sample_rays
+        N_samples = N_samples if N_samples > 0 else self.nSamples
+        xyz, z, valid = sample_rays(self, torch.cat([rays_o, rays_d], -1), N_samples, "ndc", is_train)
+        return xyz, z[:1], valid
+
+    def sample_ray_contracted(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        from .renderer import sample_rays
+        N_samples = N_samples if N_samples > 0 else self.nSamples
+        xyz, z, valid = sample_rays(self, torch.cat([rays_o, rays_d], -1), N_samples, "contract",
+                                    is_train)
+        return xyz, z[:1], valid
+
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        for i in range(3):
+            vec_id = VEC_MODE[i]
+            m0, m1 = MAT_MODE[i]
+            p = F.interpolate(plane_coef[i].data, size=(res_target[m1], res_target[m0]),
+                              mode="bilinear", align_corners=True)
+            l = F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1), mode="bilinear",
+                              align_corners=True)
+            plane_coef[i] = nn.Parameter(channel_last_(p))
+            line_coef[i] = nn.Parameter(channel_last_(l))
+        return plane_coef, line_coef
+
+    def _check_layout(self):
+        for n, p in self.named_parameters():
+            if ("_plane." in n or "_line." in n) and not _is_channel_last(p):
+                raise L.RdrfError(f"{n} lost its channel-last layout")
+
+
+class TensorVMSplit(TensorBase):
+    """Static field (models/tensoRF.py:11-274)."""
+
+    def init_svd_volume(self, res, device):
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize,
+                                                                  0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        return [{"params": self.density_line, "lr": lr_init_spatialxyz},
+                {"params": self.density_plane, "lr": lr_init_spatialxyz},
+                {"params": self.app_line, "lr": lr_init_spatialxyz},
+                {"params": self.app_plane, "lr": lr_init_spatialxyz},
+                {"params": self.basis_mat.parameters(), "lr": lr_init_network},
+                {"params": self.renderModule.parameters(), "lr": lr_init_network}]
+
+    def _param_list(self):
+        rm = self.renderModule
+        if self.shadingMode == "MLP_Fea":
+            if self.fea_pe != 2:
+                raise NotImplementedError("static MLP_Fea head is built for fea_pe=2 (train.py:889)")
+            last = rm.mlp[4]
+        elif self.shadingMode == "MLP_Fea_TimeEmbedding":
+            if self.fea_pe != 2:
+                raise NotImplementedError("static head is built for fea_pe=2 (train.py:889)")
+            last = rm.mlp_view[0]
+        else:
+            raise NotImplementedError("static field heads: MLP_Fea | MLP_Fea_TimeEmbedding")
+        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane)
+                + list(self.app_line) + [self.basis_mat.weight, rm.mlp[0].weight, rm.mlp[0].bias,
+                                         rm.mlp[2].weight, rm.mlp[2].bias, last.weight, last.bias])
+
+    def warp_coordinate(self, xyz_sampled, t_sampled):
+        return None
+
+    def forward(self, rays_chunk, ts_chunk, timeembeddings_chunk, xyz_sampled, z_vals, ray_valid,
+                white_bg=True, is_train=False, ray_type="ndc", N_samples=-1):
+        if timeembeddings_chunk is not None:
+            raise NotImplementedError("timeembeddings_chunk is None at every reference call site")
+        rgb, sigma, weight, dists = _StaticFn.apply(self, ray_type, rays_chunk, ts_chunk, xyz_sampled,
+                                                    z_vals, ray_valid, *self._param_list())
+        return (None, None, None, xyz_sampled, weight, None, rgb, sigma, z_vals, dists)
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane,
+                                                                    self.density_line, res_target)
+        self.update_stepSize(res_target, 1)
+
+
+class TensorVMSplit_TimeEmbedding(TensorBase):
+    """Dynamic field (models/tensoRF.py:277-892)."""
+
+    def __init__(self, aabb, gridSize, tSize, device, **kargs):
+        super().__init__(aabb, gridSize, tSize, device, **kargs)
+        self.layer1 = nn.Linear(1 + 8 * 2 * 1, 64).to(device)
+        self.layer2 = nn.Linear(64, 30).to(device)
+        self.layer3 = nn.Linear((3 + 10 * 2 * 3) + 30, 64).to(device)
+        self.layer4 = nn.Linear(64, 64).to(device)
+        self.layer5 = nn.Linear(64, 3).to(device)
+        nin = sum(self.density_n_comp) * 3 + 3 + 10 * 2 * 3 + 1 + 8 * 2 * 1
+        self.density_layer1 = nn.Linear(nin, 64).to(device)
+        self.density_layer2 = nn.Linear(64, 1).to(device)
+        self.blending_layer1 = nn.Linear(nin, 64).to(device)
+        self.blending_layer2 = nn.Linear(64, 1).to(device)
+        self.scene_flow_mlp = nn.Sequential(
+            nn.Linear(4 * 2 * 4 + 4, 64), nn.ReLU(inplace=True), nn.Linear(64, 64),
+            nn.ReLU(inplace=True), nn.Linear(64, 64), nn.ReLU(inplace=True), nn.Linear(64, 6),
+        ).to(device)
+        if self.shadingMode != "MLP_Fea_late_view" or self.fea_pe != 0:
+            raise NotImplementedError("dynamic head is built for MLP_Fea_late_view, fea_pe=0 "
+                                      "(configs/*.txt, train.py:918)")
+
+    def init_svd_volume(self, res, device):
+        self.blending_plane, self.blending_line = self.init_one_svd(self.density_n_comp,
+                                                                    self.gridSize, 0.1, device)
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize,
+                                                                  0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = nn.Linear(sum(self.app_n_comp) * 3, self.app_dim, bias=False).to(device)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        g = [{"params": self.density_line, "lr": lr_init_spatialxyz},
+             {"params": self.density_plane, "lr": lr_init_spatialxyz},
+             {"params": self.blending_line, "lr": lr_init_spatialxyz},
+             {"params": self.blending_plane, "lr": lr_init_spatialxyz},
+             {"params": self.app_line, "lr": lr_init_spatialxyz},
+             {"params": self.app_plane, "lr": lr_init_spatialxyz},
+             {"params": self.basis_mat.parameters(), "lr": lr_init_network},
+             {"params": self.scene_flow_mlp.parameters(), "lr": lr_init_network}]
+        for m in (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.density_layer1,
+                  self.density_layer2, self.blending_layer1, self.blending_layer2):
+            g.append({"params": m.parameters(), "lr": lr_init_network})
+        g.append({"params": self.renderModule.parameters(), "lr": lr_init_network})
+        return g
+
+    def _param_list(self):
+        rm = self.renderModule
+        t = (list(self.density_plane) + list(self.density_line) + list(self.blending_plane)
+             + list(self.blending_line) + list(self.app_plane) + list(self.app_line))
+        t += [self.basis_mat.weight, rm.mlp[0].weight, rm.mlp[0].bias, rm.mlp[2].weight,
+              rm.mlp[2].bias, rm.mlp_view[0].weight, rm.mlp_view[0].bias]
+        for m in (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.density_layer1,
+                  self.density_layer2, self.blending_layer1, self.blending_layer2):
+            t += [m.weight, m.bias]
+        for i in (0, 2, 4, 6):
+            t += [self.scene_flow_mlp[i].weight, self.scene_flow_mlp[i].bias]
+        return t
+
+    def forward(self, rays_chunk, ts_chunk, timeembeddings_chunk, xyz_sampled, z_vals, ray_valid,
+                white_bg=True, is_train=False, ray_type="ndc", N_samples=-1):
+        if timeembeddings_chunk is not None:
+            raise NotImplementedError("timeembeddings_chunk is None at every reference call site")
+        blending, weight, xyz_prime, rgb, sigma, dists = _DynamicFn.apply(
+            self, ray_type, rays_chunk, ts_chunk, xyz_sampled, z_vals, ray_valid, *self._param_list())
+        return (None, None, blending, xyz_sampled, weight, xyz_prime, rgb, sigma, z_vals, dists)
+
+    def get_forward_backward_scene_flow(self, unnormalized_pts, t_sampled):
+        return _SceneFlowFn.apply(self, unnormalized_pts, t_sampled, *self._param_list())
+
+    def warp_coordinate(self, unnormalized_xyz_sampled, t_sampled):
+        """(N,S,3), (N,S) -> warped un-normalised coordinates (value only; the differentiable path
+        is forward()'s xyz_prime output)."""
+        xyz = unnormalized_xyz_sampled
+        N, S, _ = xyz.shape
+        rays = torch.zeros(N, 6, device=xyz.device)
+        rays[:, 5] = 1.0
+        z = torch.zeros(N, S, device=xyz.device)
+        valid = torch.ones(N, S, dtype=torch.bool, device=xyz.device)
+        with torch.no_grad():
+            out = self.forward(rays, t_sampled[:, 0].contiguous(), None, xyz, z, valid)
+        return out[5]
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane,
+                                                                    self.density_line, res_target)
+        self.blending_plane, self.blending_line = self.up_sampling_VM(self.blending_plane,
+                                                                      self.blending_line, res_target)
+        self.update_stepSize(res_target, 1)
