@@ -26,7 +26,7 @@ def load_case(name):
     return g, sd_s, cfg_s, sd_d, cfg_d
 
 
-def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None):
+def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None, atol=0.0):
     a = torch.as_tensor(a).detach().cpu().double()
     b = torch.as_tensor(b).detach().cpu().double()
     assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -37,5 +37,5 @@ def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None):
         return
     scale = max(float(b.abs().max()), 1e-30)
     err = float((a - b).abs().max())
-    assert err <= rtol * scale * atol_scale + 1e-30, (
+    assert err <= rtol * scale * atol_scale + atol + 1e-30, (
         f"{name}: max abs err {err:.3e} > {rtol * atol_scale:.1e} * max|ref| ({scale:.3e})")
