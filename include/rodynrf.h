@@ -10,7 +10,7 @@
  *   ray generation (ids2pixel .. ndc_rays_blender2)               train.py:96-103, 1062-1077
  *
  * Each entry point below replaces one of those calls (cited per function).  The host-side mirror
- * (robust-dynrf_amd/*.py) binds them with ctypes and re-exposes the reference signatures.
+ * (robust-dynrf_amd/ *.py) binds them with ctypes and re-exposes the reference signatures.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host; all tensors fp32, row major;
@@ -92,6 +92,10 @@ const char* rdrf_last_error(void);
 
 /* Bytes of workspace a forward/backward call of either field needs for N rays x S samples. */
 size_t rdrf_workspace_bytes(int N, int S);
+/* Training mode: a forward call given a `saved` buffer of this size (kind 0 = static field,
+ * 1 = dynamic field, 2 = scene flow) stores the activations its backward needs; the matching
+ * *_bwd call must receive the same buffer untouched.  saved == NULL => inference, nothing kept. */
+size_t rdrf_saved_bytes(int kind, int N, int S);
 
 /* ---- ray generation: train.py:96-103 + dataLoader/ray_utils.py:53-140 + camera.py:8-15 -------
  * ids[N] int64 flat ray ids over (T,H,W); poses9[T][9] 6-D rotation + translation; focal scalar.
@@ -112,46 +116,49 @@ int rdrf_sample_ndc(const float* rays, int N, int S, float near, float far, cons
 int rdrf_sample_contract(const float* rays, int N, int S, float near, float far,
                          const float* jitter_inner, const float* jitter_outer, float* xyz,
                          float* z, uint8_t* valid, rdrf_stream_t stream);
-/* grad_xyz[N][S][3], grad_z[N][S] -> grad_rays[N][6] (+=). z_row[S] are the sample depths. */
-int rdrf_sample_bwd(const float* rays, const float* z_row, int N, int S, int ray_type,
+/* grad_xyz[N][S][3] -> grad_rays[N][6] (+=). z[N][S] are the sample depths the sampler returned. */
+int rdrf_sample_bwd(const float* rays, const float* z, int N, int S, int ray_type,
                     const float* grad_xyz, float* grad_rays, rdrf_stream_t stream);
 
 /* ---- TensorVMSplit.forward (models/tensorBase.py:704-850, models/tensoRF.py:118-196) ---------
  * outputs: rgb[N][S][3], sigma[N][S], weight[N][S], dists[N][S] (= dists*distance_scale). */
 int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                     const float* ts, const float* xyz, const float* z, const uint8_t* valid, int N,
-                    int S, float* rgb, float* sigma, float* weight, float* dists, void* ws,
-                    size_t ws_bytes, rdrf_stream_t stream);
+                    int S, float* rgb, float* sigma, float* weight, float* dists, void* saved,
+                    size_t saved_bytes, void* ws, size_t ws_bytes, rdrf_stream_t stream);
 /* g_* are gradients wrt the four outputs (any may be NULL = zero). G receives parameter
  * gradients (+=); g_xyz[N][S][3], g_z[N][S], g_rays[N][6] (+=, each may be NULL). */
 int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                     const float* ts, const float* xyz, const float* z, const uint8_t* valid, int N,
                     int S, const float* g_rgb, const float* g_sigma, const float* g_weight,
                     const float* g_dists, const RdrfStaticParams* G, float* g_xyz, float* g_z,
-                    float* g_rays, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+                    float* g_rays, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                    rdrf_stream_t stream);
 
 /* ---- TensorVMSplit_TimeEmbedding.forward (models/tensorBase.py:704-850,
  *      models/tensoRF.py:521-811) -- adds blending[N][S], xyz_prime[N][S][3]. */
 int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* rays,
                      const float* ts, const float* xyz, const float* z, const uint8_t* valid,
                      int N, int S, float* blending, float* weight, float* xyz_prime, float* rgb,
-                     float* sigma, float* dists, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+                     float* sigma, float* dists, void* saved, size_t saved_bytes, void* ws,
+                     size_t ws_bytes, rdrf_stream_t stream);
 int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* rays,
                      const float* ts, const float* xyz, const float* z, const uint8_t* valid,
                      int N, int S, const float* g_blending, const float* g_weight,
                      const float* g_xyz_prime, const float* g_rgb, const float* g_sigma,
                      const float* g_dists, const RdrfDynamicParams* G, float* g_xyz, float* g_z,
-                     float* g_rays, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+                     float* g_rays, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                     rdrf_stream_t stream);
 
 /* ---- get_forward_backward_scene_flow (models/tensoRF.py:446-462) -----------------------------
  * pts[N][S][3] un-normalised, ts[N] -> sf_f[N][S][3], sf_b[N][S][3]. */
 int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* pts,
-                        const float* ts, int N, int S, float* sf_f, float* sf_b, void* ws,
-                        size_t ws_bytes, rdrf_stream_t stream);
+                        const float* ts, int N, int S, float* sf_f, float* sf_b, void* saved,
+                        size_t saved_bytes, void* ws, size_t ws_bytes, rdrf_stream_t stream);
 int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* pts,
                         const float* ts, int N, int S, const float* g_sf_f, const float* g_sf_b,
-                        const RdrfDynamicParams* G, float* g_pts, void* ws, size_t ws_bytes,
-                        rdrf_stream_t stream);
+                        const RdrfDynamicParams* G, float* g_pts, void* saved, size_t saved_bytes,
+                        void* ws, size_t ws_bytes, rdrf_stream_t stream);
 
 /* ---- renderer.raw2outputs (renderer.py:173-315) ----------------------------------------------
  * add_white_bg: the caller draws the train-time coin (renderer.py:269). out13: pointers to the 13

@@ -1,14 +1,1290 @@
-// rdrf_bwd.hip -- backward kernels (placeholder until the forward path is parity-green)
-#include "rdrf_host.hpp"
+// rdrf_bwd.hip -- backward of the two fields and of the scene-flow MLP for gfx950.
+//
+// Structure per phase (appearance / density / scene flow):
+//   1. the training-mode forward saved the per-tile activations as [tile][row][32 samples]
+//      (rdrf_kernels.hpp, namespace sv);
+//   2. a backward-DATA kernel (k_*_bwd) walks the same tiles with the TRANSPOSED weight packs
+//      resident in LDS: d_in = W^T dz runs on the fp32 MFMA in the same canonical register layout
+//      as the forward (dz of one layer is the B operand of the next), applies the relu masks from
+//      the saved rows, back-propagates the positional encodings and the VM gathers (atomic scatter
+//      into the channel-last planes/lines + coordinate gradients), and writes every dz as rows;
+//   3. k_dw (generic) forms dW = sum_samples dz (x) in on the MFMA: a lane reads 64 contiguous
+//      bytes of a row (16 samples) straight into its operand registers -- rows of 32 samples are
+//      already the layout the k-contraction over samples needs, so nothing is transposed.
+// References: autograd of /root/reference/models/tensorBase.py:704-850, models/tensoRF.py:118-196,
+// 446-462, 521-811 (grid_sample backward per SURVEY.md Appendix A).
+#include "rdrf_kernels.hpp"
 
+// ------------------------------------------------------------------------------------------------
+// backward LDS images (transposed packs + small layers), float offsets inside each region
+// ------------------------------------------------------------------------------------------------
+namespace pkb {
+// dynamic density phase
+constexpr int K1_W5 = 0;                          // small 3 x [2][32]
+constexpr int K1_DEN2 = K1_W5 + 3 * 64;           // small 1
+constexpr int K1_BLE2 = K1_DEN2 + 64;
+constexpr int K1_W4T = K1_BLE2 + 64;              // NBI 2 x KK 32
+constexpr int K1_W3T_X0 = K1_W4T + 2 * 32 * 64;   // NBI 2
+constexpr int K1_W3T_T = K1_W3T_X0 + 2 * 32 * 64; // NBI 1
+constexpr int K1_DEN1T_F = K1_W3T_T + 1 * 32 * 64;  // NBI 3
+constexpr int K1_DEN1T_X0 = K1_DEN1T_F + 3 * 32 * 64;
+constexpr int K1_BLE1T_F = K1_DEN1T_X0 + 2 * 32 * 64;
+constexpr int K1_BLE1T_X0 = K1_BLE1T_F + 3 * 32 * 64;
+constexpr int K1_SIZE = K1_BLE1T_X0 + 2 * 32 * 64;
+// dynamic appearance phase
+constexpr int K3_RGBV = 0;                        // small 3 x [2][64]
+constexpr int K3_RGB2T = K3_RGBV + 3 * 128;       // NBI 4 x KK 64
+constexpr int K3_RGB1T_F = K3_RGB2T + 4 * 64 * 64;   // NBI 1
+constexpr int K3_RGB1T_X0 = K3_RGB1T_F + 1 * 64 * 64;  // NBI 2
+constexpr int K3_BASIST = K3_RGB1T_X0 + 2 * 64 * 64;  // NBI 7 x KK 16
+constexpr int K3_SIZE = K3_BASIST + 7 * 16 * 64;
+// static appearance phase
+constexpr int S3_W3 = 0;                          // small 3 x [2][64]
+constexpr int S3_W2T = S3_W3 + 3 * 128;           // NBI 4 x 64
+constexpr int S3_W1T_F = S3_W2T + 4 * 64 * 64;    // NBI 1
+constexpr int S3_W1T_P = S3_W1T_F + 1 * 64 * 64;  // NBI 4
+constexpr int S3_BASIST = S3_W1T_P + 4 * 64 * 64; // NBI 3 x KK 16
+constexpr int S3_SIZE = S3_BASIST + 3 * 16 * 64;
+// scene flow
+constexpr int SF_W6 = 0;                          // small 6 x [2][32]
+constexpr int SF_W4T = SF_W6 + 6 * 64;
+constexpr int SF_W2T = SF_W4T + 2 * 32 * 64;
+constexpr int SF_W0T = SF_W2T + 2 * 32 * 64;      // NBI 2 (40 -> 64)
+constexpr int SF_SIZE = SF_W0T + 2 * 32 * 64;
+constexpr int REG_K1 = 0, REG_K3 = REG_K1 + K1_SIZE, REG_SF = REG_K3 + K3_SIZE,
+              REG_DYN_END = REG_SF + SF_SIZE;
+constexpr int REG_S3 = 0, REG_STAT_END = S3_SIZE;
+static_assert(K1_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
+              "backward weight images must fit the LDS");
+}  // namespace pkb
+
+// ------------------------------------------------------------------------------------------------
+// argument block of the backward kernels
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const float* rays;
+  const float* ts;
+  const float* xyz;
+  const float* z;
+  const uint8_t* valid;
+  int N, S;
+  Box box;
+  float distance_scale, weight_thres, density_shift;
+  int act, ray_type, static_head;
+  // upstream gradients (nullable)
+  const float *g_rgb, *g_sigma, *g_weight, *g_dists, *g_blending, *g_xyz_prime;
+  // saved by the forward
+  SavedPtrs sp;
+  // packed weights (global) and gradient rows (workspace)
+  const float* pk;
+  float* grows1;   // density-phase dz rows
+  float* grows3;   // appearance-phase dz rows
+  float* dxw_app;  // [N*S*3] coordinate grads arriving from the appearance phase
+  float* dxn_app;  // [N*S*3]
+  float* dtout;    // [N*32]
+  // outputs
+  float* g_xyz;
+};
+
+struct StaticG {
+  RdrfVM density, app;
+  float *b3, *w3;
+};
+struct DynG {
+  RdrfVM density, blending, app;
+  float *rbv, *rwv, *l5b, *db2, *bb2;
+};
+
+// ------------------------------------------------------------------------------------------------
+// VM gather backward for one quad: scatter into plane / line (atomics) + coordinate gradients
+// ------------------------------------------------------------------------------------------------
+RDRF_D void atomic_add4(float* p, f32x4 v) {
+  atomicAdd(p + 0, v.x);
+  atomicAdd(p + 1, v.y);
+  atomicAdd(p + 2, v.z);
+  atomicAdd(p + 3, v.w);
+}
+RDRF_D float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <int C0Q, int C1Q>
+RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
+                            float x2, f32x4 dq, float& dx0, float& dx1, float& dx2) {
+  QuadSel<C0Q, C1Q> s = quad_sel<C0Q, C1Q>(g);
+  const int pi = s.pi;
+  const float cx = pi == 2 ? x1 : x0;
+  const float cy = pi == 0 ? x1 : x2;
+  const float cl = pi == 0 ? x2 : (pi == 1 ? x1 : x0);
+  const float* P = pi == 0 ? vm.plane[0] : (pi == 1 ? vm.plane[1] : vm.plane[2]);
+  const float* Lp = pi == 0 ? vm.line[0] : (pi == 1 ? vm.line[1] : vm.line[2]);
+  float* GP = pi == 0 ? gvm.plane[0] : (pi == 1 ? gvm.plane[1] : gvm.plane[2]);
+  float* GL = pi == 0 ? gvm.line[0] : (pi == 1 ? gvm.line[1] : gvm.line[2]);
+  const int H = pi == 0 ? vm.H[0] : (pi == 1 ? vm.H[1] : vm.H[2]);
+  const int W = pi == 0 ? vm.W[0] : (pi == 1 ? vm.W[1] : vm.W[2]);
+  const int L = pi == 0 ? vm.L[0] : (pi == 1 ? vm.L[1] : vm.L[2]);
+  const int lv = s.level, st = 1 << lv;
+  const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
+  Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
+  const int C = s.C, qo = 4 * s.q;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const size_t o00 = (size_t)((ty.i0 << lv) * W + (tx.i0 << lv)) * C + qo;
+  const size_t o01 = (size_t)((ty.i0 << lv) * W + ((tx.i0 + 1) << lv)) * C + qo;
+  const size_t o10 = (size_t)(((ty.i0 + 1) << lv) * W + (tx.i0 << lv)) * C + qo;
+  const size_t o11 = (size_t)(((ty.i0 + 1) << lv) * W + ((tx.i0 + 1) << lv)) * C + qo;
+  const bool k00 = ty.ok0 && tx.ok0, k01 = ty.ok0 && tx.ok1, k10 = ty.ok1 && tx.ok0,
+             k11 = ty.ok1 && tx.ok1;
+  const f32x4 v00 = k00 ? ld4(P + o00) : zero, v01 = k01 ? ld4(P + o01) : zero;
+  const f32x4 v10 = k10 ? ld4(P + o10) : zero, v11 = k11 ? ld4(P + o11) : zero;
+  const size_t l0 = (size_t)(tl.i0 << lv) * C + qo, l1 = (size_t)((tl.i0 + 1) << lv) * C + qo;
+  const f32x4 a0 = tl.ok0 ? ld4(Lp + l0) : zero, a1 = tl.ok1 ? ld4(Lp + l1) : zero;
+  const f32x4 pv = v00 * (tx.w0 * ty.w0) + v01 * (tx.w1 * ty.w0) + v10 * (tx.w0 * ty.w1) +
+                   v11 * (tx.w1 * ty.w1);
+  const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
+  const f32x4 dp = dq * lvv;  // grad wrt the interpolated plane quad
+  const f32x4 dl = dq * pv;   // grad wrt the interpolated line quad
+  if (k00) atomic_add4(GP + o00, dp * (tx.w0 * ty.w0));
+  if (k01) atomic_add4(GP + o01, dp * (tx.w1 * ty.w0));
+  if (k10) atomic_add4(GP + o10, dp * (tx.w0 * ty.w1));
+  if (k11) atomic_add4(GP + o11, dp * (tx.w1 * ty.w1));
+  if (tl.ok0) atomic_add4(GL + l0, dl * tl.w0);
+  if (tl.ok1) atomic_add4(GL + l1, dl * tl.w1);
+  // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
+  const float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
+  const float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
+  const float gcl = 0.5f * (float)(Ls - 1) * dot4(dl, a1 - a0);
+  if (pi == 0) { dx0 += gcx; dx1 += gcy; dx2 += gcl; }
+  else if (pi == 1) { dx0 += gcx; dx2 += gcy; dx1 += gcl; }
+  else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
+}
+
+// d(X0)/d(xn): X0 = [xn, t | (sin q, cos q) pairs], q_j = xn[j/10] * 2^(j%10); returns this lane
+// half's partial (combine with __shfl_xor 32)
+RDRF_D void x0_bwd(const float (&X0)[32], const float (&dX0)[32], int h, float& d0, float& d1,
+                   float& d2) {
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o == 0 && h == 0) {
+      d0 += dX0[0]; d1 += dX0[1]; d2 += dX0[2];
+    } else {
+      const int k = 2 * o + h - 1;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int j = 2 * k + p;
+        const int d = j / 10, f = j - d * 10;
+        const float sv = X0[o * 4 + 2 * p], cv = X0[o * 4 + 2 * p + 1];
+        const float dq = ldexpf(dX0[o * 4 + 2 * p] * cv - dX0[o * 4 + 2 * p + 1] * sv, f);
+        if (d == 0) d0 += dq; else if (d == 1) d1 += dq; else d2 += dq;
+      }
+    }
+  }
+}
+
+RDRF_D float act_grad(float f, int act, float shift) {
+  return act == RDRF_ACT_RELU ? (f > 0.0f ? 1.0f : 0.0f) : sigmoidf_(f + shift);
+}
+
+template <int NB>
+RDRF_D void acc_zero(f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// appearance phase backward-data (dynamic: MLP_Fea_late_view; static: MLP_Fea | TimeEmbedding)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
+  __shared__ __attribute__((aligned(16))) float lds[pkb::K3_SIZE];
+  lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = a.sp.hdr->count;
+  const int ntiles = (count + 31) >> 5;
+  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < count;
+    const int idx = act ? a.sp.list[li] : 0;
+    const int n = idx / a.S;
+    const float* svb = a.sp.act3 + (size_t)tile * sv::K3_ROWS * 32;
+    float* gb = a.grows3 + (size_t)tile * sv::K3G_ROWS * 32;
+    float vx, vy, vz;
+    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    // ---- output layer: v = Wv [H2, vd] + b ; rgb = sigmoid(v)
+    float H2[64];
+    load_rows<64>(svb, sv::K3_H2, H2, s, h);
+    float dzv[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small<64>(H2, lds + pkb::K3_RGBV + o * 128, h) + w.rbv[o];
+      v += w.rwv[o * 131 + 128] * vx + w.rwv[o * 131 + 129] * vy + w.rwv[o * 131 + 130] * vz;
+      const float r = sigmoidf_(v);
+      const float g = (act && a.g_rgb) ? a.g_rgb[(size_t)idx * 3 + o] : 0.f;
+      dzv[o] = g * r * (1.0f - r);
+      if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
+      // view-direction columns and bias of the output layer (tiny: wave reduce + one atomic)
+      const float m = h == 0 ? dzv[o] : 0.f;
+      const float sb = wave_sum(m), s0 = wave_sum(m * vx), s1 = wave_sum(m * vy), s2 = wave_sum(m * vz);
+      if (lane == 0) {
+        atomicAdd(gw.rbv + o, sb);
+        atomicAdd(gw.rwv + o * 131 + 128, s0);
+        atomicAdd(gw.rwv + o * 131 + 129, s1);
+        atomicAdd(gw.rwv + o * 131 + 130, s2);
+      }
+    }
+    float dz2[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+      float d = 0.f;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) d = fmaf(lds[pkb::K3_RGBV + o * 128 + h * 64 + kk], dzv[o], d);
+      dz2[kk] = H2[kk] > 0.f ? d : 0.f;
+    }
+    save_rows<64>(gb, sv::K3G_DZ2, dz2, s, h);
+    // ---- layer 2 backward: dH1 = W2^T dz2
+    float dz1[64];
+    {
+      f32x16 acc[4];
+      acc_zero<4>(acc);
+      mfma_seg<4, 64>(acc, dz2, lds + pkb::K3_RGB2T, lane);
+      float H1[64];
+      load_rows<64>(svb, sv::K3_H1, H1, s, h);
+#pragma unroll
+      for (int kk = 0; kk < 64; ++kk) dz1[kk] = H1[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
+    }
+    save_rows<64>(gb, sv::K3G_DZ1, dz1, s, h);
+    // ---- layer 1 backward: feature block and X0 block (t / PE(t) carry no gradient)
+    float dF[16], dX0[32];
+    {
+      f32x16 acc[1];
+      acc_zero<1>(acc);
+      mfma_seg<1, 64>(acc, dz1, lds + pkb::K3_RGB1T_F, lane);
+      acc_copy<1>(dF, acc);
+      f32x16 acc2[2];
+      acc_zero<2>(acc2);
+      mfma_seg<2, 64>(acc2, dz1, lds + pkb::K3_RGB1T_X0, lane);
+      acc_copy<2>(dX0, acc2);
+    }
+    save_rows<16>(gb, sv::K3G_DF, dF, s, h);
+    float dn0 = 0.f, dn1 = 0.f, dn2 = 0.f;
+    {
+      float X0[32];
+      load_rows<32>(svb, sv::K3_X0, X0, s, h);
+      x0_bwd(X0, dX0, h, dn0, dn1, dn2);
+    }
+    dn0 += __shfl_xor(dn0, 32, 64); dn1 += __shfl_xor(dn1, 32, 64); dn2 += __shfl_xor(dn2, 32, 64);
+    // ---- basis backward + gather backward at the warped coordinate
+    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+    {
+      f32x16 acc[7];
+      acc_zero<7>(acc);
+      mfma_seg<7, 16>(acc, dF, lds + pkb::K3_BASIST, lane);
+      const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
+                  xw2 = a.sp.xw[(size_t)idx * 3 + 2];
+      if (act) {
+#pragma unroll
+        for (int o = 0; o < 27; ++o) {
+          f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
+                      acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
+          gather_quad_bwd<12, 3>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, dw0, dw1, dw2);
+        }
+      }
+    }
+    dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
+    if (act && h == 0) {
+      a.dxw_app[(size_t)idx * 3 + 0] = dw0; a.dxw_app[(size_t)idx * 3 + 1] = dw1;
+      a.dxw_app[(size_t)idx * 3 + 2] = dw2;
+      a.dxn_app[(size_t)idx * 3 + 0] = dn0; a.dxn_app[(size_t)idx * 3 + 1] = dn1;
+      a.dxn_app[(size_t)idx * 3 + 2] = dn2;
+    }
+  }
+}
+
+template <int HEAD>
+__global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, StaticG gw) {
+  __shared__ __attribute__((aligned(16))) float lds[pkb::S3_SIZE];
+  lds_fill(lds, a.pk + pkb::REG_S3, pkb::S3_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = a.sp.hdr->count;
+  const int ntiles = (count + 31) >> 5;
+  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < count;
+    const int idx = act ? a.sp.list[li] : 0;
+    const int n = idx / a.S;
+    const float* svb = a.sp.act3 + (size_t)tile * sv::S3_ROWS * 32;
+    float* gb = a.grows3 + (size_t)tile * sv::K3G_ROWS * 32;
+    float vx, vy, vz;
+    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    float H2[64];
+    load_rows<64>(svb, sv::S3_H2, H2, s, h);
+    float dzv[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small<64>(H2, lds + pkb::S3_W3 + o * 128, h) + w.b3[o];
+      if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING)
+        v += w.w3[o * 131 + 128] * vx + w.w3[o * 131 + 129] * vy + w.w3[o * 131 + 130] * vz;
+      const float r = sigmoidf_(v);
+      const float g = (act && a.g_rgb) ? a.g_rgb[(size_t)idx * 3 + o] : 0.f;
+      dzv[o] = g * r * (1.0f - r);
+      if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
+      const float m = h == 0 ? dzv[o] : 0.f;
+      const float sb = wave_sum(m);
+      if (lane == 0) atomicAdd(gw.b3 + o, sb);
+      if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING) {
+        const float s0 = wave_sum(m * vx), s1 = wave_sum(m * vy), s2 = wave_sum(m * vz);
+        if (lane == 0) {
+          atomicAdd(gw.w3 + o * 131 + 128, s0);
+          atomicAdd(gw.w3 + o * 131 + 129, s1);
+          atomicAdd(gw.w3 + o * 131 + 130, s2);
+        }
+      }
+    }
+    float dz2[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+      float d = 0.f;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) d = fmaf(lds[pkb::S3_W3 + o * 128 + h * 64 + kk], dzv[o], d);
+      dz2[kk] = H2[kk] > 0.f ? d : 0.f;
+    }
+    save_rows<64>(gb, sv::K3G_DZ2, dz2, s, h);
+    float dz1[64];
+    {
+      f32x16 acc[4];
+      acc_zero<4>(acc);
+      mfma_seg<4, 64>(acc, dz2, lds + pkb::S3_W2T, lane);
+      float H1[64];
+      load_rows<64>(svb, sv::S3_H1, H1, s, h);
+#pragma unroll
+      for (int kk = 0; kk < 64; ++kk) dz1[kk] = H1[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
+    }
+    save_rows<64>(gb, sv::K3G_DZ1, dz1, s, h);
+    float dF[16];
+    {
+      f32x16 acc[1];
+      acc_zero<1>(acc);
+      mfma_seg<1, 64>(acc, dz1, lds + pkb::S3_W1T_F, lane);
+      acc_copy<1>(dF, acc);
+      f32x16 accp[4];
+      acc_zero<4>(accp);
+      mfma_seg<4, 64>(accp, dz1, lds + pkb::S3_W1T_P, lane);
+      float P[64];
+      load_rows<64>(svb, sv::S3_P, P, s, h);
+      // PE2 backward: P[4r..4r+3] = (sin f, cos f, sin 2f, cos 2f) of feature slot r
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d0 = accp[r >> 2][(r & 3) * 4 + 0], d1 = accp[r >> 2][(r & 3) * 4 + 1];
+        const float d2 = accp[r >> 2][(r & 3) * 4 + 2], d3 = accp[r >> 2][(r & 3) * 4 + 3];
+        dF[r] += d0 * P[4 * r + 1] - d1 * P[4 * r + 0] + 2.0f * (d2 * P[4 * r + 3] - d3 * P[4 * r + 2]);
+      }
+    }
+    // the view-direction slots (27..29) of the feature block are not features
+    if (HEAD == RDRF_HEAD_MLP_FEA) {
+      if (h == 0) dF[15] = 0.f;
+      else { dF[12] = 0.f; dF[13] = 0.f; }
+    }
+    save_rows<16>(gb, sv::K3G_DF, dF, s, h);
+    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+    {
+      f32x16 acc[3];
+      acc_zero<3>(acc);
+      mfma_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, lane);
+      const float x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+      if (act) {
+#pragma unroll
+        for (int o = 0; o < 9; ++o) {
+          f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
+                      acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
+          gather_quad_bwd<12, 3>(w.app, gw.app, 2 * o + h, x0, x1, x2, dq, dw0, dw1, dw2);
+        }
+      }
+    }
+    dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
+    if (act && h == 0 && a.g_xyz) {  // static coordinates are xn(xyz): straight to g_xyz
+      atomicAdd(a.g_xyz + (size_t)idx * 3 + 0, dw0 * a.box.inv[0]);
+      atomicAdd(a.g_xyz + (size_t)idx * 3 + 1, dw1 * a.box.inv[1]);
+      atomicAdd(a.g_xyz + (size_t)idx * 3 + 2, dw2 * a.box.inv[2]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d(weight)/d(alpha) along a ray.  weight_k = alpha_k T_k, T_k = prod_{j<k} p_j, p = 1-alpha+1e-10
+//   dL/dalpha_k = gw_k T_k - (sum_{m>k} gw_m w_m) / p_k
+// ------------------------------------------------------------------------------------------------
+
+// static field, density phase backward: wave per ray, lane per sample
+__global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w, StaticG gw) {
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x;
+  if (n >= a.N) return;
+  float vx, vy, vz;
+  const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float total = 0.f;
+  if (a.g_weight) {  // pass 0: sum_m gw_m w_m
+    float carry = 1.0f;
+    for (int j0 = 0; j0 < a.S; j0 += 64) {
+      const int j = j0 + lane;
+      const bool act = j < a.S;
+      const int idx = n * a.S + (act ? j : 0);
+      const bool vld = act && a.valid[idx] != 0;
+      const float sigma = vld ? density_act(a.sp.raw[idx], a.act, a.density_shift) : 0.f;
+      const float zj = act ? a.z[idx] : 0.f;
+      const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+      const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+      const float alpha = 1.0f - expf(-sigma * ds);
+      const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+      const float incl = scan_mul64(p, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.0f;
+      const float wt = alpha * carry * excl;
+      carry *= __shfl(incl, 63, 64);
+      total += act ? a.g_weight[idx] * wt : 0.f;
+    }
+    total = wave_sum(total);
+  }
+  float carry = 1.0f, prefix = 0.f;
+  for (int j0 = 0; j0 < a.S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool act = j < a.S;
+    const int idx = n * a.S + (act ? j : 0);
+    const bool vld = act && a.valid[idx] != 0;
+    const float f = a.sp.raw[idx];
+    const float sigma = vld ? density_act(f, a.act, a.density_shift) : 0.f;
+    const float zj = act ? a.z[idx] : 0.f;
+    const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+    const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+    const float alpha = 1.0f - expf(-sigma * ds);
+    const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+    float g_alpha = 0.f;
+    if (a.g_weight) {
+      const float incl = scan_mul64(p, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.0f;
+      const float T = carry * excl;
+      carry *= __shfl(incl, 63, 64);
+      const float gwv = act ? a.g_weight[idx] : 0.f;
+      const float c = gwv * alpha * T;
+      // inclusive prefix sum of c over the wave
+      float inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      const float suffix = total - (prefix + inc);
+      prefix += __shfl(inc, 63, 64);
+      g_alpha = gwv * T - suffix / p;
+    }
+    float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
+    g_sigma += g_alpha * ds * (1.0f - alpha);
+    const float gf = vld ? g_sigma * act_grad(f, a.act, a.density_shift) : 0.f;
+    if (vld && gf != 0.f) {
+      const float x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+      const f32x4 dq = {gf, gf, gf, gf};
+#pragma unroll
+      for (int g = 0; g < 6; ++g) gather_quad_bwd<4, 1>(w.density, gw.density, g, x0, x1, x2, dq, d0, d1, d2);
+      if (a.g_xyz) {
+        atomicAdd(a.g_xyz + (size_t)idx * 3 + 0, d0 * a.box.inv[0]);
+        atomicAdd(a.g_xyz + (size_t)idx * 3 + 1, d1 * a.box.inv[1]);
+        atomicAdd(a.g_xyz + (size_t)idx * 3 + 2, d2 * a.box.inv[2]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic field, density / blending / warp backward-data: wave per ray, 32-sample tiles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
+  __shared__ __attribute__((aligned(16))) float lds[pkb::K1_SIZE];
+  lds_fill(lds, a.pk + pkb::REG_K1, pkb::K1_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int tpr = (a.S + 31) >> 5;
+  for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
+    float vx, vy, vz;
+    const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    float total = 0.f;
+    if (a.g_weight) {
+      float carry = 1.0f;
+      for (int j0 = 0; j0 < a.S; j0 += 32) {
+        const int j = j0 + s;
+        const bool act = j < a.S;
+        const int idx = n * a.S + (act ? j : 0);
+        const bool vld = act && a.valid[idx] != 0;
+        const float sigma = vld ? density_act(a.sp.raw[(size_t)idx * 2], a.act, a.density_shift) : 0.f;
+        const float zj = act ? a.z[idx] : 0.f;
+        const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+        const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+        const float alpha = 1.0f - expf(-sigma * ds);
+        const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+        const float incl = scan_mul32(p, s);
+        float excl = __shfl_up(incl, 1, 32);
+        if (s == 0) excl = 1.0f;
+        const float wt = alpha * carry * excl;
+        carry *= __shfl(incl, 31, 32);
+        total += (act && h == 0) ? a.g_weight[idx] * wt : 0.f;
+      }
+      total = wave_sum(total);
+    }
+    float carry = 1.0f, prefix = 0.f;
+    float dTacc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dTacc[i] = 0.f;
+    for (int j0 = 0; j0 < a.S; j0 += 32) {
+      const int j = j0 + s;
+      const bool act = j < a.S;
+      const int idx = n * a.S + (act ? j : 0);
+      const bool vld = act && a.valid[idx] != 0;
+      const size_t tl = (size_t)n * tpr + (j0 >> 5);
+      const float* svb = a.sp.act1 + tl * sv::K1_ROWS * 32;
+      float* gb = a.grows1 + tl * sv::K1G_ROWS * 32;
+      const float fd = a.sp.raw[(size_t)idx * 2], fb = a.sp.raw[(size_t)idx * 2 + 1];
+      const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.f;
+      const float zj = act ? a.z[idx] : 0.f;
+      const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+      const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+      const float alpha = 1.0f - expf(-sigma * ds);
+      const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+      float g_alpha = 0.f;
+      if (a.g_weight) {
+        const float incl = scan_mul32(p, s);
+        float excl = __shfl_up(incl, 1, 32);
+        if (s == 0) excl = 1.0f;
+        const float T = carry * excl;
+        carry *= __shfl(incl, 31, 32);
+        const float gwv = act ? a.g_weight[idx] : 0.f;
+        float inc = gwv * alpha * T;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+          const float o = __shfl_up(inc, d, 32);
+          if (s >= d) inc += o;
+        }
+        const float suffix = total - (prefix + inc);
+        prefix += __shfl(inc, 31, 32);
+        g_alpha = gwv * T - suffix / p;
+      }
+      float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
+      g_sigma += g_alpha * ds * (1.0f - alpha);
+      const float g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
+      const float bl = sigmoidf_(fb);
+      const float g_fb = (vld && a.g_blending) ? a.g_blending[idx] * bl * (1.0f - bl) : 0.f;
+      // coordinate gradients arriving from the appearance phase
+      float dw0 = act ? a.dxw_app[(size_t)idx * 3 + 0] : 0.f, dw1 = act ? a.dxw_app[(size_t)idx * 3 + 1] : 0.f,
+            dw2 = act ? a.dxw_app[(size_t)idx * 3 + 2] : 0.f;
+      float dn0 = act ? a.dxn_app[(size_t)idx * 3 + 0] : 0.f, dn1 = act ? a.dxn_app[(size_t)idx * 3 + 1] : 0.f,
+            dn2 = act ? a.dxn_app[(size_t)idx * 3 + 2] : 0.f;
+      if (h == 1) { dw0 = dw1 = dw2 = 0.f; dn0 = dn1 = dn2 = 0.f; }  // halves are summed below
+      const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
+                  xw2 = a.sp.xw[(size_t)idx * 3 + 2];
+      f32x16 accX[2];  // d(X0) accumulated over density head, blending head and warp layer 3
+      acc_zero<2>(accX);
+      // ---- density head and blending head
+#pragma unroll
+      for (int head = 0; head < 2; ++head) {
+        const float gfh = head == 0 ? g_fd : g_fb;
+        float Hh[32], dzh[32];
+        load_rows<32>(svb, head == 0 ? sv::K1_HD : sv::K1_HB, Hh, s, h);
+        const float* w2 = lds + (head == 0 ? pkb::K1_DEN2 : pkb::K1_BLE2) + h * 32;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) dzh[kk] = Hh[kk] > 0.f ? w2[kk] * gfh : 0.f;
+        save_rows<32>(gb, head == 0 ? sv::K1G_DZD : sv::K1G_DZB, dzh, s, h);
+        f32x16 accF[3];
+        acc_zero<3>(accF);
+        mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1_DEN1T_F : pkb::K1_BLE1T_F), lane);
+        mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1_DEN1T_X0 : pkb::K1_BLE1T_X0), lane);
+        if (vld) {
+#pragma unroll
+          for (int o = 0; o < 9; ++o) {
+            f32x4 dq = {accF[o >> 2][(o & 3) * 4 + 0], accF[o >> 2][(o & 3) * 4 + 1],
+                        accF[o >> 2][(o & 3) * 4 + 2], accF[o >> 2][(o & 3) * 4 + 3]};
+            if (head == 0)
+              gather_quad_bwd<4, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, dw0, dw1, dw2);
+            else
+              gather_quad_bwd<4, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, dw0, dw1, dw2);
+          }
+        }
+      }
+      dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
+      // xw = normalize(unnormalize(xn) + delta); xyz_prime = xyz + delta
+      float dd0 = dw0 * a.box.inv[0], dd1 = dw1 * a.box.inv[1], dd2 = dw2 * a.box.inv[2];
+      float gp0 = 0.f, gp1 = 0.f, gp2 = 0.f;
+      if (act && a.g_xyz_prime) {
+        gp0 = a.g_xyz_prime[(size_t)idx * 3 + 0]; gp1 = a.g_xyz_prime[(size_t)idx * 3 + 1];
+        gp2 = a.g_xyz_prime[(size_t)idx * 3 + 2];
+      }
+      dd0 += gp0; dd1 += gp1; dd2 += gp2;
+      if (!act) { dd0 = dd1 = dd2 = 0.f; }
+      // small-layer dz rows: [d_delta(3), g_fd, g_fb]
+      if (h == 0) {
+        gb[(size_t)(sv::K1G_SM + 0) * 32 + s] = dd0; gb[(size_t)(sv::K1G_SM + 1) * 32 + s] = dd1;
+        gb[(size_t)(sv::K1G_SM + 2) * 32 + s] = dd2; gb[(size_t)(sv::K1G_SM + 3) * 32 + s] = g_fd;
+        gb[(size_t)(sv::K1G_SM + 4) * 32 + s] = g_fb;
+      }
+      {  // biases of the small layers
+        const float m0 = h == 0 ? dd0 : 0.f, m1 = h == 0 ? dd1 : 0.f, m2 = h == 0 ? dd2 : 0.f;
+        const float m3 = h == 0 ? g_fd : 0.f, m4 = h == 0 ? g_fb : 0.f;
+        const float r0 = wave_sum(m0), r1 = wave_sum(m1), r2 = wave_sum(m2), r3 = wave_sum(m3),
+                    r4 = wave_sum(m4);
+        if (lane == 0) {
+          atomicAdd(gw.l5b + 0, r0); atomicAdd(gw.l5b + 1, r1); atomicAdd(gw.l5b + 2, r2);
+          atomicAdd(gw.db2, r3); atomicAdd(gw.bb2, r4);
+        }
+      }
+      // ---- warp MLP backward: layer5 (VALU) -> layer4 -> layer3
+      float dz4[32];
+      {
+        float H4[32];
+        load_rows<32>(svb, sv::K1_H4, H4, s, h);
+        const float* w5 = lds + pkb::K1_W5 + h * 32;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+          const float d = w5[kk] * dd0 + w5[64 + kk] * dd1 + w5[128 + kk] * dd2;
+          dz4[kk] = H4[kk] > 0.f ? d : 0.f;
+        }
+      }
+      save_rows<32>(gb, sv::K1G_DZ4, dz4, s, h);
+      float dz3[32];
+      {
+        f32x16 acc[2];
+        acc_zero<2>(acc);
+        mfma_seg<2, 32>(acc, dz4, lds + pkb::K1_W4T, lane);
+        float H3[32];
+        load_rows<32>(svb, sv::K1_H3, H3, s, h);
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) dz3[kk] = H3[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
+      }
+      save_rows<32>(gb, sv::K1G_DZ3, dz3, s, h);
+      mfma_seg<2, 32>(accX, dz3, lds + pkb::K1_W3T_X0, lane);
+      {
+        f32x16 accT[1];
+        acc_zero<1>(accT);
+        mfma_seg<1, 32>(accT, dz3, lds + pkb::K1_W3T_T, lane);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dTacc[i] += accT[0][i];
+      }
+      // ---- positional encoding backward -> d(xn); plus the identity path xw <- xn
+      {
+        float X0[32], dX0[32];
+        load_rows<32>(svb, sv::K1_X0, X0, s, h);
+        acc_copy<2>(dX0, accX);
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+        x0_bwd(X0, dX0, h, e0, e1, e2);
+        e0 += __shfl_xor(e0, 32, 64); e1 += __shfl_xor(e1, 32, 64); e2 += __shfl_xor(e2, 32, 64);
+        dn0 += __shfl_xor(dn0, 32, 64); dn1 += __shfl_xor(dn1, 32, 64); dn2 += __shfl_xor(dn2, 32, 64);
+        dn0 += e0 + dw0; dn1 += e1 + dw1; dn2 += e2 + dw2;
+      }
+      if (act && h == 0 && a.g_xyz) {
+        a.g_xyz[(size_t)idx * 3 + 0] += dn0 * a.box.inv[0] + gp0;
+        a.g_xyz[(size_t)idx * 3 + 1] += dn1 * a.box.inv[1] + gp1;
+        a.g_xyz[(size_t)idx * 3 + 2] += dn2 * a.box.inv[2] + gp2;
+      }
+    }
+    // per-ray d(tout): sum over the samples (lanes of each half)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = dTacc[i];
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if (s == 0) a.dtout[(size_t)n * 32 + elem_of(i, h)] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// time branch backward: [t, PE8(t)] -> 64 -> relu -> 30, one thread per ray, 128 rays per block;
+// parameter gradients are reduced inside the block through LDS, then one atomic per entry.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_time_branch_bwd(const float* __restrict__ ts, DynW w, int N,
+                                                         const float* __restrict__ dtout,
+                                                         float* __restrict__ g_l1w,
+                                                         float* __restrict__ g_l1b,
+                                                         float* __restrict__ g_l2w,
+                                                         float* __restrict__ g_l2b) {
+  __shared__ float s_tin[128][17];
+  __shared__ float s_h[128][65];
+  __shared__ float s_dz1[128][65];
+  __shared__ float s_dz2[128][31];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x * 128 + tid;
+  const bool act = n < N;
+  float tin[17];
+  const float t = act ? ts[n] : 0.f;
+  tin[0] = t;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) sincosf(ldexpf(t, f), &tin[1 + f], &tin[9 + f]);
+  for (int i = 0; i < 17; ++i) s_tin[tid][i] = tin[i];
+  for (int o = 0; o < 30; ++o) s_dz2[tid][o] = act ? dtout[(size_t)n * 32 + o] : 0.f;
+  for (int k = 0; k < 64; ++k) {
+    float hk = w.l1b[k];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) hk = fmaf(w.l1w[k * 17 + i], tin[i], hk);
+    float dh = 0.f;
+    for (int o = 0; o < 30; ++o) dh = fmaf(w.l2w[o * 64 + k], s_dz2[tid][o], dh);
+    s_h[tid][k] = fmaxf(hk, 0.f);
+    s_dz1[tid][k] = hk > 0.f ? dh : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 30 * 64; e += 128) {
+    const int o = e / 64, k = e - o * 64;
+    float a = 0.f;
+    for (int r = 0; r < 128; ++r) a = fmaf(s_dz2[r][o], s_h[r][k], a);
+    atomicAdd(g_l2w + e, a);
+  }
+  for (int e = tid; e < 64 * 17; e += 128) {
+    const int k = e / 17, i = e - k * 17;
+    float a = 0.f;
+    for (int r = 0; r < 128; ++r) a = fmaf(s_dz1[r][k], s_tin[r][i], a);
+    atomicAdd(g_l1w + e, a);
+  }
+  if (tid < 30) {
+    float a = 0.f;
+    for (int r = 0; r < 128; ++r) a += s_dz2[r][tid];
+    atomicAdd(g_l2b + tid, a);
+  }
+  if (tid < 64) {
+    float a = 0.f;
+    for (int r = 0; r < 128; ++r) a += s_dz1[r][tid];
+    atomicAdd(g_l1b + tid, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene flow backward-data
+// ------------------------------------------------------------------------------------------------
+RDRF_D void sf_x_bwd(const float (&X)[20], const float (&dX)[20], int h, float& d0, float& d1,
+                     float& d2) {
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    if (o == 0 && h == 0) {
+      d0 += dX[0]; d1 += dX[1]; d2 += dX[2];
+    } else {
+      const int k = 2 * o + h - 1;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pr = 2 * k + p;
+        if (pr < 12) {
+          const int d = pr >> 2, f = pr & 3;
+          const float dq = ldexpf(dX[o * 4 + 2 * p] * X[o * 4 + 2 * p + 1] -
+                                  dX[o * 4 + 2 * p + 1] * X[o * 4 + 2 * p], f);
+          if (d == 0) d0 += dq; else if (d == 1) d1 += dq; else d2 += dq;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_scene_flow_bwd(int N, int S, Box box,
+                                                        const float* __restrict__ pkg,
+                                                        const float* __restrict__ act_rows,
+                                                        float* __restrict__ grows,
+                                                        const float* __restrict__ g_f,
+                                                        const float* __restrict__ g_b,
+                                                        float* __restrict__ g_sfb6,
+                                                        float* __restrict__ g_pts) {
+  __shared__ __attribute__((aligned(16))) float lds[pkb::SF_SIZE];
+  lds_fill(lds, pkg + pkb::REG_SF, pkb::SF_SIZE);
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int total = N * S;
+  const int ntiles = (total + 31) >> 5;
+  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < total;
+    const int idx = act ? li : 0;
+    const float* svb = act_rows + (size_t)tile * sv::SF_ROWS * 32;
+    float* gb = grows + (size_t)tile * sv::SFG_ROWS * 32;
+    float dz6[6];
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+      const float* gsrc = o < 3 ? g_f : g_b;
+      dz6[o] = (act && gsrc) ? gsrc[(size_t)idx * 3 + (o % 3)] : 0.f;
+      if (h == 0) gb[(size_t)(sv::SFG_DZ6 + o) * 32 + s] = dz6[o];
+      const float r = wave_sum(h == 0 ? dz6[o] : 0.f);
+      if (lane == 0) atomicAdd(g_sfb6 + o, r);
+    }
+    float dz[32], Hh[32];
+    load_rows<32>(svb, sv::SF_H4, Hh, s, h);
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      float d = 0.f;
+#pragma unroll
+      for (int o = 0; o < 6; ++o) d = fmaf(lds[pkb::SF_W6 + o * 64 + h * 32 + kk], dz6[o], d);
+      dz[kk] = Hh[kk] > 0.f ? d : 0.f;
+    }
+    save_rows<32>(gb, sv::SFG_DZ4, dz, s, h);
+    f32x16 acc[2];
+    acc_zero<2>(acc);
+    mfma_seg<2, 32>(acc, dz, lds + pkb::SF_W4T, lane);
+    load_rows<32>(svb, sv::SF_H2, Hh, s, h);
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) dz[kk] = Hh[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
+    save_rows<32>(gb, sv::SFG_DZ2, dz, s, h);
+    acc_zero<2>(acc);
+    mfma_seg<2, 32>(acc, dz, lds + pkb::SF_W2T, lane);
+    load_rows<32>(svb, sv::SF_H0, Hh, s, h);
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) dz[kk] = Hh[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
+    save_rows<32>(gb, sv::SFG_DZ0, dz, s, h);
+    if (g_pts) {
+      acc_zero<2>(acc);
+      mfma_seg<2, 32>(acc, dz, lds + pkb::SF_W0T, lane);
+      float X[20], dX[20];
+      load_rows<20>(svb, sv::SF_X, X, s, h);
+#pragma unroll
+      for (int kk = 0; kk < 20; ++kk) dX[kk] = acc[kk >> 4][kk & 15];
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+      sf_x_bwd(X, dX, h, d0, d1, d2);
+      d0 += __shfl_xor(d0, 32, 64); d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
+      if (act && h == 0) {
+        g_pts[(size_t)idx * 3 + 0] += d0 * box.inv[0];
+        g_pts[(size_t)idx * 3 + 1] += d1 * box.inv[1];
+        g_pts[(size_t)idx * 3 + 2] += d2 * box.inv[2];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic dW kernel: dW[out][col(e)] += sum_tiles sum_samples dz[out][s] * in[e][s]
+// ------------------------------------------------------------------------------------------------
+struct DwJob {
+  const float* A;   // dz rows: tile t, row r at A + (t*A_stride + A_row0 + r)*32
+  int A_stride, A_row0, nbo, out_dim, out_row0;
+  const float* B;   // input rows
+  int B_stride;
+  int nblk;         // number of 32-row input blocks
+  int blk_row0[8], blk_seg[8], blk_e0[8];
+  int in_dim, ld;
+  float* dW;
+  float* db;        // bias gradient (nullable), indexed like the out rows
+  const int* count; // device sample count (compacted phases) or nullptr
+  int ntiles;
+};
+#define RDRF_MAX_DW_JOBS 12
+struct DwJobs {
+  DwJob j[RDRF_MAX_DW_JOBS];
+  int n;
+  int item0[RDRF_MAX_DW_JOBS + 1];  // prefix of work items (nbo * ceil(nblk/4)) per job
+};
+
+__global__ __launch_bounds__(256) void k_dw(DwJobs jobs) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
+  const int wave = threadIdx.x >> 6;
+  const int item = blockIdx.y * 4 + wave;
+  if (item >= jobs.item0[jobs.n]) return;
+  int ji = 0;
+  while (item >= jobs.item0[ji + 1]) ++ji;
+  const DwJob& J = jobs.j[ji];
+  const int local = item - jobs.item0[ji];
+  const int ngrp = (J.nblk + 3) >> 2;
+  const int bo = local / ngrp, grp = local - bo * ngrp;
+  const int b0 = grp * 4;
+  const int nb = (J.nblk - b0) < 4 ? (J.nblk - b0) : 4;
+  const int ntiles = J.count ? ((*J.count + 31) >> 5) : J.ntiles;
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  float bsum = 0.f;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const float* ap = J.A + ((size_t)t * J.A_stride + J.A_row0 + bo * 32 + li) * 32 + h * 16;
+    float av[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = ld4(ap + q * 4);
+      av[q * 4 + 0] = v.x; av[q * 4 + 1] = v.y; av[q * 4 + 2] = v.z; av[q * 4 + 3] = v.w;
+    }
+    if (grp == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += av[r];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb) {
+        const float* bp = J.B + ((size_t)t * J.B_stride + J.blk_row0[b0 + b] + li) * 32 + h * 16;
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = ld4(bp + q * 4);
+          bv[q * 4 + 0] = v.x; bv[q * 4 + 1] = v.y; bv[q * 4 + 2] = v.z; bv[q * 4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[r], acc[b], 0, 0, 0);
+      }
+    }
+  }
+  // write-out: C row i = (rr&3) + 8*(rr>>2) + 4*h (out neuron), column = li (input element)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b < nb) {
+      const int col = seg_imap(J.blk_seg[b0 + b], J.blk_e0[b0 + b] + li, J.in_dim);
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int orow = bo * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h - J.out_row0;
+        if (col >= 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.dW + (size_t)orow * J.ld + col, acc[b][rr]);
+      }
+    }
+  }
+  if (grp == 0 && J.db != nullptr) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    const int orow = bo * 32 + li - J.out_row0;
+    if (h == 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.db + orow, bsum);
+  }
+}
+
+static void dw_add(DwJobs& D, const float* A, int A_stride, int A_row0, int nbo, int out_dim,
+                   int out_row0, const float* B, int B_stride, int in_dim, int ld, float* dW,
+                   float* db, const int* count, int ntiles) {
+  DwJob& j = D.j[D.n];
+  memset(&j, 0, sizeof(j));
+  j.A = A; j.A_stride = A_stride; j.A_row0 = A_row0; j.nbo = nbo; j.out_dim = out_dim;
+  j.out_row0 = out_row0; j.B = B; j.B_stride = B_stride; j.nblk = 0; j.in_dim = in_dim; j.ld = ld;
+  j.dW = dW; j.db = db; j.count = count; j.ntiles = ntiles;
+  D.n++;
+}
+static void dw_blk(DwJobs& D, int row0, int seg, int e0) {
+  DwJob& j = D.j[D.n - 1];
+  j.blk_row0[j.nblk] = row0; j.blk_seg[j.nblk] = seg; j.blk_e0[j.nblk] = e0;
+  j.nblk++;
+}
+static int dw_launch(DwJobs& D, hipStream_t stream) {
+  D.item0[0] = 0;
+  for (int i = 0; i < D.n; ++i) D.item0[i + 1] = D.item0[i] + D.j[i].nbo * ((D.j[i].nblk + 3) / 4);
+  const int items = D.item0[D.n];
+  const int gy = (items + 3) / 4;
+  int gx = (256 * 8 + gy - 1) / gy;
+  gx = gx < 1 ? 1 : gx;
+  RDRF_LAUNCH("dw", k_dw, dim3(gx, gy), dim3(256), stream, D);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+void fill_static_w(StaticW& w, const RdrfStaticParams* P);
+void fill_dyn_w(DynW& w, const RdrfDynamicParams* P);
+
+static void dyn_pack_jobs_bwd(PackJobs& J, const RdrfDynamicParams* P) {
+  using namespace pkb;
+  J.n = 0;
+  const int k1 = REG_K1, k3 = REG_K3, sf = REG_SF;
+  pack_add(J, P->l5w, 64, 3, 64, SEG_IDENT, 1, 3, 32, k1 + K1_W5);
+  pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_DEN2);
+  pack_add(J, P->bw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_BLE2);
+  pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, 2, 2, 32, k1 + K1_W4T);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_X0, 2, 2, 32, k1 + K1_W3T_X0);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, 2, 1, 32, k1 + K1_W3T_T);
+  pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, k1 + K1_DEN1T_F);
+  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, k1 + K1_DEN1T_X0);
+  pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, k1 + K1_BLE1T_F);
+  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, k1 + K1_BLE1T_X0);
+  pack_add(J, P->rwv, 131, 3, 128, SEG_IDENT, 1, 3, 64, k3 + K3_RGBV);
+  pack_add(J, P->rw2, 128, 128, 128, SEG_IDENT, 2, 4, 64, k3 + K3_RGB2T);
+  pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 2, 1, 64, k3 + K3_RGB1T_F);
+  pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_X0, 2, 2, 64, k3 + K3_RGB1T_X0);
+  pack_add(J, P->basis, 216, 27, 216, SEG_IDENT, 2, 7, 16, k3 + K3_BASIST);
+  pack_add(J, P->sfw[3], 64, 6, 64, SEG_IDENT, 1, 6, 32, sf + SF_W6);
+  pack_add(J, P->sfw[2], 64, 64, 64, SEG_IDENT, 2, 2, 32, sf + SF_W4T);
+  pack_add(J, P->sfw[1], 64, 64, 64, SEG_IDENT, 2, 2, 32, sf + SF_W2T);
+  pack_add(J, P->sfw[0], 36, 64, 36, SEG_SF_X, 2, 2, 32, sf + SF_W0T);
+}
+
+static void static_pack_jobs_bwd(PackJobs& J, const RdrfStaticParams* P, int head) {
+  using namespace pkb;
+  J.n = 0;
+  const bool fea = head == RDRF_HEAD_MLP_FEA;
+  const int in1 = fea ? 138 : 135;
+  pack_add(J, P->w3, fea ? 128 : 131, 3, 128, SEG_IDENT, 1, 3, 64, REG_S3 + S3_W3);
+  pack_add(J, P->w2, 128, 128, 128, SEG_IDENT, 2, 4, 64, REG_S3 + S3_W2T);
+  pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 2, 1, 64, REG_S3 + S3_W1T_F);
+  pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 2, 4, 64, REG_S3 + S3_W1T_P);
+  pack_add(J, P->basis, 72, 27, 72, SEG_IDENT, 2, 3, 16, REG_S3 + S3_BASIST);
+}
+
+struct Geo {
+  int grid, block;
+};
+static Geo geo_for_units(long units) {
+  Geo g;
+  const int ncu = 256;
+  int waves = (int)((units + ncu - 1) / ncu);
+  waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
+  g.block = waves * 64;
+  long blocks = (units + waves - 1) / waves;
+  g.grid = (int)(blocks < 1 ? 1 : (blocks > ncu ? ncu : blocks));
+  return g;
+}
+
+#define PACK_AREA_FLOATS (1 << 20)
+
+static void fill_bwd_common(BwdArgs& a, const RdrfFieldCfg* cfg, const float* rays, const float* ts,
+                            const float* xyz, const float* z, const uint8_t* valid, int N, int S) {
+  memset(&a, 0, sizeof(a));
+  a.rays = rays; a.ts = ts; a.xyz = xyz; a.z = z; a.valid = valid; a.N = N; a.S = S;
+  a.box = make_box(cfg);
+  a.distance_scale = cfg->distance_scale; a.weight_thres = cfg->weight_thres;
+  a.density_shift = cfg->density_shift; a.act = cfg->act; a.ray_type = cfg->ray_type;
+  a.static_head = cfg->static_head;
+}
+
+extern "C" size_t rdrf_workspace_bytes(int N, int S) {
+  size_t ns = (size_t)N * S, t1 = (size_t)N * ((S + 31) / 32), t3 = (ns + 31) / 32;
+  // forward: pack area + counter + tout + xw + list
+  size_t fwd = (size_t)PACK_AREA_FLOATS * 4 + 256 + (size_t)N * 32 * 4 + ns * 3 * 4 + ns * 4 + (1 << 12);
+  // backward: pack area + dz rows of both phases + coordinate-gradient buffers + d(tout)
+  size_t bwd = (size_t)PACK_AREA_FLOATS * 4 + t1 * sv::K1G_ROWS * 32 * 4 + t3 * sv::K3G_ROWS * 32 * 4 +
+               ns * 3 * 4 * 2 + (size_t)N * 32 * 4 + (1 << 14);
+  size_t sf = (size_t)PACK_AREA_FLOATS * 4 + t3 * sv::SFG_ROWS * 32 * 4 + (1 << 12);
+  size_t m = fwd > bwd ? fwd : bwd;
+  return m > sf ? m : sf;
+}
+
+struct BwdWs {
+  float* pk;
+  float* grows1;
+  float* grows3;
+  float* dxw;
+  float* dxn;
+  float* dtout;
+};
+static int carve_bwd(BwdWs& b, void* ws, size_t ws_bytes, int N, int S, int dynamic) {
+  WsCarver c(ws, ws_bytes);
+  size_t ns = (size_t)N * S, t1 = (size_t)N * ((S + 31) / 32), t3 = (ns + 31) / 32;
+  b.pk = c.take<float>(PACK_AREA_FLOATS);
+  b.grows3 = c.take<float>(t3 * sv::K3G_ROWS * 32);
+  b.grows1 = dynamic ? c.take<float>(t1 * sv::K1G_ROWS * 32) : nullptr;
+  b.dxw = dynamic ? c.take<float>(ns * 3) : nullptr;
+  b.dxn = dynamic ? c.take<float>(ns * 3) : nullptr;
+  b.dtout = dynamic ? c.take<float>((size_t)N * 32) : nullptr;
+  RDRF_CHECK(c.ok(), -3, "backward workspace too small: need %zu have %zu", c.off, ws_bytes);
+  return 0;
+}
+
+extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
+                               const float* ts, const float* xyz, const float* z,
+                               const uint8_t* valid, int N, int S, const float* g_rgb,
+                               const float* g_sigma, const float* g_weight, const float* g_dists,
+                               const RdrfStaticParams* G, float* g_xyz, float* g_z, float* g_rays,
+                               void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                               rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "static_bwd: bad arguments");
+  // dists depends on z and rays only: g_dists matters only when g_z / g_rays are requested
+  RDRF_CHECK(g_z == nullptr && g_rays == nullptr, -38,
+             "static_bwd: gradients through dists / view directions (g_z, g_rays) are not built yet");
+  (void)g_dists;
+  BwdArgs a;
+  fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
+  a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_xyz = g_xyz;
+  RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 0, N, S), -3, "static_bwd: saved buffer too small");
+  BwdWs b;
+  int rc = carve_bwd(b, ws, ws_bytes, N, S, 0);
+  if (rc) return rc;
+  a.pk = b.pk; a.grows3 = b.grows3;
+  StaticW w;
+  fill_static_w(w, P);
+  StaticG gw;
+  gw.density = G->density; gw.app = G->app; gw.b3 = G->b3; gw.w3 = G->w3;
+  PackJobs J;
+  static_pack_jobs_bwd(J, P, cfg->static_head);
+  rc = pack_launch(J, b.pk, stream);
+  if (rc) return rc;
+  const size_t t3 = ((size_t)N * S + 31) / 32;
+  if (g_rgb != nullptr) {
+    const Geo g = geo_for_units((long)t3);
+    if (cfg->static_head == RDRF_HEAD_MLP_FEA)
+      RDRF_LAUNCH("static_app_bwd", k_static_app_bwd<RDRF_HEAD_MLP_FEA>, dim3(g.grid), dim3(g.block),
+                  stream, a, w, gw);
+    else
+      RDRF_LAUNCH("static_app_bwd", k_static_app_bwd<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING>, dim3(g.grid),
+                  dim3(g.block), stream, a, w, gw);
+    const bool fea = cfg->static_head == RDRF_HEAD_MLP_FEA;
+    const int in1 = fea ? 138 : 135;
+    const int* cnt = &a.sp.hdr->count;
+    DwJobs D;
+    D.n = 0;
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZV, 1, 3, 0, a.sp.act3, sv::S3_ROWS, 128,
+           fea ? 128 : 131, G->w3, nullptr, cnt, 0);
+    for (int i = 0; i < 4; ++i) dw_blk(D, sv::S3_H2 + 32 * i, SEG_IDENT, 32 * i);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZ2, 4, 128, 0, a.sp.act3, sv::S3_ROWS, 128, 128, G->w2,
+           G->b2, cnt, 0);
+    for (int i = 0; i < 4; ++i) dw_blk(D, sv::S3_H1 + 32 * i, SEG_IDENT, 32 * i);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZ1, 4, 128, 0, a.sp.act3, sv::S3_ROWS, in1, in1, G->w1,
+           G->b1, cnt, 0);
+    dw_blk(D, sv::S3_F, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 0);
+    for (int i = 0; i < 4; ++i) dw_blk(D, sv::S3_P + 32 * i, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 32 * i);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DF, 1, 27, 0, a.sp.act3, sv::S3_ROWS, 72, 72, G->basis,
+           nullptr, cnt, 0);
+    for (int i = 0; i < 3; ++i) dw_blk(D, sv::S3_G + 32 * i, SEG_IDENT, 32 * i);
+    rc = dw_launch(D, stream);
+    if (rc) return rc;
+  }
+  if (g_sigma != nullptr || g_weight != nullptr)
+    RDRF_LAUNCH("static_density_bwd", k_static_density_bwd, dim3(N), dim3(64), stream, a, w, gw);
+  return 0;
+}
+
+extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg,
+                                const float* rays, const float* ts, const float* xyz,
+                                const float* z, const uint8_t* valid, int N, int S,
+                                const float* g_blending, const float* g_weight,
+                                const float* g_xyz_prime, const float* g_rgb, const float* g_sigma,
+                                const float* g_dists, const RdrfDynamicParams* G, float* g_xyz,
+                                float* g_z, float* g_rays, void* saved, size_t saved_bytes, void* ws,
+                                size_t ws_bytes, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "dynamic_bwd: bad arguments");
+  RDRF_CHECK(g_z == nullptr && g_rays == nullptr, -38,
+             "dynamic_bwd: gradients through dists (g_z, g_rays) are not built yet");
+  (void)g_dists;
+  BwdArgs a;
+  fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
+  a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_blending = g_blending;
+  a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz;
+  RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 1, N, S), -3, "dynamic_bwd: saved buffer too small");
+  BwdWs b;
+  int rc = carve_bwd(b, ws, ws_bytes, N, S, 1);
+  if (rc) return rc;
+  a.pk = b.pk; a.grows1 = b.grows1; a.grows3 = b.grows3; a.dxw_app = b.dxw; a.dxn_app = b.dxn;
+  a.dtout = b.dtout;
+  DynW w;
+  fill_dyn_w(w, P);
+  DynG gw;
+  gw.density = G->density; gw.blending = G->blending; gw.app = G->app;
+  gw.rbv = G->rbv; gw.rwv = G->rwv; gw.l5b = G->l5b; gw.db2 = G->db2; gw.bb2 = G->bb2;
+  PackJobs J;
+  dyn_pack_jobs_bwd(J, P);
+  rc = pack_launch(J, b.pk, stream);
+  if (rc) return rc;
+  const size_t ns = (size_t)N * S, t3 = (ns + 31) / 32, t1 = (size_t)N * ((S + 31) / 32);
+  RDRF_HIP(hipMemsetAsync(b.dxw, 0, ns * 3 * 4, stream));
+  RDRF_HIP(hipMemsetAsync(b.dxn, 0, ns * 3 * 4, stream));
+  const int* cnt = &a.sp.hdr->count;
+  DwJobs D;
+  D.n = 0;
+  if (g_rgb != nullptr) {
+    const Geo g = geo_for_units((long)t3);
+    RDRF_LAUNCH("dyn_app_bwd", k_dyn_app_bwd, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZV, 1, 3, 0, a.sp.act3, sv::K3_ROWS, 128, 131, G->rwv,
+           nullptr, cnt, 0);
+    for (int i = 0; i < 4; ++i) dw_blk(D, sv::K3_H2 + 32 * i, SEG_IDENT, 32 * i);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZ2, 4, 128, 0, a.sp.act3, sv::K3_ROWS, 128, 128, G->rw2,
+           G->rb2, cnt, 0);
+    for (int i = 0; i < 4; ++i) dw_blk(D, sv::K3_H1 + 32 * i, SEG_IDENT, 32 * i);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZ1, 4, 128, 0, a.sp.act3, sv::K3_ROWS, 107, 107, G->rw1,
+           G->rb1, cnt, 0);
+    dw_blk(D, sv::K3_F, SEG_RGB1_F, 0);
+    dw_blk(D, sv::K3_X0, SEG_RGB1_X0, 0);
+    dw_blk(D, sv::K3_X0 + 32, SEG_RGB1_X0, 32);
+    dw_blk(D, sv::K3_X1, SEG_RGB1_X1, 0);
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DF, 1, 27, 0, a.sp.act3, sv::K3_ROWS, 216, 216, G->basis,
+           nullptr, cnt, 0);
+    for (int i = 0; i < 7; ++i) dw_blk(D, sv::K3_A + 32 * i, SEG_IDENT, 32 * i);
+  }
+  {
+    const Geo g = geo_for_units(N);
+    RDRF_LAUNCH("dyn_density_bwd", k_dyn_density_bwd, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((N + 127) / 128), dim3(128), stream, ts, w,
+                N, b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
+    const int T1 = (int)t1;
+    // layer3: [X0 | tout]
+    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_DZ3, 2, 64, 0, a.sp.act1, sv::K1_ROWS, 93, 93, G->l3w,
+           G->l3b, nullptr, T1);
+    dw_blk(D, sv::K1_X0, SEG_WARP3_X0, 0);
+    dw_blk(D, sv::K1_X0 + 32, SEG_WARP3_X0, 32);
+    dw_blk(D, sv::K1_T, SEG_WARP3_T, 0);
+    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_DZ4, 2, 64, 0, a.sp.act1, sv::K1_ROWS, 64, 64, G->l4w,
+           G->l4b, nullptr, T1);
+    dw_blk(D, sv::K1_H3, SEG_IDENT, 0);
+    dw_blk(D, sv::K1_H3 + 32, SEG_IDENT, 32);
+    // small layers share one dz block: rows 0..2 -> layer5, row 3 -> density_layer2, row 4 -> blending_layer2
+    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 3, 0, a.sp.act1, sv::K1_ROWS, 64, 64, G->l5w,
+           nullptr, nullptr, T1);
+    dw_blk(D, sv::K1_H4, SEG_IDENT, 0);
+    dw_blk(D, sv::K1_H4 + 32, SEG_IDENT, 32);
+    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 3, a.sp.act1, sv::K1_ROWS, 64, 64, G->dw2,
+           nullptr, nullptr, T1);
+    dw_blk(D, sv::K1_HD, SEG_IDENT, 0);
+    dw_blk(D, sv::K1_HD + 32, SEG_IDENT, 32);
+    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, a.sp.act1, sv::K1_ROWS, 64, 64, G->bw2,
+           nullptr, nullptr, T1);
+    dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
+    dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
+    for (int head = 0; head < 2; ++head) {
+      dw_add(D, b.grows1, sv::K1G_ROWS, head ? sv::K1G_DZB : sv::K1G_DZD, 2, 64, 0, a.sp.act1,
+             sv::K1_ROWS, 152, 152, head ? G->bw1 : G->dw1, head ? G->bb1 : G->db1, nullptr, T1);
+      const int f0 = head ? sv::K1_FB : sv::K1_FD;
+      dw_blk(D, f0, SEG_IDENT72, 0);
+      dw_blk(D, f0 + 32, SEG_IDENT72, 32);
+      dw_blk(D, f0 + 64, SEG_IDENT72, 64);
+      dw_blk(D, sv::K1_X0, SEG_DEN1_X0, 0);
+      dw_blk(D, sv::K1_X0 + 32, SEG_DEN1_X0, 32);
+      dw_blk(D, sv::K1_X1, SEG_DEN1_X1, 0);
+    }
+  }
+  rc = dw_launch(D, stream);
+  return rc;
+}
+
+extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg,
+                                   const float* pts, const float* ts, int N, int S,
+                                   const float* g_sf_f, const float* g_sf_b,
+                                   const RdrfDynamicParams* G, float* g_pts, void* saved,
+                                   size_t saved_bytes, void* ws, size_t ws_bytes,
+                                   rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "scene_flow_bwd: bad arguments");
+  const size_t tiles = ((size_t)N * S + 31) / 32;
+  RDRF_CHECK(saved_bytes >= tiles * sv::SF_ROWS * 32 * 4, -3, "scene_flow_bwd: saved buffer too small");
+  WsCarver c(ws, ws_bytes);
+  float* pkbuf = c.take<float>(PACK_AREA_FLOATS);
+  float* grows = c.take<float>(tiles * sv::SFG_ROWS * 32);
+  RDRF_CHECK(c.ok(), -3, "scene_flow_bwd: workspace too small: need %zu have %zu", c.off, ws_bytes);
+  PackJobs J;
+  dyn_pack_jobs_bwd(J, P);
+  int rc = pack_launch(J, pkbuf, stream);
+  if (rc) return rc;
+  const Geo g = geo_for_units((long)tiles);
+  RDRF_LAUNCH("scene_flow_bwd", k_scene_flow_bwd, dim3(g.grid), dim3(g.block), stream, N, S,
+              make_box(cfg), pkbuf, (const float*)saved, grows, g_sf_f, g_sf_b, G->sfb[3], g_pts);
+  const float* act = (const float*)saved;
+  const int T = (int)tiles;
+  DwJobs D;
+  D.n = 0;
+  dw_add(D, grows, sv::SFG_ROWS, sv::SFG_DZ6, 1, 6, 0, act, sv::SF_ROWS, 64, 64, G->sfw[3], nullptr,
+         nullptr, T);
+  dw_blk(D, sv::SF_H4, SEG_IDENT, 0);
+  dw_blk(D, sv::SF_H4 + 32, SEG_IDENT, 32);
+  dw_add(D, grows, sv::SFG_ROWS, sv::SFG_DZ4, 2, 64, 0, act, sv::SF_ROWS, 64, 64, G->sfw[2], G->sfb[2],
+         nullptr, T);
+  dw_blk(D, sv::SF_H2, SEG_IDENT, 0);
+  dw_blk(D, sv::SF_H2 + 32, SEG_IDENT, 32);
+  dw_add(D, grows, sv::SFG_ROWS, sv::SFG_DZ2, 2, 64, 0, act, sv::SF_ROWS, 64, 64, G->sfw[1], G->sfb[1],
+         nullptr, T);
+  dw_blk(D, sv::SF_H0, SEG_IDENT, 0);
+  dw_blk(D, sv::SF_H0 + 32, SEG_IDENT, 32);
+  dw_add(D, grows, sv::SFG_ROWS, sv::SFG_DZ0, 2, 64, 0, act, sv::SF_ROWS, 36, 36, G->sfw[0], G->sfb[0],
+         nullptr, T);
+  dw_blk(D, sv::SF_X, SEG_SF_X, 0);
+  dw_blk(D, sv::SF_X + 32, SEG_SF_X, 32);
+  return dw_launch(D, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// not built yet (round 2): ray-generation / sampler backward, fused render
+// ------------------------------------------------------------------------------------------------
 #define NOT_YET(name) do { rdrf_set_error(name ": not implemented yet"); return -38; } while (0)
-
 extern "C" int rdrf_generate_rays_bwd(const int64_t*, const float*, const float*, int, int, int, int, int, float, const float*, float*, float*, rdrf_stream_t) { NOT_YET("generate_rays_bwd"); }
-extern "C" int rdrf_sample_bwd(const float*, const float*, int, int, int, const float*, float*, rdrf_stream_t) { NOT_YET("sample_bwd"); }
-extern "C" int rdrf_static_bwd(const RdrfStaticParams*, const RdrfFieldCfg*, const float*, const float*, const float*, const float*, const uint8_t*, int, int, const float*, const float*, const float*, const float*, const RdrfStaticParams*, float*, float*, float*, void*, size_t, rdrf_stream_t) { NOT_YET("static_bwd"); }
-extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams*, const RdrfFieldCfg*, const float*, const float*, const float*, const float*, const uint8_t*, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const RdrfDynamicParams*, float*, float*, float*, void*, size_t, rdrf_stream_t) { NOT_YET("dynamic_bwd"); }
-extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams*, const RdrfFieldCfg*, const float*, const float*, int, int, const float*, const float*, const RdrfDynamicParams*, float*, void*, size_t, rdrf_stream_t) { NOT_YET("scene_flow_bwd"); }
-extern "C" int rdrf_composite_bwd(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, const float* const*, float* const*, rdrf_stream_t) { NOT_YET("composite_bwd"); }
 extern "C" size_t rdrf_render_workspace_bytes(int N, int S) { return 0; }
 extern "C" int rdrf_render_fwd(const RdrfStaticParams*, const RdrfFieldCfg*, const RdrfDynamicParams*, const RdrfFieldCfg*, const float*, const float*, int, int, float, float, float*, float*, void*, size_t, rdrf_stream_t) { NOT_YET("render_fwd"); }
 extern "C" int rdrf_selftest_mlp(const float*, const float*, const float*, int, int, int, float*, void*, size_t, rdrf_stream_t) { NOT_YET("selftest_mlp"); }

@@ -9,58 +9,7 @@
 //                  blending MLPs -> scan -> weight/compaction), k_dyn_app (MFMA tiles over the
 //                  compacted list: 216-feature gather -> basis -> 107->128->128->(131)->3)
 //   scene flow   : k_scene_flow (36->64->64->64->6, models/tensoRF.py:446-462)
-#include "rdrf_host.hpp"
-
-// ------------------------------------------------------------------------------------------------
-struct FieldArgs {
-  // inputs
-  const float* rays;
-  const float* ts;
-  const float* xyz;
-  const float* z;
-  const uint8_t* valid;
-  int N, S;
-  Box box;
-  float distance_scale, weight_thres, density_shift;
-  int act, ray_type, static_head;
-  // outputs
-  float *rgb, *sigma, *weight, *dists, *blending, *xyz_prime;
-  // workspace
-  const float* pk;   // packed weights
-  float* tout;       // [N][32]
-  float* xw;         // [N][S][3] warped normalised coordinate
-  int* list;         // compacted sample ids
-  int* counter;
-};
-
-struct StaticW {
-  RdrfVM density, app;
-  const float *b1, *b2, *b3, *w3;
-};
-struct DynW {
-  RdrfVM density, blending, app;
-  const float *l1w, *l1b, *l2w, *l2b;
-  const float *l3b, *l4b, *l5b, *db1, *db2, *bb1, *bb2, *rb1, *rb2, *rbv, *rwv;
-  const float *sfb0, *sfb2, *sfb4, *sfb6;
-};
-
-RDRF_D float density_act(float f, int act, float shift) {
-  return act == RDRF_ACT_RELU ? fmaxf(f, 0.0f) : softplusf_(f + shift);
-}
-
-RDRF_D float ray_norm(const float* rays, int n, int ray_type, float& vx, float& vy, float& vz) {
-  vx = rays[n * 6 + 3];
-  vy = rays[n * 6 + 4];
-  vz = rays[n * 6 + 5];
-  float nrm = 1.0f;
-  if (ray_type != RDRF_RAY_OTHER) {
-    nrm = sqrtf(vx * vx + vy * vy + vz * vz);
-    vx /= nrm;
-    vy /= nrm;
-    vz /= nrm;
-  }
-  return nrm;
-}
+#include "rdrf_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // static field, density phase: one wave per ray, one lane per sample (64 per step)
@@ -94,6 +43,7 @@ __global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
       }
     }
     const float sigma = vld ? density_act(f, a.act, a.density_shift) : 0.0f;
+    if (a.raw != nullptr && act) a.raw[idx] = f;
     const float zj = act ? a.z[idx] : 0.f;
     const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
     const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
@@ -138,6 +88,7 @@ __global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
     const bool act = li < count;
     const int idx = act ? a.list[li] : 0;
     const int n = idx / a.S;
+    float* svb = a.act3 ? a.act3 + (size_t)tile * sv::S3_ROWS * 32 : nullptr;
     float vx, vy, vz;
     ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
     const float x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
@@ -167,15 +118,20 @@ __global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
       if (h == 0) F[15] = vx;
       else { F[12] = vy; F[13] = vz; }
     }
+    save_rows<36>(svb, sv::S3_G, G, s, h);
+    save_rows<16>(svb, sv::S3_F, F, s, h);
+    save_rows<64>(svb, sv::S3_P, P, s, h);
     f32x16 acc[4];
     acc_bias<4>(acc, pkw + pk::S3_B1, h);
     mfma_seg<4, 16>(acc, F, pkw + pk::S3_W1_F, lane);
     mfma_seg<4, 64>(acc, P, pkw + pk::S3_W1_P, lane);
     float H1[64];
     acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::S3_H1, H1, s, h);
     acc_bias<4>(acc, pkw + pk::S3_B2, h);
     mfma_seg<4, 64>(acc, H1, pkw + pk::S3_W2, lane);
     acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::S3_H2, H1, s, h);
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
       float v = dot_small<64>(H1, pkw + pk::S3_W3 + o * 128, h) + w.b3[o];
@@ -247,6 +203,10 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
     const float xn2 = norm_c(pz, a.box.lo[2], a.box.inv[2]);
     float X0[32];
     fill_x0(X0, xn0, xn1, xn2, t, h);
+    float* svb = a.act1 ? a.act1 + ((size_t)n * ((a.S + 31) >> 5) + (j0 >> 5)) * sv::K1_ROWS * 32 : nullptr;
+    save_rows<32>(svb, sv::K1_X0, X0, s, h);
+    save_rows<8>(svb, sv::K1_X1, X1, s, h);
+    save_rows<16>(svb, sv::K1_T, T, s, h);
     // ---- warp MLP: [xn, PE10(xn), tout] -> 64 -> 64 -> 3  (models/tensoRF.py:521-541)
     float d0, d1, d2;
     {
@@ -256,9 +216,11 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
       mfma_seg<2, 16>(acc, T, pkw + pk::K1_W3_T, lane);
       float H3[32];
       acc_relu<2>(H3, acc);
+      save_rows<32>(svb, sv::K1_H3, H3, s, h);
       acc_bias<2>(acc, pkw + pk::K1_B4, h);
       mfma_seg<2, 32>(acc, H3, pkw + pk::K1_W4, lane);
       acc_relu<2>(H3, acc);
+      save_rows<32>(svb, sv::K1_H4, H3, s, h);
       d0 = dot_small<32>(H3, pkw + pk::K1_W5 + 0 * 64, h) + w.l5b[0];
       d1 = dot_small<32>(H3, pkw + pk::K1_W5 + 1 * 64, h) + w.l5b[1];
       d2 = dot_small<32>(H3, pkw + pk::K1_W5 + 2 * 64, h) + w.l5b[2];
@@ -292,6 +254,8 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
       mfma_seg<2, 8>(acc, X1, pkw + pk::K1_DEN1_X1, lane);
       float Hd[32];
       acc_relu<2>(Hd, acc);
+      save_rows<36>(svb, sv::K1_FD, Fv, s, h);
+      save_rows<32>(svb, sv::K1_HD, Hd, s, h);
       fd = dot_small<32>(Hd, pkw + pk::K1_DEN2, h) + w.db2[0];
     }
     {
@@ -309,6 +273,8 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
       mfma_seg<2, 8>(acc, X1, pkw + pk::K1_BLE1_X1, lane);
       float Hd[32];
       acc_relu<2>(Hd, acc);
+      save_rows<36>(svb, sv::K1_FB, Fv, s, h);
+      save_rows<32>(svb, sv::K1_HB, Hd, s, h);
       fb = dot_small<32>(Hd, pkw + pk::K1_BLE2, h) + w.bb2[0];
     }
     const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.0f;
@@ -330,6 +296,7 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
       a.weight[idx] = wt;
       a.dists[idx] = ds;
       a.blending[idx] = blend;
+      if (a.raw != nullptr) { a.raw[(size_t)idx * 2] = fd; a.raw[(size_t)idx * 2 + 1] = fb; }
     }
     const unsigned long long bal = __ballot(m);
     if (bal) {
@@ -359,6 +326,7 @@ __global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
     const int idx = act ? a.list[li] : 0;
     const int n = idx / a.S;
     const float t = a.ts[n];
+    float* svb = a.act3 ? a.act3 + (size_t)tile * sv::K3_ROWS * 32 : nullptr;
     float vx, vy, vz;
     ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
     const float xn0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
@@ -379,10 +347,14 @@ __global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
       acc_bias<1>(accF, nullptr, h);
       mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
       acc_copy<1>(F, accF);
+      save_rows<108>(svb, sv::K3_A, A, s, h);
     }
     float X0[32], X1[8];
     fill_x0(X0, xn0, xn1, xn2, t, h);
     fill_x1(X1, t, h);
+    save_rows<16>(svb, sv::K3_F, F, s, h);
+    save_rows<32>(svb, sv::K3_X0, X0, s, h);
+    save_rows<8>(svb, sv::K3_X1, X1, s, h);
     f32x16 acc[4];
     acc_bias<4>(acc, pkw + pk::K3_B1, h);
     mfma_seg<4, 16>(acc, F, pkw + pk::K3_RGB1_F, lane);
@@ -390,9 +362,11 @@ __global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
     mfma_seg<4, 8>(acc, X1, pkw + pk::K3_RGB1_X1, lane);
     float H1[64];
     acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::K3_H1, H1, s, h);
     acc_bias<4>(acc, pkw + pk::K3_B2, h);
     mfma_seg<4, 64>(acc, H1, pkw + pk::K3_RGB2, lane);
     acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::K3_H2, H1, s, h);
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
       float v = dot_small<64>(H1, pkw + pk::K3_RGBV + o * 128, h) + w.rbv[o];
@@ -432,7 +406,8 @@ __global__ __launch_bounds__(512) void k_scene_flow(const float* __restrict__ pt
                                                    const float* __restrict__ ts, int N, int S,
                                                    Box box, const float* __restrict__ pkg, DynW w,
                                                    float* __restrict__ sf_f,
-                                                   float* __restrict__ sf_b) {
+                                                   float* __restrict__ sf_b,
+                                                   float* __restrict__ act_rows) {
   __shared__ __attribute__((aligned(16))) float lds[pk::SF_SIZE];
   lds_fill(lds, pkg + pk::REG_SF, pk::SF_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
@@ -450,17 +425,22 @@ __global__ __launch_bounds__(512) void k_scene_flow(const float* __restrict__ pt
     const float xn2 = norm_c(pts[(size_t)idx * 3 + 2], box.lo[2], box.inv[2]);
     float X[20];
     fill_sf_x(X, xn0, xn1, xn2, t, h);
+    float* svb = act_rows ? act_rows + (size_t)tile * sv::SF_ROWS * 32 : nullptr;
+    save_rows<20>(svb, sv::SF_X, X, s, h);
     f32x16 acc[2];
     acc_bias<2>(acc, pkw + pk::SF_B0, h);
     mfma_seg<2, 20>(acc, X, pkw + pk::SF_W0, lane);
     float H[32];
     acc_relu<2>(H, acc);
+    save_rows<32>(svb, sv::SF_H0, H, s, h);
     acc_bias<2>(acc, pkw + pk::SF_B2, h);
     mfma_seg<2, 32>(acc, H, pkw + pk::SF_W2, lane);
     acc_relu<2>(H, acc);
+    save_rows<32>(svb, sv::SF_H2, H, s, h);
     acc_bias<2>(acc, pkw + pk::SF_B4, h);
     mfma_seg<2, 32>(acc, H, pkw + pk::SF_W4, lane);
     acc_relu<2>(H, acc);
+    save_rows<32>(svb, sv::SF_H4, H, s, h);
 #pragma unroll
     for (int o = 0; o < 6; ++o) {
       const float v = dot_small<32>(H, pkw + pk::SF_W6 + o * 64, h) + w.sfb6[o];
@@ -555,13 +535,9 @@ void fill_dyn_w(DynW& w, const RdrfDynamicParams* P) {
 
 #define PACK_AREA_FLOATS (1 << 20) /* 4 MiB: forward + transposed packs of either field */
 
-extern "C" size_t rdrf_workspace_bytes(int N, int S) {
-  size_t ns = (size_t)N * (size_t)S;
-  // pack area + counter + tout + xw + list (+ slack for alignment)
-  return (size_t)PACK_AREA_FLOATS * 4 + 256 + (size_t)N * 32 * 4 + ns * 3 * 4 + ns * 4 + (1 << 12);
-}
 
-int ws_carve_fwd(FieldArgs& a, void* ws, size_t ws_bytes, int N, int S) {
+int ws_carve_fwd(FieldArgs& a, void* ws, size_t ws_bytes, int N, int S, void* saved,
+                 size_t saved_bytes, int dynamic) {
   WsCarver c(ws, ws_bytes);
   size_t ns = (size_t)N * S;
   a.pk = c.take<float>(PACK_AREA_FLOATS);
@@ -570,7 +546,25 @@ int ws_carve_fwd(FieldArgs& a, void* ws, size_t ws_bytes, int N, int S) {
   a.xw = c.take<float>(ns * 3);
   a.list = c.take<int>(ns);
   RDRF_CHECK(c.ok(), -3, "workspace too small: need %zu have %zu", c.off, ws_bytes);
+  if (saved != nullptr) {  // training mode: the backward re-uses these instead of recomputing
+    SavedPtrs sp;
+    RDRF_CHECK(carve_saved(sp, saved, saved_bytes, dynamic, N, S), -3,
+               "saved buffer too small: need %zu have %zu", saved_bytes_field(dynamic, N, S),
+               saved_bytes);
+    a.counter = &sp.hdr->count;
+    a.list = sp.list;
+    a.xw = sp.xw;
+    a.tout = sp.tout;
+    a.raw = sp.raw;
+    a.act1 = sp.act1;
+    a.act3 = sp.act3;
+  }
   return 0;
+}
+
+extern "C" size_t rdrf_saved_bytes(int kind, int N, int S) {
+  if (kind == 2) return ((size_t)N * S + 31) / 32 * sv::SF_ROWS * 32 * 4 + 256;
+  return saved_bytes_field(kind == 1, N, S);
 }
 
 // persistent launch geometry: one workgroup per CU (its LDS holds the kernel's weight image),
@@ -593,8 +587,8 @@ static Geo geo_for_tiles(int N, int S) { return geo_for_units(((long)N * S + 31)
 extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                                const float* ts, const float* xyz, const float* z,
                                const uint8_t* valid, int N, int S, float* rgb, float* sigma,
-                               float* weight, float* dists, void* ws, size_t ws_bytes,
-                               rdrf_stream_t stream_) {
+                               float* weight, float* dists, void* saved, size_t saved_bytes,
+                               void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "static_fwd: bad arguments");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
@@ -602,7 +596,7 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   FieldArgs a;
   fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
-  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S);
+  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S, saved, saved_bytes, 0);
   if (rc) return rc;
   StaticW w;
   fill_static_w(w, P);
@@ -627,8 +621,8 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 const float* rays, const float* ts, const float* xyz,
                                 const float* z, const uint8_t* valid, int N, int S,
                                 float* blending, float* weight, float* xyz_prime, float* rgb,
-                                float* sigma, float* dists, void* ws, size_t ws_bytes,
-                                rdrf_stream_t stream_) {
+                                float* sigma, float* dists, void* saved, size_t saved_bytes,
+                                void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "dynamic_fwd: bad arguments");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
@@ -637,7 +631,7 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
   a.blending = blending; a.xyz_prime = xyz_prime;
-  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S);
+  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S, saved, saved_bytes, 1);
   if (rc) return rc;
   DynW w;
   fill_dyn_w(w, P);
@@ -656,12 +650,15 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
 
 extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg,
                                    const float* pts, const float* ts, int N, int S, float* sf_f,
-                                   float* sf_b, void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
+                                   float* sf_b, void* saved, size_t saved_bytes, void* ws,
+                                   size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "scene_flow_fwd: bad arguments");
   FieldArgs a;
   memset(&a, 0, sizeof(a));
-  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S);
+  RDRF_CHECK(saved == nullptr || saved_bytes >= rdrf_saved_bytes(2, N, S), -3,
+             "scene_flow_fwd: saved buffer too small");
+  int rc = ws_carve_fwd(a, ws, ws_bytes, N, S, nullptr, 0, 1);
   if (rc) return rc;
   DynW w;
   fill_dyn_w(w, P);
@@ -671,6 +668,6 @@ extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCf
   if (rc) return rc;
   const Geo g = geo_for_tiles(N, S);
   RDRF_LAUNCH("scene_flow", k_scene_flow, dim3(g.grid), dim3(g.block), stream, pts, ts, N, S,
-              make_box(cfg), a.pk, w, sf_f, sf_b);
+              make_box(cfg), a.pk, w, sf_f, sf_b, (float*)saved);
   return 0;
 }

@@ -297,3 +297,237 @@ extern "C" int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, cons
   RDRF_LAUNCH("composite", k_composite, dim3(N), dim3(64), stream, a);
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// compositor backward (autograd of renderer.py:173-315).  One wave per ray, three sweeps:
+//   1. recompute the sums (pre-clamp maps, accumulations, normaliser U of weights_d)
+//   2. per-sample upstream gradients on each weight -> the three suffix-sum totals
+//   3. final per-sample gradients with running prefix sums (suffix = total - prefix)
+// Transmittance: T_k = prod_{j<k} p_j  =>  dL/dp_j = (sum_{m>j} T_m A_m) / p_j.
+// ------------------------------------------------------------------------------------------------
+struct CompBArgs {
+  const float *rgb_s, *sigma_s, *rgb_d, *sigma_d, *dists, *blending, *z, *rays;
+  int N, S, ray_type, add_white_bg;
+  const float* g[13];
+  float* gi[8];
+};
+
+struct CompSample {
+  float ad, as, b, di, zz, pd, ps, pf, Td, Ts, Tf, sd, ss;
+  float cd[3], cs[3];
+};
+
+RDRF_D float wave_incl_sum(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+RDRF_D CompSample comp_load(const CompBArgs& a, int n, int j, int lane, float& cd, float& cs, float& cf) {
+  CompSample q;
+  const bool act = j < a.S;
+  const size_t idx = (size_t)n * a.S + (act ? j : 0);
+  q.di = a.dists[idx]; q.b = a.blending[idx]; q.zz = a.z[idx];
+  q.sd = a.sigma_d[idx]; q.ss = a.sigma_s[idx];
+  q.ad = act ? alpha_of(q.sd, q.di) : 0.f;
+  q.as = act ? alpha_of(q.ss, q.di) : 0.f;
+  q.pd = act ? one_minus_alpha_eps(q.ad) : 1.f;
+  q.ps = act ? one_minus_alpha_eps(q.as) : 1.f;
+  q.pf = act ? tfull_factor(q.ad, q.as, q.b) : 1.f;
+  const float id = scan_mul64(q.pd, lane), is = scan_mul64(q.ps, lane), ifl = scan_mul64(q.pf, lane);
+  float ed = __shfl_up(id, 1, 64), es = __shfl_up(is, 1, 64), ef = __shfl_up(ifl, 1, 64);
+  if (lane == 0) { ed = 1.f; es = 1.f; ef = 1.f; }
+  q.Td = cd * ed; q.Ts = cs * es; q.Tf = cf * ef;
+  cd *= __shfl(id, 63, 64); cs *= __shfl(is, 63, 64); cf *= __shfl(ifl, 63, 64);
+  for (int c = 0; c < 3; ++c) { q.cd[c] = a.rgb_d[idx * 3 + c]; q.cs[c] = a.rgb_s[idx * 3 + c]; }
+  if (!act) { q.ad = 0.f; q.as = 0.f; }
+  return q;
+}
+
+__global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x;
+  if (n >= a.N) return;
+  const int S = a.S;
+  // ---- sweep 1
+  float U = 0.f, acc_s = 0.f, acc_f = 0.f;
+  float ru[3] = {0, 0, 0}, rs[3] = {0, 0, 0}, rf[3] = {0, 0, 0};
+  {
+    float cd = 1.f, cs = 1.f, cf = 1.f;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+      const int j = j0 + lane;
+      CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
+      if (j < S) {
+        const float u = q.ad * q.Td, ws = q.as * q.Ts;
+        const float fd = q.Tf * q.ad * q.b, fs = q.Tf * q.as * (1.0f - q.b);
+        U += u; acc_s += ws; acc_f += (q.ad * q.b + q.as * (1.0f - q.b)) * q.Tf;
+        for (int c = 0; c < 3; ++c) { ru[c] += u * q.cd[c]; rs[c] += ws * q.cs[c]; rf[c] += fd * q.cd[c] + fs * q.cs[c]; }
+      }
+    }
+    U = wave_sum(U); acc_s = wave_sum(acc_s); acc_f = wave_sum(acc_f);
+    for (int c = 0; c < 3; ++c) { ru[c] = wave_sum(ru[c]); rs[c] = wave_sum(rs[c]); rf[c] = wave_sum(rf[c]); }
+  }
+  const float Ue = U + 1e-10f;
+  const float acc_d = U / Ue;
+  const float white = a.add_white_bg ? 1.f : 0.f;
+  const bool rl_on = (1.0f - acc_f) > 0.f;
+  const float rl = rl_on ? 1.0f - acc_f : 0.f;
+  float far = 0.f;
+  if (a.ray_type == RDRF_RAY_NDC) far = a.rays[(size_t)n * 6 + 2] + a.rays[(size_t)n * 6 + 5];
+  else if (a.ray_type == RDRF_RAY_CONTRACT) far = 256.0f;
+  float grf[3], grs[3], grd[3], sgf = 0.f, sgs = 0.f, sgd = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float pf = rf[c] + white * rl, ps = rs[c] + white * (1.0f - acc_s),
+                pd = ru[c] / Ue + white * (1.0f - acc_d);
+    grf[c] = (a.g[0] && pf >= 0.f && pf <= 1.f) ? a.g[0][(size_t)n * 3 + c] : 0.f;
+    grs[c] = (a.g[4] && ps >= 0.f && ps <= 1.f) ? a.g[4][(size_t)n * 3 + c] : 0.f;
+    grd[c] = (a.g[8] && pd >= 0.f && pd <= 1.f) ? a.g[8][(size_t)n * 3 + c] : 0.f;
+    sgf += grf[c]; sgs += grs[c]; sgd += grd[c];
+  }
+  const float Gdep_f = a.g[1] ? a.g[1][n] : 0.f, Gacc_f = a.g[2] ? a.g[2][n] : 0.f;
+  const float Gdep_s = a.g[5] ? a.g[5][n] : 0.f, Gacc_s = a.g[6] ? a.g[6][n] : 0.f;
+  const float Gdep_d = a.g[9] ? a.g[9][n] : 0.f, Gacc_d = a.g[10] ? a.g[10][n] : 0.f;
+  const float Gdyn = a.g[12] ? a.g[12][n] : 0.f;
+  const float const_d = Gacc_d - white * sgd - Gdep_d * far;
+  const float const_s = Gacc_s - white * sgs - Gdep_s * far;
+  const float const_f = Gacc_f + (rl_on ? (-white * sgf - Gdep_f * far) : 0.f);
+  // ---- sweep 2: totals
+  float D1 = 0.f, tot_s = 0.f, tot_f = 0.f;
+  {
+    float cd = 1.f, cs = 1.f, cf = 1.f;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+      const int j = j0 + lane;
+      CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
+      if (j < S) {
+        const size_t idx = (size_t)n * S + j;
+        const float u = q.ad * q.Td, ws = q.as * q.Ts;
+        const float cfd = q.ad * q.b, cfs = q.as * (1.0f - q.b);
+        float dd = 0.f, dsv = 0.f, dfd = 0.f, dfs = 0.f;
+        for (int c = 0; c < 3; ++c) { dd += grd[c] * q.cd[c]; dsv += grs[c] * q.cs[c]; dfd += grf[c] * q.cd[c]; dfs += grf[c] * q.cs[c]; }
+        const float gwd = (a.g[11] ? a.g[11][idx] : 0.f) + dd + Gdep_d * q.zz + const_d;
+        const float gws = (a.g[7] ? a.g[7][idx] : 0.f) + dsv + Gdep_s * q.zz + const_s;
+        const float gwf = (a.g[3] ? a.g[3][idx] : 0.f) + Gdep_f * q.zz + Gdyn * q.b + const_f;
+        D1 += gwd * (u / Ue);
+        tot_s += gws * ws;
+        tot_f += q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs));
+      }
+    }
+    D1 = wave_sum(D1); tot_s = wave_sum(tot_s); tot_f = wave_sum(tot_f);
+  }
+  const float tot_d = D1 * 1e-10f / Ue;
+  // ---- sweep 3
+  {
+    float cd = 1.f, cs = 1.f, cf = 1.f, pre_d = 0.f, pre_s = 0.f, pre_f = 0.f;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+      const int j = j0 + lane;
+      CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
+      const bool act = j < S;
+      const size_t idx = (size_t)n * S + (act ? j : 0);
+      const float u = q.ad * q.Td, ws = q.as * q.Ts;
+      const float cfd = q.ad * q.b, cfs = q.as * (1.0f - q.b);
+      const float wf = (cfd + cfs) * q.Tf;
+      float dd = 0.f, dsv = 0.f, dfd = 0.f, dfs = 0.f;
+      for (int c = 0; c < 3; ++c) { dd += grd[c] * q.cd[c]; dsv += grs[c] * q.cs[c]; dfd += grf[c] * q.cd[c]; dfs += grf[c] * q.cs[c]; }
+      const float gwd = (a.g[11] ? a.g[11][idx] : 0.f) + dd + Gdep_d * q.zz + const_d;
+      const float gws = (a.g[7] ? a.g[7][idx] : 0.f) + dsv + Gdep_s * q.zz + const_s;
+      const float gwf = (a.g[3] ? a.g[3][idx] : 0.f) + Gdep_f * q.zz + Gdyn * q.b + const_f;
+      const float gu = (gwd - D1) / Ue;
+      const float td = act ? gu * u : 0.f, ts_ = act ? gws * ws : 0.f;
+      const float tf = act ? q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs)) : 0.f;
+      const float id = wave_incl_sum(td, lane), is = wave_incl_sum(ts_, lane), ifl = wave_incl_sum(tf, lane);
+      const float suf_d = tot_d - (pre_d + id), suf_s = tot_s - (pre_s + is), suf_f = tot_f - (pre_f + ifl);
+      pre_d += __shfl(id, 63, 64); pre_s += __shfl(is, 63, 64); pre_f += __shfl(ifl, 63, 64);
+      if (act) {
+        float g_ad = gu * q.Td - suf_d / q.pd;
+        float g_as = gws * q.Ts - suf_s / q.ps;
+        const float g_pf = suf_f / q.pf;
+        const float g_cfd = q.Tf * (dfd + gwf), g_cfs = q.Tf * (dfs + gwf);
+        const float uu = 1.0f - q.ad * q.b, vv = 1.0f - q.as * (1.0f - q.b);
+        g_ad += g_cfd * q.b - g_pf * q.b * vv;
+        g_as += g_cfs * (1.0f - q.b) - g_pf * uu * (1.0f - q.b);
+        const float g_b = Gdyn * wf + g_cfd * q.ad - g_cfs * q.as + g_pf * (-q.ad * vv + uu * q.as);
+        const float wdn = u / Ue;
+        if (a.gi[1]) a.gi[1][idx] += g_as * q.di * (1.0f - q.as);
+        if (a.gi[3]) a.gi[3][idx] += g_ad * q.di * (1.0f - q.ad);
+        if (a.gi[4]) a.gi[4][idx] += g_ad * q.sd * (1.0f - q.ad) + g_as * q.ss * (1.0f - q.as);
+        if (a.gi[5]) a.gi[5][idx] += g_b;
+        if (a.gi[6]) a.gi[6][idx] += Gdep_d * wdn + Gdep_s * ws + Gdep_f * wf;
+        for (int c = 0; c < 3; ++c) {
+          if (a.gi[0]) a.gi[0][idx * 3 + c] += grs[c] * ws + grf[c] * q.Tf * cfs;
+          if (a.gi[2]) a.gi[2][idx * 3 + c] += grd[c] * wdn + grf[c] * q.Tf * cfd;
+        }
+      }
+    }
+  }
+  if (lane == 0 && a.gi[7] && a.ray_type == RDRF_RAY_NDC) {
+    const float gfar = Gdep_d * (1.0f - acc_d) + Gdep_s * (1.0f - acc_s) + Gdep_f * rl;
+    a.gi[7][(size_t)n * 6 + 2] += gfar;
+    a.gi[7][(size_t)n * 6 + 5] += gfar;
+  }
+}
+
+extern "C" int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
+                                  const float* sigma_d, const float* dists, const float* blending,
+                                  const float* z, const float* rays, int N, int S, int ray_type,
+                                  int add_white_bg, const float* const g_out13[13],
+                                  float* const g_in8[8], rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 0 && g_out13 && g_in8, -1, "composite_bwd: bad arguments");
+  CompBArgs a;
+  a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
+  a.dists = dists; a.blending = blending; a.z = z; a.rays = rays;
+  a.N = N; a.S = S; a.ray_type = ray_type; a.add_white_bg = add_white_bg;
+  for (int i = 0; i < 13; ++i) a.g[i] = g_out13[i];
+  for (int i = 0; i < 8; ++i) a.gi[i] = g_in8[i];
+  RDRF_LAUNCH("composite_bwd", k_composite_bwd, dim3(N), dim3(64), stream, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler backward: xyz = o + d * z (then the L-inf contraction for ray_type contract)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sample_bwd(const float* __restrict__ rays,
+                                                   const float* __restrict__ zrow, int N, int S,
+                                                   int ray_type, const float* __restrict__ g_xyz,
+                                                   float* __restrict__ g_rays) {
+  const int lane = threadIdx.x, n = blockIdx.x;
+  if (n >= N) return;
+  const float* r = rays + (size_t)n * 6;
+  float go[3] = {0, 0, 0}, gd[3] = {0, 0, 0};
+  for (int j = lane; j < S; j += 64) {
+    const float t = zrow[(size_t)n * S + j];
+    float g[3] = {g_xyz[((size_t)n * S + j) * 3 + 0], g_xyz[((size_t)n * S + j) * 3 + 1],
+                  g_xyz[((size_t)n * S + j) * 3 + 2]};
+    if (ray_type == RDRF_RAY_CONTRACT) {
+      float p[3], nrm = 0.f;
+      int m = 0;
+      for (int k = 0; k < 3; ++k) {
+        p[k] = r[k] + r[3 + k] * t;
+        if (fabsf(p[k]) > nrm) { nrm = fabsf(p[k]); m = k; }
+      }
+      if (nrm > 1.0f) {  // pc_i = (2/n - 1/n^2) p_i, n = |p_m|
+        const float sc = 2.0f / nrm - 1.0f / (nrm * nrm);
+        const float dsc = (-2.0f / (nrm * nrm) + 2.0f / (nrm * nrm * nrm)) * (p[m] > 0.f ? 1.f : -1.f);
+        const float gp = g[0] * p[0] + g[1] * p[1] + g[2] * p[2];
+        for (int k = 0; k < 3; ++k) g[k] = g[k] * sc;
+        g[m] += gp * dsc;
+      }
+    }
+    for (int k = 0; k < 3; ++k) { go[k] += g[k]; gd[k] += g[k] * t; }
+  }
+  for (int k = 0; k < 3; ++k) { go[k] = wave_sum(go[k]); gd[k] = wave_sum(gd[k]); }
+  if (lane == 0)
+    for (int k = 0; k < 3; ++k) { g_rays[(size_t)n * 6 + k] += go[k]; g_rays[(size_t)n * 6 + 3 + k] += gd[k]; }
+}
+
+extern "C" int rdrf_sample_bwd(const float* rays, const float* z, int N, int S, int ray_type,
+                               const float* grad_xyz, float* grad_rays, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 0 && rays && z && grad_xyz && grad_rays, -1, "sample_bwd: bad arguments");
+  RDRF_LAUNCH("sample_bwd", k_sample_bwd, dim3(N), dim3(64), stream, rays, z, N, S, ray_type, grad_xyz,
+              grad_rays);
+  return 0;
+}

@@ -146,6 +146,15 @@ def _dynamic_struct(t):
     return P
 
 
+def _alloc_saved(ctx, kind, N, S, dev):
+    """training mode: a per-call buffer the forward fills with the activations its backward needs
+    (inference -- no input requires grad -- keeps nothing)."""
+    if not any(ctx.needs_input_grad):
+        return None, 0
+    nbytes = int(L.lib.rdrf_saved_bytes(kind, N, S))
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
 def _prep_inputs(rays, ts, xyz, z, valid):
     L.require_device(rays, ts, xyz, z, valid)
     rays, ts, xyz, z = L.f32c(rays), L.f32c(ts), L.f32c(xyz), L.f32c(z)
@@ -166,13 +175,15 @@ class _StaticFn(torch.autograd.Function):
         weight = torch.empty(N, S, device=dev)
         dists = torch.empty(N, S, device=dev)
         ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
+        saved, sbytes = _alloc_saved(ctx, 0, N, S, dev)
         P = _static_struct(params)
         cfg = _cfg_struct(field, ray_type)
         L.check(L.lib.rdrf_static_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
                                       L.ptr(z), L.ptr(valid), N, S, L.ptr(rgb), L.ptr(sigma),
-                                      L.ptr(weight), L.ptr(dists), L.ptr(ws), C.c_size_t(ws.numel()),
-                                      L.stream_of(z)), "rdrf_static_fwd")
-        ctx.field, ctx.ray_type = field, ray_type
+                                      L.ptr(weight), L.ptr(dists), L.ptr(saved), C.c_size_t(sbytes),
+                                      L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(z)),
+                "rdrf_static_fwd")
+        ctx.field, ctx.ray_type, ctx.saved = field, ray_type, saved
         ctx.save_for_backward(rays, ts, xyz, z, valid, *params)
         return rgb, sigma, weight, dists
 
@@ -195,8 +206,10 @@ class _StaticFn(torch.autograd.Function):
         L.check(L.lib.rdrf_static_bwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
                                       L.ptr(z), L.ptr(valid), N, S, L.ptr(g_rgb), L.ptr(g_sigma),
                                       L.ptr(g_weight), L.ptr(g_dists), C.byref(G), L.ptr(g_xyz),
-                                      L.ptr(g_z), L.ptr(g_rays), L.ptr(ws), C.c_size_t(ws.numel()),
+                                      L.ptr(g_z), L.ptr(g_rays), L.ptr(ctx.saved),
+                                      C.c_size_t(ctx.saved.numel()), L.ptr(ws), C.c_size_t(ws.numel()),
                                       L.stream_of(z)), "rdrf_static_bwd")
+        ctx.saved = None
         return (None, None, g_rays, None, g_xyz, g_z, None, *grads)
 
 
@@ -210,14 +223,15 @@ class _DynamicFn(torch.autograd.Function):
         xyz_prime = torch.empty(N, S, 3, device=dev)
         sigma, weight, dists, blending = (torch.empty(N, S, device=dev) for _ in range(4))
         ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
+        saved, sbytes = _alloc_saved(ctx, 1, N, S, dev)
         P = _dynamic_struct(params)
         cfg = _cfg_struct(field, ray_type)
         L.check(L.lib.rdrf_dynamic_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
                                        L.ptr(z), L.ptr(valid), N, S, L.ptr(blending), L.ptr(weight),
                                        L.ptr(xyz_prime), L.ptr(rgb), L.ptr(sigma), L.ptr(dists),
-                                       L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(z)),
-                "rdrf_dynamic_fwd")
-        ctx.field, ctx.ray_type = field, ray_type
+                                       L.ptr(saved), C.c_size_t(sbytes), L.ptr(ws),
+                                       C.c_size_t(ws.numel()), L.stream_of(z)), "rdrf_dynamic_fwd")
+        ctx.field, ctx.ray_type, ctx.saved = field, ray_type, saved
         ctx.save_for_backward(rays, ts, xyz, z, valid, *params)
         return blending, weight, xyz_prime, rgb, sigma, dists
 
@@ -241,8 +255,10 @@ class _DynamicFn(torch.autograd.Function):
         L.check(L.lib.rdrf_dynamic_bwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
                                        L.ptr(z), L.ptr(valid), N, S, L.ptr(gb), L.ptr(gw),
                                        L.ptr(gxp), L.ptr(gr), L.ptr(gs), L.ptr(gd), C.byref(G),
-                                       L.ptr(g_xyz), L.ptr(g_z), L.ptr(g_rays), L.ptr(ws),
+                                       L.ptr(g_xyz), L.ptr(g_z), L.ptr(g_rays), L.ptr(ctx.saved),
+                                       C.c_size_t(ctx.saved.numel()), L.ptr(ws),
                                        C.c_size_t(ws.numel()), L.stream_of(z)), "rdrf_dynamic_bwd")
+        ctx.saved = None
         return (None, None, g_rays, None, g_xyz, g_z, None, *grads)
 
 
@@ -255,13 +271,14 @@ class _SceneFlowFn(torch.autograd.Function):
         sf_f = torch.empty(N, S, 3, device=pts.device)
         sf_b = torch.empty(N, S, 3, device=pts.device)
         ws = L.workspace(pts.device, L.lib.rdrf_workspace_bytes(N, S))
+        saved, sbytes = _alloc_saved(ctx, 2, N, S, pts.device)
         P = _dynamic_struct(params)
         cfg = _cfg_struct(field, "ndc")
         L.check(L.lib.rdrf_scene_flow_fwd(C.byref(P), C.byref(cfg), L.ptr(pts), L.ptr(ts), N, S,
-                                          L.ptr(sf_f), L.ptr(sf_b), L.ptr(ws),
-                                          C.c_size_t(ws.numel()), L.stream_of(pts)),
+                                          L.ptr(sf_f), L.ptr(sf_b), L.ptr(saved), C.c_size_t(sbytes),
+                                          L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(pts)),
                 "rdrf_scene_flow_fwd")
-        ctx.field = field
+        ctx.field, ctx.saved = field, saved
         ctx.save_for_backward(pts, ts, *params)
         return sf_f, sf_b
 
@@ -278,9 +295,11 @@ class _SceneFlowFn(torch.autograd.Function):
         g_b = None if g_b is None else L.f32c(g_b)
         ws = L.workspace(pts.device, L.lib.rdrf_workspace_bytes(N, S))
         L.check(L.lib.rdrf_scene_flow_bwd(C.byref(P), C.byref(cfg), L.ptr(pts), L.ptr(ts), N, S,
-                                          L.ptr(g_f), L.ptr(g_b), C.byref(G), L.ptr(g_pts), L.ptr(ws),
+                                          L.ptr(g_f), L.ptr(g_b), C.byref(G), L.ptr(g_pts),
+                                          L.ptr(ctx.saved), C.c_size_t(ctx.saved.numel()), L.ptr(ws),
                                           C.c_size_t(ws.numel()), L.stream_of(pts)),
                 "rdrf_scene_flow_bwd")
+        ctx.saved = None
         return (None, g_pts, None, *grads)
 
 

@@ -1,0 +1,127 @@
+"""GPU parity (backward): gradients of every parameter of both fields through the HIP backward
+kernels vs (a) the reference's own autograd (golden vectors) and (b) the CPU oracle's autograd on a
+seeded mid-size batch.  Tolerance 2e-4 relative to each gradient tensor's max magnitude (atomics
+reorder the fp32 sums)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import CASES, assert_close
+
+pytestmark = pytest.mark.gpu
+
+ONAMES = ["rgb_map_full", "depth_map_full", "acc_map_full", "weights_full", "rgb_map_s",
+          "depth_map_s", "acc_map_s", "weights_s", "rgb_map_d", "depth_map_d", "acc_map_d",
+          "weights_d", "dynamicness_map"]
+
+
+def _golden_loss(g, o_s, o_d, outs, sf_f, sf_b, dev):
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    L = 0.0
+    for k, v in zip(ONAMES, outs):
+        L = L + (v * t("lw.c1." + k)).sum()
+    for k, v in (("blending", o_d[2]), ("weight", o_d[4]), ("xyz_prime", o_d[5]), ("weight_s", o_s[4])):
+        L = L + (v * t("lw.f." + k)).sum()
+    return L + (sf_f * t("lw.sf_f")).sum() + (sf_b * t("lw.sf_b")).sum()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_gradients(case):
+    import rodynrf
+    from _gpu_util import fields_from_case
+    g, st, dy, _ = fields_from_case(case)
+    rt = str(g["meta.ray_type"])
+    dev = "cuda"
+    rays = torch.from_numpy(g["rays"]).to(dev)
+    ts = torch.from_numpy(g["ts"]).to(dev)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    z = torch.from_numpy(g["z"]).to(dev)
+    valid = torch.from_numpy(g["valid"]).to(dev)
+    S = z.shape[1]
+    o_s = st(rays, ts, None, xyz, z, valid, is_train=True, ray_type=rt, N_samples=S)
+    o_d = dy(rays, ts, None, xyz, z, valid, is_train=True, ray_type=rt, N_samples=S)
+    outs = rodynrf.raw2outputs(o_s[6], o_s[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], rays,
+                               is_train=True, ray_type=rt, add_white_bg=True)
+    sf_f, sf_b = dy.get_forward_backward_scene_flow(o_d[3], ts)
+    L = _golden_loss(g, o_s, o_d, outs, sf_f, sf_b, dev)
+    at = 256.0 * 2.0 ** -20 if rt == "contract" else 0.0
+    assert_close(L, g["loss"], "loss", rtol=2e-4, atol=at * 20)
+    L.backward()
+    bad = []
+    for mod, pre in ((st, "gs."), (dy, "gd.")):
+        for k, p in mod.named_parameters():
+            ref = g[pre + k]
+            if ref.shape == ():
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            assert p.grad is not None, f"no grad for {pre}{k}"
+            try:
+                assert_close(p.grad, ref, pre + k, rtol=2e-4)
+            except AssertionError as e:
+                bad.append(str(e))
+    assert not bad, "\n".join(bad)
+
+
+def test_oracle_gradients_midsize():
+    """N=96 rays x S=70 samples on a 40x44x26 grid, seeded weights, against the oracle's autograd
+    (multi-tile rays, ragged last tile, partially-filled compacted tiles)."""
+    import rodynrf
+    from _gpu_util import COMMON, make_rays, oracle_cfg, oracle_sd
+    from oracle import rodynrf_oracle as O
+    torch.manual_seed(5)
+    N, S, grid = 96, 70, [40, 44, 26]
+    aabb = torch.tensor([[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]])
+    kw = dict(COMMON, near_far=[0.0, 1.0], density_shift=-10.0, fea2denseAct="relu")
+    st = rodynrf.TensorVMSplit(aabb, grid, 12, "cuda", shadingMode="MLP_Fea", fea_pe=2, **kw)
+    dy = rodynrf.TensorVMSplit_TimeEmbedding(aabb, grid, 12, "cuda", shadingMode="MLP_Fea_late_view",
+                                             fea_pe=0, **kw)
+    rays, ts = make_rays(N, 11)
+    jit = torch.rand(S, generator=torch.Generator().manual_seed(4))
+    gl = torch.Generator().manual_seed(9)
+    tgt = torch.rand(N, 3, generator=gl)
+    sd_s, sd_d = oracle_sd(st), oracle_sd(dy)
+    for sd in (sd_s, sd_d):
+        for v in sd.values():
+            v.requires_grad_(True)
+    cfg_s, cfg_d = oracle_cfg(st), oracle_cfg(dy)
+    xyz, z, valid = O.sampleXYZ(rays, aabb, [0.0, 1.0], S, "ndc", jit)
+    r_s = O.field_forward(sd_s, cfg_s, rays, ts, xyz, z, valid, "ndc", dynamic=False)
+    r_d = O.field_forward(sd_d, cfg_d, rays, ts, xyz, z, valid, "ndc", dynamic=True)
+    r_o = O.raw2outputs(r_s[6], r_s[7], r_d[6], r_d[7], r_d[9], r_d[2], r_d[8], rays, True, "ndc")
+    sf = O.scene_flow(sd_d, aabb, r_d[3], ts)
+
+    def loss(outs, sf, t):  # the three image terms of train.py:1323-1332,1827-1835 + extras
+        return (3 * ((outs[0] - t) ** 2).mean() + ((outs[8] - t) ** 2).mean() + ((outs[4] - t) ** 2).mean()
+                + 0.1 * outs[12].mean() + 0.05 * outs[9].mean() + 0.01 * (sf[0] ** 2).mean()
+                + 0.01 * (sf[1] ** 2).mean())
+
+    Lr = loss(r_o, sf, tgt)
+    ks, kd = list(sd_s.keys()), list(sd_d.keys())
+    gref = torch.autograd.grad(Lr, [sd_s[k] for k in ks] + [sd_d[k] for k in kd], allow_unused=True)
+    dev = "cuda"
+    cr, ct = rays.to(dev), ts.to(dev)
+    o_s = st(cr, ct, None, xyz.to(dev), z.to(dev), valid.to(dev), ray_type="ndc")
+    o_d = dy(cr, ct, None, xyz.to(dev), z.to(dev), valid.to(dev), ray_type="ndc")
+    outs = rodynrf.raw2outputs(o_s[6], o_s[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], cr,
+                               is_train=True, ray_type="ndc", add_white_bg=True)
+    sfg = dy.get_forward_backward_scene_flow(o_d[3], ct)
+    Lg = loss(outs, sfg, tgt.to(dev))
+    assert_close(Lg, Lr, "loss", rtol=1e-4)
+    Lg.backward()
+    own_s, own_d = dict(st.named_parameters()), dict(dy.named_parameters())
+    bad = []
+    for k, gr in zip(ks, gref[: len(ks)]):
+        if gr is None:
+            continue
+        try:
+            assert_close(own_s[k].grad, gr, "gs." + k, rtol=2e-4)
+        except AssertionError as e:
+            bad.append(str(e))
+    for k, gr in zip(kd, gref[len(ks):]):
+        if gr is None:
+            continue
+        try:
+            assert_close(own_d[k].grad, gr, "gd." + k, rtol=2e-4)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad)
