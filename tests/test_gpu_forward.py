@@ -63,7 +63,10 @@ def test_golden_forward(case):
                                        gt("fd.dists"), gt("fd.blending"), gt("fd.z"), rays,
                                        is_train=True, ray_type=rt, add_white_bg=white)
             for k, v in zip(ONAMES, outs):
-                assert_close(v, g[pre + k], pre + k)
+                # contract depth adds (1-acc)*256: fp32 rounding of acc (2^-23 relative to 1)
+                # is amplified by 256, so that output carries an absolute term 256*2^-22
+                at = 256.0 * 2.0 ** -22 if (rt == "contract" and "depth" in k) else 0.0
+                assert_close(v, g[pre + k], pre + k, atol=at)
         sf_f, sf_b = dy.get_forward_backward_scene_flow(xyz, ts)
         assert_close(sf_f, g["sf.f"], "sf.f")
         assert_close(sf_b, g["sf.b"], "sf.b")
