@@ -423,8 +423,8 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
   if (n >= a.N) return;
   float vx, vy, vz;
   const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-  float total = 0.f;
-  if (a.g_weight) {  // pass 0: sum_m gw_m w_m
+  double total = 0.;
+  if (a.g_weight) {  // pass 0: sum_m gw_m w_m (fp64: suffix = total - prefix must not cancel)
     float carry = 1.0f;
     for (int j0 = 0; j0 < a.S; j0 += 64) {
       const int j = j0 + lane;
@@ -442,11 +442,13 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
       if (lane == 0) excl = 1.0f;
       const float wt = alpha * carry * excl;
       carry *= __shfl(incl, 63, 64);
-      total += act ? a.g_weight[idx] * wt : 0.f;
+      total += act ? (double)(a.g_weight[idx] * wt) : 0.;
     }
-    total = wave_sum(total);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
   }
-  float carry = 1.0f, prefix = 0.f;
+  float carry = 1.0f;
+  double prefix = 0.;
   for (int j0 = 0; j0 < a.S; j0 += 64) {
     const int j = j0 + lane;
     const bool act = j < a.S;
@@ -469,13 +471,13 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
       const float gwv = act ? a.g_weight[idx] : 0.f;
       const float c = gwv * alpha * T;
       // inclusive prefix sum of c over the wave
-      float inc = c;
+      double inc = (double)c;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(inc, d, 64);
+        const double o = __shfl_up(inc, d, 64);
         if (lane >= d) inc += o;
       }
-      const float suffix = total - (prefix + inc);
+      const float suffix = (float)(total - (prefix + inc));
       prefix += __shfl(inc, 63, 64);
       g_alpha = gwv * T - suffix / p;
     }
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
     float vx, vy, vz;
     const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-    float total = 0.f;
+    double total = 0.;
     if (a.g_weight) {
       float carry = 1.0f;
       for (int j0 = 0; j0 < a.S; j0 += 32) {
@@ -530,11 +532,13 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         if (s == 0) excl = 1.0f;
         const float wt = alpha * carry * excl;
         carry *= __shfl(incl, 31, 32);
-        total += (act && h == 0) ? a.g_weight[idx] * wt : 0.f;
+        total += (act && h == 0) ? (double)(a.g_weight[idx] * wt) : 0.;
       }
-      total = wave_sum(total);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
     }
-    float carry = 1.0f, prefix = 0.f;
+    float carry = 1.0f;
+    double prefix = 0.;
     float dTacc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dTacc[i] = 0.f;
@@ -561,13 +565,13 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         const float T = carry * excl;
         carry *= __shfl(incl, 31, 32);
         const float gwv = act ? a.g_weight[idx] : 0.f;
-        float inc = gwv * alpha * T;
+        double inc = (double)(gwv * alpha * T);
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {
-          const float o = __shfl_up(inc, d, 32);
+          const double o = __shfl_up(inc, d, 32);
           if (s >= d) inc += o;
         }
-        const float suffix = total - (prefix + inc);
+        const float suffix = (float)(total - (prefix + inc));
         prefix += __shfl(inc, 31, 32);
         g_alpha = gwv * T - suffix / p;
       }

@@ -317,12 +317,19 @@ struct CompSample {
   float cd[3], cs[3];
 };
 
-RDRF_D float wave_incl_sum(float v, int lane) {
+// prefix sums are carried in fp64: suffix = total - prefix would otherwise cancel in fp32 (the
+// reference's cumprod backward forms the suffix sum directly)
+RDRF_D double wave_incl_sum(double v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
+    const double o = __shfl_up(v, d, 64);
     if (lane >= d) v += o;
   }
+  return v;
+}
+RDRF_D double wave_sum_d(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
 
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
   const float const_s = Gacc_s - white * sgs - Gdep_s * far;
   const float const_f = Gacc_f + (rl_on ? (-white * sgf - Gdep_f * far) : 0.f);
   // ---- sweep 2: totals
-  float D1 = 0.f, tot_s = 0.f, tot_f = 0.f;
+  double D1 = 0., tot_s = 0., tot_f = 0., DU = 0.;
   {
     float cd = 1.f, cs = 1.f, cf = 1.f;
     for (int j0 = 0; j0 < S; j0 += 64) {
@@ -410,17 +417,21 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
         const float gwd = (a.g[11] ? a.g[11][idx] : 0.f) + dd + Gdep_d * q.zz + const_d;
         const float gws = (a.g[7] ? a.g[7][idx] : 0.f) + dsv + Gdep_s * q.zz + const_s;
         const float gwf = (a.g[3] ? a.g[3][idx] : 0.f) + Gdep_f * q.zz + Gdyn * q.b + const_f;
-        D1 += gwd * (u / Ue);
-        tot_s += gws * ws;
-        tot_f += q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs));
+        D1 += (double)gwd * (double)(u / Ue);
+        DU += (double)gwd * (double)u;
+        tot_s += (double)(gws * ws);
+        tot_f += (double)(q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs)));
       }
     }
-    D1 = wave_sum(D1); tot_s = wave_sum(tot_s); tot_f = wave_sum(tot_f);
+    D1 = wave_sum_d(D1); tot_s = wave_sum_d(tot_s); tot_f = wave_sum_d(tot_f); DU = wave_sum_d(DU);
   }
-  const float tot_d = D1 * 1e-10f / Ue;
+  const float D1f = (float)D1;
+  // sum_m gu_m u_m with gu = (gwd - D1)/Ue
+  const double tot_d = (DU - D1 * (double)U) / (double)Ue;
   // ---- sweep 3
   {
-    float cd = 1.f, cs = 1.f, cf = 1.f, pre_d = 0.f, pre_s = 0.f, pre_f = 0.f;
+    float cd = 1.f, cs = 1.f, cf = 1.f;
+    double pre_d = 0., pre_s = 0., pre_f = 0.;
     for (int j0 = 0; j0 < S; j0 += 64) {
       const int j = j0 + lane;
       CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
@@ -434,11 +445,12 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
       const float gwd = (a.g[11] ? a.g[11][idx] : 0.f) + dd + Gdep_d * q.zz + const_d;
       const float gws = (a.g[7] ? a.g[7][idx] : 0.f) + dsv + Gdep_s * q.zz + const_s;
       const float gwf = (a.g[3] ? a.g[3][idx] : 0.f) + Gdep_f * q.zz + Gdyn * q.b + const_f;
-      const float gu = (gwd - D1) / Ue;
-      const float td = act ? gu * u : 0.f, ts_ = act ? gws * ws : 0.f;
-      const float tf = act ? q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs)) : 0.f;
-      const float id = wave_incl_sum(td, lane), is = wave_incl_sum(ts_, lane), ifl = wave_incl_sum(tf, lane);
-      const float suf_d = tot_d - (pre_d + id), suf_s = tot_s - (pre_s + is), suf_f = tot_f - (pre_f + ifl);
+      const float gu = (gwd - D1f) / Ue;
+      const double td = act ? (double)(gu * u) : 0., ts_ = act ? (double)(gws * ws) : 0.;
+      const double tf = act ? (double)(q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs))) : 0.;
+      const double id = wave_incl_sum(td, lane), is = wave_incl_sum(ts_, lane), ifl = wave_incl_sum(tf, lane);
+      const float suf_d = (float)(tot_d - (pre_d + id)), suf_s = (float)(tot_s - (pre_s + is)),
+                  suf_f = (float)(tot_f - (pre_f + ifl));
       pre_d += __shfl(id, 63, 64); pre_s += __shfl(is, 63, 64); pre_f += __shfl(ifl, 63, 64);
       if (act) {
         float g_ad = gu * q.Td - suf_d / q.pd;
