@@ -416,17 +416,20 @@ __global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, St
 //   dL/dalpha_k = gw_k T_k - (sum_{m>k} gw_m w_m) / p_k
 // ------------------------------------------------------------------------------------------------
 
-// static field, density phase backward: wave per ray, lane per sample
+// static field, density phase backward: wave per ray, lane per sample.  The suffix sum is formed
+// directly by walking the ray LAST tile first (transmittance carries of each tile start come from a
+// forward pre-pass); total - prefix would cancel catastrophically when p -> 1e-10.
 __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w, StaticG gw) {
+  __shared__ float carr[32];
   const int lane = threadIdx.x;
   const int n = blockIdx.x;
   if (n >= a.N) return;
   float vx, vy, vz;
   const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-  double total = 0.;
-  if (a.g_weight) {  // pass 0: sum_m gw_m w_m (fp64: suffix = total - prefix must not cancel)
+  if (a.g_weight) {
     float carry = 1.0f;
     for (int j0 = 0; j0 < a.S; j0 += 64) {
+      if (lane == 0) carr[j0 >> 6] = carry;
       const int j = j0 + lane;
       const bool act = j < a.S;
       const int idx = n * a.S + (act ? j : 0);
@@ -437,19 +440,14 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
       const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
       const float alpha = 1.0f - expf(-sigma * ds);
       const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
-      const float incl = scan_mul64(p, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 1.0f;
-      const float wt = alpha * carry * excl;
-      carry *= __shfl(incl, 63, 64);
-      total += act ? (double)(a.g_weight[idx] * wt) : 0.;
+      carry *= __shfl(scan_mul64(p, lane), 63, 64);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
   }
-  float carry = 1.0f;
-  double prefix = 0.;
-  for (int j0 = 0; j0 < a.S; j0 += 64) {
+  __syncthreads();
+  float sufcarry = 0.f;
+  const int ntile = (a.S + 63) >> 6;
+  for (int tl = ntile - 1; tl >= 0; --tl) {
+    const int j0 = tl << 6;
     const int j = j0 + lane;
     const bool act = j < a.S;
     const int idx = n * a.S + (act ? j : 0);
@@ -466,20 +464,18 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
       const float incl = scan_mul64(p, lane);
       float excl = __shfl_up(incl, 1, 64);
       if (lane == 0) excl = 1.0f;
-      const float T = carry * excl;
-      carry *= __shfl(incl, 63, 64);
+      const float T = carr[tl] * excl;
       const float gwv = act ? a.g_weight[idx] : 0.f;
-      const float c = gwv * alpha * T;
-      // inclusive prefix sum of c over the wave
-      double inc = (double)c;
+      float rinc = gwv * alpha * T;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
+        const float o = __shfl_down(rinc, d, 64);
+        if (lane + d < 64) rinc += o;
       }
-      const float suffix = (float)(total - (prefix + inc));
-      prefix += __shfl(inc, 63, 64);
-      g_alpha = gwv * T - suffix / p;
+      float rex = __shfl_down(rinc, 1, 64);
+      if (lane == 63) rex = 0.f;
+      g_alpha = gwv * T - (sufcarry + rex) / p;
+      sufcarry += __shfl(rinc, 0, 64);
     }
     float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
     g_sigma += g_alpha * ds * (1.0f - alpha);
@@ -506,6 +502,7 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::K1_SIZE];
+  __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
   lds_fill(lds, a.pk + pkb::REG_K1, pkb::K1_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -513,10 +510,10 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
     float vx, vy, vz;
     const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-    double total = 0.;
-    if (a.g_weight) {
+    if (a.g_weight) {  // pre-pass: transmittance at each tile start
       float carry = 1.0f;
       for (int j0 = 0; j0 < a.S; j0 += 32) {
+        if (lane == 0) carr[wave][j0 >> 5] = carry;
         const int j = j0 + s;
         const bool act = j < a.S;
         const int idx = n * a.S + (act ? j : 0);
@@ -527,27 +524,20 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
         const float alpha = 1.0f - expf(-sigma * ds);
         const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
-        const float incl = scan_mul32(p, s);
-        float excl = __shfl_up(incl, 1, 32);
-        if (s == 0) excl = 1.0f;
-        const float wt = alpha * carry * excl;
-        carry *= __shfl(incl, 31, 32);
-        total += (act && h == 0) ? (double)(a.g_weight[idx] * wt) : 0.;
+        carry *= __shfl(scan_mul32(p, s), 31, 32);
       }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
     }
-    float carry = 1.0f;
-    double prefix = 0.;
+    float sufcarry = 0.f;
     float dTacc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dTacc[i] = 0.f;
-    for (int j0 = 0; j0 < a.S; j0 += 32) {
+    for (int tli = tpr - 1; tli >= 0; --tli) {  // LAST tile first: direct suffix sums
+      const int j0 = tli << 5;
       const int j = j0 + s;
       const bool act = j < a.S;
       const int idx = n * a.S + (act ? j : 0);
       const bool vld = act && a.valid[idx] != 0;
-      const size_t tl = (size_t)n * tpr + (j0 >> 5);
+      const size_t tl = (size_t)n * tpr + tli;
       const float* svb = a.sp.act1 + tl * sv::K1_ROWS * 32;
       float* gb = a.grows1 + tl * sv::K1G_ROWS * 32;
       const float fd = a.sp.raw[(size_t)idx * 2], fb = a.sp.raw[(size_t)idx * 2 + 1];
@@ -562,18 +552,18 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         const float incl = scan_mul32(p, s);
         float excl = __shfl_up(incl, 1, 32);
         if (s == 0) excl = 1.0f;
-        const float T = carry * excl;
-        carry *= __shfl(incl, 31, 32);
+        const float T = carr[wave][tli] * excl;
         const float gwv = act ? a.g_weight[idx] : 0.f;
-        double inc = (double)(gwv * alpha * T);
+        float rinc = gwv * alpha * T;
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {
-          const double o = __shfl_up(inc, d, 32);
-          if (s >= d) inc += o;
+          const float o = __shfl_down(rinc, d, 32);
+          if (s + d < 32) rinc += o;
         }
-        const float suffix = (float)(total - (prefix + inc));
-        prefix += __shfl(inc, 31, 32);
-        g_alpha = gwv * T - suffix / p;
+        float rex = __shfl_down(rinc, 1, 32);
+        if (s == 31) rex = 0.f;
+        g_alpha = gwv * T - (sufcarry + rex) / p;
+        sufcarry += __shfl(rinc, 0, 32);
       }
       float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
       g_sigma += g_alpha * ds * (1.0f - alpha);
@@ -1082,7 +1072,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
                                rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "static_bwd: bad arguments");
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 2048, -1, "static_bwd: bad arguments (S <= 2048)");
   // dists depends on z and rays only: g_dists matters only when g_z / g_rays are requested
   RDRF_CHECK(g_z == nullptr && g_rays == nullptr, -38,
              "static_bwd: gradients through dists / view directions (g_z, g_rays) are not built yet");
@@ -1147,7 +1137,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 float* g_z, float* g_rays, void* saved, size_t saved_bytes, void* ws,
                                 size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "dynamic_bwd: bad arguments");
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 1024, -1, "dynamic_bwd: bad arguments (S <= 1024)");
   RDRF_CHECK(g_z == nullptr && g_rays == nullptr, -38,
              "dynamic_bwd: gradients through dists (g_z, g_rays) are not built yet");
   (void)g_dists;

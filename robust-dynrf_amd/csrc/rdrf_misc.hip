@@ -317,22 +317,6 @@ struct CompSample {
   float cd[3], cs[3];
 };
 
-// prefix sums are carried in fp64: suffix = total - prefix would otherwise cancel in fp32 (the
-// reference's cumprod backward forms the suffix sum directly)
-RDRF_D double wave_incl_sum(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
-  return v;
-}
-RDRF_D double wave_sum_d(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-
 RDRF_D CompSample comp_load(const CompBArgs& a, int n, int j, int lane, float& cd, float& cs, float& cf) {
   CompSample q;
   const bool act = j < a.S;
@@ -354,7 +338,22 @@ RDRF_D CompSample comp_load(const CompBArgs& a, int n, int j, int lane, float& c
   return q;
 }
 
+// exclusive reverse (suffix) sum over the wave: sum of v over lanes > lane
+RDRF_D float wave_suffix_excl(float v, int lane, float& total) {
+  float inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(inc, d, 64);
+    if (lane + d < 64) inc += o;
+  }
+  total = __shfl(inc, 0, 64);
+  float ex = __shfl_down(inc, 1, 64);
+  if (lane == 63) ex = 0.f;
+  return ex;
+}
+
 __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
+  __shared__ float carr[3][32];  // transmittance carries at each 64-sample tile start (S <= 2048)
   const int lane = threadIdx.x;
   const int n = blockIdx.x;
   if (n >= a.N) return;
@@ -365,6 +364,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
   {
     float cd = 1.f, cs = 1.f, cf = 1.f;
     for (int j0 = 0; j0 < S; j0 += 64) {
+      if (lane == 0) { carr[0][j0 >> 6] = cd; carr[1][j0 >> 6] = cs; carr[2][j0 >> 6] = cf; }
       const int j = j0 + lane;
       CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
       if (j < S) {
@@ -377,6 +377,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
     U = wave_sum(U); acc_s = wave_sum(acc_s); acc_f = wave_sum(acc_f);
     for (int c = 0; c < 3; ++c) { ru[c] = wave_sum(ru[c]); rs[c] = wave_sum(rs[c]); rf[c] = wave_sum(rf[c]); }
   }
+  __syncthreads();
   const float Ue = U + 1e-10f;
   const float acc_d = U / Ue;
   const float white = a.add_white_bg ? 1.f : 0.f;
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
   const float const_d = Gacc_d - white * sgd - Gdep_d * far;
   const float const_s = Gacc_s - white * sgs - Gdep_s * far;
   const float const_f = Gacc_f + (rl_on ? (-white * sgf - Gdep_f * far) : 0.f);
-  // ---- sweep 2: totals
-  double D1 = 0., tot_s = 0., tot_f = 0., DU = 0.;
+  // ---- sweep 2: D1 = sum_m gwd_m * wd_m  (normalisation of weights_d)
+  float D1 = 0.f;
   {
     float cd = 1.f, cs = 1.f, cf = 1.f;
     for (int j0 = 0; j0 < S; j0 += 64) {
@@ -410,29 +411,22 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
       CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
       if (j < S) {
         const size_t idx = (size_t)n * S + j;
-        const float u = q.ad * q.Td, ws = q.as * q.Ts;
-        const float cfd = q.ad * q.b, cfs = q.as * (1.0f - q.b);
-        float dd = 0.f, dsv = 0.f, dfd = 0.f, dfs = 0.f;
-        for (int c = 0; c < 3; ++c) { dd += grd[c] * q.cd[c]; dsv += grs[c] * q.cs[c]; dfd += grf[c] * q.cd[c]; dfs += grf[c] * q.cs[c]; }
+        float dd = 0.f;
+        for (int c = 0; c < 3; ++c) dd += grd[c] * q.cd[c];
         const float gwd = (a.g[11] ? a.g[11][idx] : 0.f) + dd + Gdep_d * q.zz + const_d;
-        const float gws = (a.g[7] ? a.g[7][idx] : 0.f) + dsv + Gdep_s * q.zz + const_s;
-        const float gwf = (a.g[3] ? a.g[3][idx] : 0.f) + Gdep_f * q.zz + Gdyn * q.b + const_f;
-        D1 += (double)gwd * (double)(u / Ue);
-        DU += (double)gwd * (double)u;
-        tot_s += (double)(gws * ws);
-        tot_f += (double)(q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs)));
+        D1 += gwd * ((q.ad * q.Td) / Ue);
       }
     }
-    D1 = wave_sum_d(D1); tot_s = wave_sum_d(tot_s); tot_f = wave_sum_d(tot_f); DU = wave_sum_d(DU);
+    D1 = wave_sum(D1);
   }
-  const float D1f = (float)D1;
-  // sum_m gu_m u_m with gu = (gwd - D1)/Ue
-  const double tot_d = (DU - D1 * (double)U) / (double)Ue;
-  // ---- sweep 3
+  // ---- sweep 3, LAST tile first: direct suffix sums (no total - prefix cancellation; the
+  // factor 1/p can be 1e10 when alpha -> 1)
   {
-    float cd = 1.f, cs = 1.f, cf = 1.f;
-    double pre_d = 0., pre_s = 0., pre_f = 0.;
-    for (int j0 = 0; j0 < S; j0 += 64) {
+    float suf_d = 0.f, suf_s = 0.f, suf_f = 0.f;  // sums over all later tiles
+    const int ntile = (S + 63) >> 6;
+    for (int tl = ntile - 1; tl >= 0; --tl) {
+      const int j0 = tl << 6;
+      float cd = carr[0][tl], cs = carr[1][tl], cf = carr[2][tl];
       const int j = j0 + lane;
       CompSample q = comp_load(a, n, j, lane, cd, cs, cf);
       const bool act = j < S;
@@ -445,17 +439,18 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
       const float gwd = (a.g[11] ? a.g[11][idx] : 0.f) + dd + Gdep_d * q.zz + const_d;
       const float gws = (a.g[7] ? a.g[7][idx] : 0.f) + dsv + Gdep_s * q.zz + const_s;
       const float gwf = (a.g[3] ? a.g[3][idx] : 0.f) + Gdep_f * q.zz + Gdyn * q.b + const_f;
-      const float gu = (gwd - D1f) / Ue;
-      const double td = act ? (double)(gu * u) : 0., ts_ = act ? (double)(gws * ws) : 0.;
-      const double tf = act ? (double)(q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs))) : 0.;
-      const double id = wave_incl_sum(td, lane), is = wave_incl_sum(ts_, lane), ifl = wave_incl_sum(tf, lane);
-      const float suf_d = (float)(tot_d - (pre_d + id)), suf_s = (float)(tot_s - (pre_s + is)),
-                  suf_f = (float)(tot_f - (pre_f + ifl));
-      pre_d += __shfl(id, 63, 64); pre_s += __shfl(is, 63, 64); pre_f += __shfl(ifl, 63, 64);
+      const float gu = (gwd - D1) / Ue;
+      const float td = act ? gu * u : 0.f, ts_ = act ? gws * ws : 0.f;
+      const float tf = act ? q.Tf * (cfd * dfd + cfs * dfs + gwf * (cfd + cfs)) : 0.f;
+      float tot_d, tot_s, tot_f;
+      const float sd = suf_d + wave_suffix_excl(td, lane, tot_d);
+      const float ss = suf_s + wave_suffix_excl(ts_, lane, tot_s);
+      const float sfv = suf_f + wave_suffix_excl(tf, lane, tot_f);
+      suf_d += tot_d; suf_s += tot_s; suf_f += tot_f;
       if (act) {
-        float g_ad = gu * q.Td - suf_d / q.pd;
-        float g_as = gws * q.Ts - suf_s / q.ps;
-        const float g_pf = suf_f / q.pf;
+        float g_ad = gu * q.Td - sd / q.pd;
+        float g_as = gws * q.Ts - ss / q.ps;
+        const float g_pf = sfv / q.pf;
         const float g_cfd = q.Tf * (dfd + gwf), g_cfs = q.Tf * (dfs + gwf);
         const float uu = 1.0f - q.ad * q.b, vv = 1.0f - q.as * (1.0f - q.b);
         g_ad += g_cfd * q.b - g_pf * q.b * vv;
@@ -487,7 +482,7 @@ extern "C" int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, cons
                                   int add_white_bg, const float* const g_out13[13],
                                   float* const g_in8[8], rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  RDRF_CHECK(N > 0 && S > 0 && g_out13 && g_in8, -1, "composite_bwd: bad arguments");
+  RDRF_CHECK(N > 0 && S > 0 && S <= 2048 && g_out13 && g_in8, -1, "composite_bwd: bad arguments (S <= 2048)");
   CompBArgs a;
   a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
   a.dists = dists; a.blending = blending; a.z = z; a.rays = rays;
