@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""bench.py -- training rays/s of the RoDynRF ray-batch hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one Nvidia.txt-shaped training iteration (robust-dynrf_amd/step.py): 4 dynamic + 5
+static forward passes, scene-flow MLP, the three-way compositor, one backward through all of it,
+the gradient exchange (N > 1) and one Adam step, on synthetic Balloon1-shaped inputs that are
+resident in HBM before the timed region.  Workload at N = 1: BASELINE.json configs[1] (Nvidia
+Balloon1, configs/Nvidia.txt, 4096 rays/iter, static + dynamic TensorVMSplit, first resolution
+stage 128^3 -> grid [141,157,94], 115 samples/ray).  For N > 1 every rank keeps 4096 rays
+(weak scaling): rays are sharded, parameters replicated, one flat gradient all-reduce over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = rays consumed by the whole job per second.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+# algorithmic FLOP per sample: f32 multiply-adds x 2
+F_DYN_DENSITY = 26496 + 19584 + 19584      # warp + density head + blending head
+F_DYN_APP = 11664 + 60946                  # basis + late-view head
+F_STAT_APP = 72752                         # basis + MLP_Fea head
+F_SCENE_FLOW = 21760
+PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def prof_get(L, name):
+    ms, n = C.c_double(), C.c_int()
+    L.lib.rdrf_prof_get(name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
+
+def cpu_baseline(trainer, n_rays, S, seed=0):
+    """The oracle (oracle/rodynrf_oracle.py, torch-CPU restatement of the reference) running the
+    SAME step structure on `n_rays` rays on the host cores: kind "port"."""
+    from oracle import rodynrf_oracle as O
+    st, dy = trainer.st, trainer.dy
+    cfg = trainer.cfg
+    sd_s = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in st.state_dict().items()}
+    sd_d = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in dy.state_dict().items()}
+    aabb = st.aabb.detach().cpu()
+    base = dict(aabb=aabb, act="relu", density_shift=-10.0, distance_scale=25.0, weight_thres=1e-4, view_pe=0)
+    cfg_s = dict(base, head="MLP_Fea", fea_pe=2)
+    cfg_d = dict(base, head="MLP_Fea_late_view", fea_pe=0)
+    d = trainer.data
+    g = torch.Generator().manual_seed(seed)
+    ids = d.perm[:n_rays].cpu()
+    ids2 = d.perm[n_rays:2 * n_rays].cpu()
+    ids3 = d.perm[2 * n_rays:3 * n_rays].cpu()
+    poses, focal = d.poses.cpu(), float(d.focal)
+    H, W, T = cfg["H"], cfg["W"], cfg["T"]
+    ts_of = lambda i: (i // (H * W)).float() * (2.0 / (T - 1)) - 1.0
+    rgb_t, disp_t, fg = d.rgb[ids.to(d.device)].cpu(), d.disp[ids.to(d.device)].cpu(), d.fgmask[ids.to(d.device)].cpu()
+
+    def rp(rays, ts, static_grad, dynamic, white):
+        jit = torch.rand(S, generator=g)
+        xyz, z, valid = O.sampleXYZ(rays, aabb, cfg["near_far"], S, "ndc", jit)
+        if static_grad:
+            o_s = O.field_forward(sd_s, cfg_s, rays, ts, xyz, z, valid, "ndc", dynamic=False)
+        else:
+            with torch.no_grad():
+                o_s = O.field_forward(sd_s, cfg_s, rays, ts, xyz, z, valid, "ndc", dynamic=False)
+        if dynamic:
+            o_d = O.field_forward(sd_d, cfg_d, rays, ts, xyz, z, valid, "ndc", dynamic=True)
+            a = (o_d[6], o_d[7], o_d[9], o_d[2], o_d[8])
+        else:
+            o_d = None
+            a = (torch.zeros_like(o_s[6]), torch.zeros_like(o_s[7]), o_s[9], torch.zeros_like(o_s[7]), z)
+        outs = O.raw2outputs(o_s[6], o_s[7], a[0], a[1], a[2], a[3], a[4], rays, white, "ndc")
+        return o_s, o_d, outs, xyz
+
+    def step():
+        rays = O.generate_rays(ids, poses, focal, H, W, ndc=True, near=1.0)
+        ts = ts_of(ids)
+        dt = 2.0 / (T - 1)
+        _, oA, outA, xyzA = rp(rays, ts, False, True, True)
+        loss = 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
+        loss = loss + 0.1 * (outA[12] - fg).abs().mean() + 0.04 * (outA[9] - disp_t).abs().mean()
+        _, oB, outB, _ = rp(rays, ts_of(ids2), False, True, False)
+        loss = loss + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+        sf_f, sf_b = O.scene_flow(sd_d, aabb, oA[3], ts)
+        w_d = outA[11].detach()[..., None]
+        loss = loss + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
+        loss = loss + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
+        for ids_n, sgn in ((ids2, 1.0), (ids3, -1.0)):
+            rays_n = O.generate_rays(ids_n, poses, focal, H, W, ndc=True, near=1.0)
+            _, oN, outN, xyzN = rp(rays_n, (ts + sgn * dt).clamp(-1, 1), False, True, True)
+            induced = (outN[11][..., None] * xyzN).sum(1)
+            target = (outA[11].detach()[..., None] * (xyzA + (sf_f if sgn > 0 else sf_b)).detach()).sum(1)
+            loss = loss + 0.02 * (induced - target).abs().mean()
+        _, _, outE, _ = rp(rays, ts, True, False, False)
+        m = (1.0 - fg)[:, None]
+        loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
+        loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
+        ps = list(sd_s.values()) + list(sd_d.values())
+        torch.autograd.grad(loss, ps, allow_unused=True)
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    step()
+    dtm = time.perf_counter() - t0
+    return dict(value=n_rays / dtm, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/rodynrf_oracle.py (torch-CPU restatement of the reference), the same "
+                       f"5-pass step on {n_rays} rays x {S} samples, 1 step after 1 warm-up, "
+                       f"{dtm:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--stage", default="stage0", choices=["stage0", "final"])
+    ap.add_argument("--weights", default="dense", choices=["dense", "sparse"])
+    ap.add_argument("--rays-per-gpu", type=int, default=4096)
+    ap.add_argument("--cpu-rays", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    P = importlib.import_module("robust-dynrf_amd.parallel")
+    rank, local, world = P.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L = importlib.import_module("robust-dynrf_amd._lib")
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+
+    cfg = S_.balloon1_config(args.stage)
+    cfg["batch_size"] = args.rays_per_gpu * world   # weak scaling: fixed rays per GPU
+    trainer = S_.Trainer(cfg, dev, weights=args.weights)
+    params = [p for g in trainer.opt.param_groups for p in g["params"]]
+    bucket = P.GradBucket(params)
+    shard = (rank, world)
+
+    def one_step():
+        loss = trainer.step(shard)
+        bucket.allreduce_()
+        trainer.finish_step()
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = cfg["batch_size"] / (ms * 1e-3)
+    loss_val = float(loss.item())
+
+    out = {
+        "metric": "training rays/sec (Nvidia Balloon1, configs/Nvidia.txt, static+dynamic TensorVMSplit)",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: Nvidia Balloon1, configs/Nvidia.txt, "
+                               f"{args.rays_per_gpu} rays/iter/GPU, 1xMI355X per rank, static+dynamic "
+                               "TensorVMSplit; one step = 4 dynamic + 5 static forward passes, scene-flow "
+                               "MLP, compositor, full backward, Adam",
+                   "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
+                   "global_batch": cfg["batch_size"], "weights": args.weights,
+                   "parallelism": f"ray-sharded dp{world}", "final_loss": loss_val},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # measured sample fractions (enter the algorithmic FLOP counts)
+        with torch.no_grad():
+            ids = trainer.data.batch(0, args.rays_per_gpu, 0)
+            rays = trainer.rays_for(ids)
+            ts = trainer.data.ts_of(ids)
+            o_s, o_d, _, _ = S_.ray_pass(trainer.st, trainer.dy, rays, ts, cfg["n_samples"], cfg["ray_type"])
+            valid_frac = float((o_d[7] >= 0).float().mean())  # all samples processed by the density phase
+            f_d = float((o_d[4] > 1e-4).float().mean())
+            f_s = float((o_s[4] > 1e-4).float().mean())
+        L.lib.rdrf_prof_enable(1)
+        L.lib.rdrf_prof_reset()
+        NP = 2
+        for _ in range(NP):
+            trainer.step(shard)
+            trainer.finish_step()
+        torch.cuda.synchronize()
+        ns = args.rays_per_gpu * cfg["n_samples"]
+        flops = {
+            "dyn_density": ns * F_DYN_DENSITY, "dyn_density_bwd": ns * F_DYN_DENSITY,
+            "dyn_app": ns * f_d * F_DYN_APP, "dyn_app_bwd": ns * f_d * F_DYN_APP,
+            "static_app": ns * f_s * F_STAT_APP, "static_app_bwd": ns * f_s * F_STAT_APP,
+            "dw_dyn": ns * (F_DYN_DENSITY + f_d * F_DYN_APP), "dw_static": ns * f_s * F_STAT_APP,
+            "scene_flow": ns * F_SCENE_FLOW, "scene_flow_bwd": ns * F_SCENE_FLOW, "dw_sf": ns * F_SCENE_FLOW,
+        }
+        table, tot_ms = {}, 0.0
+        for k in ["pack", "generate_rays", "sample_ndc", "static_density", "static_app", "time_branch",
+                  "dyn_density", "dyn_app", "composite", "scene_flow", "composite_bwd", "dyn_app_bwd",
+                  "dyn_density_bwd", "time_branch_bwd", "dw_dyn", "static_app_bwd", "static_density_bwd",
+                  "dw_static", "scene_flow_bwd", "dw_sf"]:
+            msk, n = prof_get(L, k)
+            if n:
+                table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}
+                tot_ms += msk / NP
+        L.lib.rdrf_prof_enable(0)
+        dom = max((k for k in table if k in flops), key=lambda k: table[k]["ms_per_step"])
+        avg_s = table[dom]["avg_us"] * 1e-6
+        ach = flops[dom] / avg_s / 1e12
+        step_flops = sum(flops[k] * table[k]["launches_per_step"] for k in table if k in flops)
+        out["roofline"] = {
+            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom,
+            "kernel_avg_us": table[dom]["avg_us"], "algorithmic_flop_per_launch": flops[dom],
+            "step_algorithmic_tflop": step_flops / 1e12,
+            "step_frac_of_peak": step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in table.items()},
+            "sum_kernel_ms_per_step": tot_ms,
+            "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, cfg["n_samples"])
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -951,14 +951,14 @@ static void dw_blk(DwJobs& D, int row0, int seg, int e0) {
   j.blk_row0[j.nblk] = row0; j.blk_seg[j.nblk] = seg; j.blk_e0[j.nblk] = e0;
   j.nblk++;
 }
-static int dw_launch(DwJobs& D, hipStream_t stream) {
+static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
   D.item0[0] = 0;
   for (int i = 0; i < D.n; ++i) D.item0[i + 1] = D.item0[i] + D.j[i].nbo * ((D.j[i].nblk + 3) / 4);
   const int items = D.item0[D.n];
   const int gy = (items + 3) / 4;
   int gx = (256 * 8 + gy - 1) / gy;
   gx = gx < 1 ? 1 : gx;
-  RDRF_LAUNCH("dw", k_dw, dim3(gx, gy), dim3(256), stream, D);
+  RDRF_LAUNCH(name, k_dw, dim3(gx, gy), dim3(256), stream, D);
   return 0;
 }
 
@@ -1120,7 +1120,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DF, 1, 27, 0, a.sp.act3, sv::S3_ROWS, 72, 72, G->basis,
            nullptr, cnt, 0);
     for (int i = 0; i < 3; ++i) dw_blk(D, sv::S3_G + 32 * i, SEG_IDENT, 32 * i);
-    rc = dw_launch(D, stream);
+    rc = dw_launch(D, stream, "dw_static");
     if (rc) return rc;
   }
   if (g_sigma != nullptr || g_weight != nullptr)
@@ -1226,7 +1226,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
       dw_blk(D, sv::K1_X1, SEG_DEN1_X1, 0);
     }
   }
-  rc = dw_launch(D, stream);
+  rc = dw_launch(D, stream, "dw_dyn");
   return rc;
 }
 
@@ -1271,7 +1271,7 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
          nullptr, T);
   dw_blk(D, sv::SF_X, SEG_SF_X, 0);
   dw_blk(D, sv::SF_X + 32, SEG_SF_X, 32);
-  return dw_launch(D, stream);
+  return dw_launch(D, stream, "dw_sf");
 }
 
 // ------------------------------------------------------------------------------------------------
