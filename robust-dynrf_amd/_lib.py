@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librodynrf.so")
+LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf.so"))  # RDRF_LIB: A/B builds
 
 RAY_TYPES = {"ndc": 0, "contract": 1}
 ACTS = {"relu": 0, "softplus": 1}

@@ -14,6 +14,11 @@
 // References: autograd of /root/reference/models/tensorBase.py:704-850, models/tensoRF.py:118-196,
 // 446-462, 521-811 (grid_sample backward per SURVEY.md Appendix A).
 #include "rdrf_kernels.hpp"
+#ifdef RDRF_NO_BIAS_ATOMICS
+#define BIAS_ATOMIC(p, v) ((void)0)
+#else
+#define BIAS_ATOMIC(p, v) atomicAdd(p, v)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // backward LDS images (transposed packs + small layers), float offsets inside each region
@@ -106,11 +111,35 @@ RDRF_D void atomic_add4(float* p, f32x4 v) {
 }
 RDRF_D float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-template <int C0Q, int C1Q>
+// Segmented run reduction over the 32 lanes of a half-wave: lanes are consecutive samples of one
+// ray, so equal keys (same texel / line entry) form CONTIGUOUS runs.  After the inclusive segmented
+// scan the last lane of each run holds the run's sum and is the only one that issues the atomic:
+// fp32 L2 atomics sustain only ~10-20 G/s on MI355X and serialise on hot addresses, so combining
+// in registers first is worth ~5 DPP steps per value.
+RDRF_D f32x4 run_scan4(f32x4 v, int key, int s) {
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const int ok = __shfl_up(key, d, 32);
+    const float ox = __shfl_up(v.x, d, 32), oy = __shfl_up(v.y, d, 32);
+    const float oz = __shfl_up(v.z, d, 32), ow = __shfl_up(v.w, d, 32);
+    if (s >= d && ok == key) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }
+  }
+  return v;
+}
+RDRF_D bool run_tail(int key, int s) {
+  const int nk = __shfl_down(key, 1, 32);
+  return s == 31 || nk != key;
+}
+
+// MODE 0: every lane is an independent sample (compacted appearance tiles): plain atomics.
+// MODE 1: lanes of a half-wave walk one ray in order: run-reduce first.  ALL lanes of the wave
+//         must call (shuffles); `live` = this lane really has a gradient to scatter.
+template <int C0Q, int C1Q, int MODE>
 RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
-                            float x2, f32x4 dq, float& dx0, float& dx1, float& dx2) {
-  QuadSel<C0Q, C1Q> s = quad_sel<C0Q, C1Q>(g);
-  const int pi = s.pi;
+                            float x2, f32x4 dq, bool live, int s, float& dx0, float& dx1,
+                            float& dx2) {
+  QuadSel<C0Q, C1Q> sl = quad_sel<C0Q, C1Q>(g);
+  const int pi = sl.pi;
   const float cx = pi == 2 ? x1 : x0;
   const float cy = pi == 0 ? x1 : x2;
   const float cl = pi == 0 ? x2 : (pi == 1 ? x1 : x0);
@@ -121,32 +150,54 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   const int H = pi == 0 ? vm.H[0] : (pi == 1 ? vm.H[1] : vm.H[2]);
   const int W = pi == 0 ? vm.W[0] : (pi == 1 ? vm.W[1] : vm.W[2]);
   const int L = pi == 0 ? vm.L[0] : (pi == 1 ? vm.L[1] : vm.L[2]);
-  const int lv = s.level, st = 1 << lv;
+  const int lv = sl.level, st = 1 << lv;
   const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
   Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
-  const int C = s.C, qo = 4 * s.q;
+  const int C = sl.C, qo = 4 * sl.q;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const size_t o00 = (size_t)((ty.i0 << lv) * W + (tx.i0 << lv)) * C + qo;
   const size_t o01 = (size_t)((ty.i0 << lv) * W + ((tx.i0 + 1) << lv)) * C + qo;
   const size_t o10 = (size_t)(((ty.i0 + 1) << lv) * W + (tx.i0 << lv)) * C + qo;
   const size_t o11 = (size_t)(((ty.i0 + 1) << lv) * W + ((tx.i0 + 1) << lv)) * C + qo;
-  const bool k00 = ty.ok0 && tx.ok0, k01 = ty.ok0 && tx.ok1, k10 = ty.ok1 && tx.ok0,
-             k11 = ty.ok1 && tx.ok1;
+  const bool k00 = live && ty.ok0 && tx.ok0, k01 = live && ty.ok0 && tx.ok1,
+             k10 = live && ty.ok1 && tx.ok0, k11 = live && ty.ok1 && tx.ok1;
+  const bool m0 = live && tl.ok0, m1 = live && tl.ok1;
   const f32x4 v00 = k00 ? ld4(P + o00) : zero, v01 = k01 ? ld4(P + o01) : zero;
   const f32x4 v10 = k10 ? ld4(P + o10) : zero, v11 = k11 ? ld4(P + o11) : zero;
   const size_t l0 = (size_t)(tl.i0 << lv) * C + qo, l1 = (size_t)((tl.i0 + 1) << lv) * C + qo;
-  const f32x4 a0 = tl.ok0 ? ld4(Lp + l0) : zero, a1 = tl.ok1 ? ld4(Lp + l1) : zero;
+  const f32x4 a0 = m0 ? ld4(Lp + l0) : zero, a1 = m1 ? ld4(Lp + l1) : zero;
   const f32x4 pv = v00 * (tx.w0 * ty.w0) + v01 * (tx.w1 * ty.w0) + v10 * (tx.w0 * ty.w1) +
                    v11 * (tx.w1 * ty.w1);
   const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
-  const f32x4 dp = dq * lvv;  // grad wrt the interpolated plane quad
-  const f32x4 dl = dq * pv;   // grad wrt the interpolated line quad
-  if (k00) atomic_add4(GP + o00, dp * (tx.w0 * ty.w0));
-  if (k01) atomic_add4(GP + o01, dp * (tx.w1 * ty.w0));
-  if (k10) atomic_add4(GP + o10, dp * (tx.w0 * ty.w1));
-  if (k11) atomic_add4(GP + o11, dp * (tx.w1 * ty.w1));
-  if (tl.ok0) atomic_add4(GL + l0, dl * tl.w0);
-  if (tl.ok1) atomic_add4(GL + l1, dl * tl.w1);
+  const f32x4 dp = live ? dq * lvv : zero;  // grad wrt the interpolated plane quad
+  const f32x4 dl = live ? dq * pv : zero;   // grad wrt the interpolated line quad
+  if (MODE == 0) {
+    if (k00) atomic_add4(GP + o00, dp * (tx.w0 * ty.w0));
+    if (k01) atomic_add4(GP + o01, dp * (tx.w1 * ty.w0));
+    if (k10) atomic_add4(GP + o10, dp * (tx.w0 * ty.w1));
+    if (k11) atomic_add4(GP + o11, dp * (tx.w1 * ty.w1));
+    if (m0) atomic_add4(GL + l0, dl * tl.w0);
+    if (m1) atomic_add4(GL + l1, dl * tl.w1);
+  } else {
+    // the quad / plane selection is uniform over a half-wave, so the (iy, ix) pair keys the run
+    const int pkey = live ? ((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff) : -1 - s;
+    const bool ptail = run_tail(pkey, s);
+    f32x4 r;
+    r = run_scan4(k00 ? dp * (tx.w0 * ty.w0) : zero, pkey, s);
+    if (ptail && live && ty.ok0 && tx.ok0) atomic_add4(GP + o00, r);
+    r = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pkey, s);
+    if (ptail && live && ty.ok0 && tx.ok1) atomic_add4(GP + o01, r);
+    r = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pkey, s);
+    if (ptail && live && ty.ok1 && tx.ok0) atomic_add4(GP + o10, r);
+    r = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pkey, s);
+    if (ptail && live && ty.ok1 && tx.ok1) atomic_add4(GP + o11, r);
+    const int lkey = live ? tl.i0 + 4 : -1 - s;
+    const bool ltail = run_tail(lkey, s);
+    r = run_scan4(m0 ? dl * tl.w0 : zero, lkey, s);
+    if (ltail && m0) atomic_add4(GL + l0, r);
+    r = run_scan4(m1 ? dl * tl.w1 : zero, lkey, s);
+    if (ltail && m1) atomic_add4(GL + l1, r);
+  }
   // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
   const float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
   const float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
@@ -225,10 +276,10 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
       const float m = h == 0 ? dzv[o] : 0.f;
       const float sb = wave_sum(m), s0 = wave_sum(m * vx), s1 = wave_sum(m * vy), s2 = wave_sum(m * vz);
       if (lane == 0) {
-        atomicAdd(gw.rbv + o, sb);
-        atomicAdd(gw.rwv + o * 131 + 128, s0);
-        atomicAdd(gw.rwv + o * 131 + 129, s1);
-        atomicAdd(gw.rwv + o * 131 + 130, s2);
+        BIAS_ATOMIC(gw.rbv + o, sb);
+        BIAS_ATOMIC(gw.rwv + o * 131 + 128, s0);
+        BIAS_ATOMIC(gw.rwv + o * 131 + 129, s1);
+        BIAS_ATOMIC(gw.rwv + o * 131 + 130, s2);
       }
     }
     float dz2[64];
@@ -280,12 +331,12 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
       mfma_seg<7, 16>(acc, dF, lds + pkb::K3_BASIST, lane);
       const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
                   xw2 = a.sp.xw[(size_t)idx * 3 + 2];
-      if (act) {
+      {  // compaction keeps ray order, so neighbouring lanes still share texels: run-reduce
 #pragma unroll
         for (int o = 0; o < 27; ++o) {
           f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
                       acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, dw0, dw1, dw2);
+          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, act, s, dw0, dw1, dw2);
         }
       }
     }
@@ -330,13 +381,13 @@ __global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, St
       if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
       const float m = h == 0 ? dzv[o] : 0.f;
       const float sb = wave_sum(m);
-      if (lane == 0) atomicAdd(gw.b3 + o, sb);
+      if (lane == 0) BIAS_ATOMIC(gw.b3 + o, sb);
       if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING) {
         const float s0 = wave_sum(m * vx), s1 = wave_sum(m * vy), s2 = wave_sum(m * vz);
         if (lane == 0) {
-          atomicAdd(gw.w3 + o * 131 + 128, s0);
-          atomicAdd(gw.w3 + o * 131 + 129, s1);
-          atomicAdd(gw.w3 + o * 131 + 130, s2);
+          BIAS_ATOMIC(gw.w3 + o * 131 + 128, s0);
+          BIAS_ATOMIC(gw.w3 + o * 131 + 129, s1);
+          BIAS_ATOMIC(gw.w3 + o * 131 + 130, s2);
         }
       }
     }
@@ -393,12 +444,12 @@ __global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, St
       const float x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
       const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
       const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
-      if (act) {
+      {
 #pragma unroll
         for (int o = 0; o < 9; ++o) {
           f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
                       acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3>(w.app, gw.app, 2 * o + h, x0, x1, x2, dq, dw0, dw1, dw2);
+          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, x0, x1, x2, dq, act, s, dw0, dw1, dw2);
         }
       }
     }
@@ -480,15 +531,17 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
     float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
     g_sigma += g_alpha * ds * (1.0f - alpha);
     const float gf = vld ? g_sigma * act_grad(f, a.act, a.density_shift) : 0.f;
-    if (vld && gf != 0.f) {
+    {
+      const bool live = vld && gf != 0.f;
       const float x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
       const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
       const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
       float d0 = 0.f, d1 = 0.f, d2 = 0.f;
       const f32x4 dq = {gf, gf, gf, gf};
 #pragma unroll
-      for (int g = 0; g < 6; ++g) gather_quad_bwd<4, 1>(w.density, gw.density, g, x0, x1, x2, dq, d0, d1, d2);
-      if (a.g_xyz) {
+      for (int g = 0; g < 6; ++g)
+        gather_quad_bwd<4, 1, 1>(w.density, gw.density, g, x0, x1, x2, dq, live, lane & 31, d0, d1, d2);
+      if (live && a.g_xyz) {
         atomicAdd(a.g_xyz + (size_t)idx * 3 + 0, d0 * a.box.inv[0]);
         atomicAdd(a.g_xyz + (size_t)idx * 3 + 1, d1 * a.box.inv[1]);
         atomicAdd(a.g_xyz + (size_t)idx * 3 + 2, d2 * a.box.inv[2]);
@@ -594,15 +647,15 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         acc_zero<3>(accF);
         mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1_DEN1T_F : pkb::K1_BLE1T_F), lane);
         mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1_DEN1T_X0 : pkb::K1_BLE1T_X0), lane);
-        if (vld) {
+        {
 #pragma unroll
           for (int o = 0; o < 9; ++o) {
             f32x4 dq = {accF[o >> 2][(o & 3) * 4 + 0], accF[o >> 2][(o & 3) * 4 + 1],
                         accF[o >> 2][(o & 3) * 4 + 2], accF[o >> 2][(o & 3) * 4 + 3]};
             if (head == 0)
-              gather_quad_bwd<4, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, dw0, dw1, dw2);
+              gather_quad_bwd<4, 1, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2);
             else
-              gather_quad_bwd<4, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, dw0, dw1, dw2);
+              gather_quad_bwd<4, 1, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2);
           }
         }
       }
@@ -628,8 +681,8 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         const float r0 = wave_sum(m0), r1 = wave_sum(m1), r2 = wave_sum(m2), r3 = wave_sum(m3),
                     r4 = wave_sum(m4);
         if (lane == 0) {
-          atomicAdd(gw.l5b + 0, r0); atomicAdd(gw.l5b + 1, r1); atomicAdd(gw.l5b + 2, r2);
-          atomicAdd(gw.db2, r3); atomicAdd(gw.bb2, r4);
+          BIAS_ATOMIC(gw.l5b + 0, r0); BIAS_ATOMIC(gw.l5b + 1, r1); BIAS_ATOMIC(gw.l5b + 2, r2);
+          BIAS_ATOMIC(gw.db2, r3); BIAS_ATOMIC(gw.bb2, r4);
         }
       }
       // ---- warp MLP backward: layer5 (VALU) -> layer4 -> layer3
@@ -802,7 +855,7 @@ __global__ __launch_bounds__(512) void k_scene_flow_bwd(int N, int S, Box box,
       dz6[o] = (act && gsrc) ? gsrc[(size_t)idx * 3 + (o % 3)] : 0.f;
       if (h == 0) gb[(size_t)(sv::SFG_DZ6 + o) * 32 + s] = dz6[o];
       const float r = wave_sum(h == 0 ? dz6[o] : 0.f);
-      if (lane == 0) atomicAdd(g_sfb6 + o, r);
+      if (lane == 0) BIAS_ATOMIC(g_sfb6 + o, r);
     }
     float dz[32], Hh[32];
     load_rows<32>(svb, sv::SF_H4, Hh, s, h);
