@@ -116,20 +116,30 @@ RDRF_D float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z +
 // scan the last lane of each run holds the run's sum and is the only one that issues the atomic:
 // fp32 L2 atomics sustain only ~10-20 G/s on MI355X and serialise on hot addresses, so combining
 // in registers first is worth ~5 DPP steps per value.
-RDRF_D f32x4 run_scan4(f32x4 v, int key, int s) {
+struct Run {
+  int start;   // first lane (0..31) of the maximal contiguous equal-key stretch this lane is in
+  bool tail;   // this lane is the last of its run
+};
+RDRF_D Run run_of(int key, int s) {
+  const int prev = __shfl_up(key, 1, 32);
+  const bool head = (s == 0) || (prev != key);
+  const unsigned long long b = __ballot(head);
+  const unsigned m = (unsigned)(b >> (32 * ((threadIdx.x & 63) >> 5)));
+  Run r;
+  r.start = 31 - __clz((int)(m & (0xffffffffu >> (31 - s))));
+  r.tail = (s == 31) || ((m >> (s + 1)) & 1u);
+  return r;
+}
+RDRF_D f32x4 run_scan4(f32x4 v, int start, int s) {
 #pragma unroll
   for (int d = 1; d < 32; d <<= 1) {
-    const int ok = __shfl_up(key, d, 32);
     const float ox = __shfl_up(v.x, d, 32), oy = __shfl_up(v.y, d, 32);
     const float oz = __shfl_up(v.z, d, 32), ow = __shfl_up(v.w, d, 32);
-    if (s >= d && ok == key) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }
+    if (s - d >= start) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }
   }
   return v;
 }
-RDRF_D bool run_tail(int key, int s) {
-  const int nk = __shfl_down(key, 1, 32);
-  return s == 31 || nk != key;
-}
+RDRF_D bool nz4(f32x4 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f; }
 
 // MODE 0: every lane is an independent sample (compacted appearance tiles): plain atomics.
 // MODE 1: lanes of a half-wave walk one ray in order: run-reduce first.  ALL lanes of the wave
@@ -179,24 +189,26 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     if (m0) atomic_add4(GL + l0, dl * tl.w0);
     if (m1) atomic_add4(GL + l1, dl * tl.w1);
   } else {
-    // the quad / plane selection is uniform over a half-wave, so the (iy, ix) pair keys the run
-    const int pkey = live ? ((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff) : -1 - s;
-    const bool ptail = run_tail(pkey, s);
+    // the quad / plane selection is uniform over a half-wave, so the (iy, ix) pair keys the run.
+    // Keys are purely geometric (a dead sample inside a run contributes zeros, it must not split
+    // the run); the run's last lane issues the atomics whatever its own liveness.
+    const bool g00 = ty.ok0 && tx.ok0, g01 = ty.ok0 && tx.ok1, g10 = ty.ok1 && tx.ok0,
+               g11 = ty.ok1 && tx.ok1;
+    const Run pr = run_of(((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff), s);
     f32x4 r;
-    r = run_scan4(k00 ? dp * (tx.w0 * ty.w0) : zero, pkey, s);
-    if (ptail && live && ty.ok0 && tx.ok0) atomic_add4(GP + o00, r);
-    r = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pkey, s);
-    if (ptail && live && ty.ok0 && tx.ok1) atomic_add4(GP + o01, r);
-    r = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pkey, s);
-    if (ptail && live && ty.ok1 && tx.ok0) atomic_add4(GP + o10, r);
-    r = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pkey, s);
-    if (ptail && live && ty.ok1 && tx.ok1) atomic_add4(GP + o11, r);
-    const int lkey = live ? tl.i0 + 4 : -1 - s;
-    const bool ltail = run_tail(lkey, s);
-    r = run_scan4(m0 ? dl * tl.w0 : zero, lkey, s);
-    if (ltail && m0) atomic_add4(GL + l0, r);
-    r = run_scan4(m1 ? dl * tl.w1 : zero, lkey, s);
-    if (ltail && m1) atomic_add4(GL + l1, r);
+    r = run_scan4(k00 ? dp * (tx.w0 * ty.w0) : zero, pr.start, s);
+    if (pr.tail && g00 && nz4(r)) atomic_add4(GP + o00, r);
+    r = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pr.start, s);
+    if (pr.tail && g01 && nz4(r)) atomic_add4(GP + o01, r);
+    r = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pr.start, s);
+    if (pr.tail && g10 && nz4(r)) atomic_add4(GP + o10, r);
+    r = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s);
+    if (pr.tail && g11 && nz4(r)) atomic_add4(GP + o11, r);
+    const Run lr = run_of(tl.i0 + 4, s);
+    r = run_scan4(m0 ? dl * tl.w0 : zero, lr.start, s);
+    if (lr.tail && tl.ok0 && nz4(r)) atomic_add4(GL + l0, r);
+    r = run_scan4(m1 ? dl * tl.w1 : zero, lr.start, s);
+    if (lr.tail && tl.ok1 && nz4(r)) atomic_add4(GL + l1, r);
   }
   // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
   const float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
