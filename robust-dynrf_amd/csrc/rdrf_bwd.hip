@@ -66,6 +66,9 @@ static_assert(K1_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE 
 // ------------------------------------------------------------------------------------------------
 // argument block of the backward kernels
 // ------------------------------------------------------------------------------------------------
+#define K1_LINES_MAX 8192   /* floats: 124 KB weight image + 1 KB carries + 32 KB lines < 160 KB */
+#define K3_LINES_MAX 11264  /* floats: 117 KB weight image (basis^T read from L2) + 44 KB lines */
+
 struct BwdArgs {
   const float* rays;
   const float* ts;
@@ -144,10 +147,43 @@ RDRF_D bool nz4(f32x4 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w 
 // MODE 0: every lane is an independent sample (compacted appearance tiles): plain atomics.
 // MODE 1: lanes of a half-wave walk one ray in order: run-reduce first.  ALL lanes of the wave
 //         must call (shuffles); `live` = this lane really has a gradient to scatter.
+// Line gradients are tiny tensors hammered by every sample (the z line has no runs along a ray), so
+// when they fit they are accumulated in LDS (ds_add_f32) by the whole workgroup and flushed to
+// global memory once per block: `ll` = LDS accumulator of this factor set or nullptr.
+struct LdsLines {
+  float* base;   // LDS accumulator (nullptr: scatter straight to global memory)
+  int off[3];    // float offset of line 0/1/2 inside it
+};
+RDRF_D void lds_add4(float* p, f32x4 v) {
+  atomicAdd(p + 0, v.x);
+  atomicAdd(p + 1, v.y);
+  atomicAdd(p + 2, v.z);
+  atomicAdd(p + 3, v.w);
+}
+RDRF_D int lines_floats(const RdrfVM& vm) { return vm.L[0] * vm.C[0] + vm.L[1] * vm.C[1] + vm.L[2] * vm.C[2]; }
+RDRF_D LdsLines make_lds_lines(float* base, const RdrfVM& vm) {
+  LdsLines l;
+  l.base = base;
+  l.off[0] = 0;
+  l.off[1] = vm.L[0] * vm.C[0];
+  l.off[2] = l.off[1] + vm.L[1] * vm.C[1];
+  return l;
+}
+RDRF_D void flush_lds_lines(const float* acc, const RdrfVM& vm, const RdrfVM& gvm) {
+  const int n0 = vm.L[0] * vm.C[0], n1 = vm.L[1] * vm.C[1], n2 = vm.L[2] * vm.C[2];
+  for (int i = threadIdx.x; i < n0 + n1 + n2; i += blockDim.x) {
+    const float v = acc[i];
+    if (v != 0.f) {
+      float* dst = i < n0 ? gvm.line[0] + i : (i < n0 + n1 ? gvm.line[1] + (i - n0) : gvm.line[2] + (i - n0 - n1));
+      atomicAdd(dst, v);
+    }
+  }
+}
+
 template <int C0Q, int C1Q, int MODE>
 RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
                             float x2, f32x4 dq, bool live, int s, float& dx0, float& dx1,
-                            float& dx2) {
+                            float& dx2, const LdsLines ll = LdsLines{nullptr, {0, 0, 0}}) {
   QuadSel<C0Q, C1Q> sl = quad_sel<C0Q, C1Q>(g);
   const int pi = sl.pi;
   const float cx = pi == 2 ? x1 : x0;
@@ -205,10 +241,15 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     r = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s);
     if (pr.tail && g11 && nz4(r)) atomic_add4(GP + o11, r);
     const Run lr = run_of(tl.i0 + 4, s);
+    float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
     r = run_scan4(m0 ? dl * tl.w0 : zero, lr.start, s);
-    if (lr.tail && tl.ok0 && nz4(r)) atomic_add4(GL + l0, r);
+    if (lr.tail && tl.ok0 && nz4(r)) {
+      if (LL) lds_add4(LL + l0, r); else atomic_add4(GL + l0, r);
+    }
     r = run_scan4(m1 ? dl * tl.w1 : zero, lr.start, s);
-    if (lr.tail && tl.ok1 && nz4(r)) atomic_add4(GL + l1, r);
+    if (lr.tail && tl.ok1 && nz4(r)) {
+      if (LL) lds_add4(LL + l1, r); else atomic_add4(GL + l1, r);
+    }
   }
   // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
   const float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
@@ -257,8 +298,16 @@ RDRF_D void acc_zero(f32x16 (&acc)[NB]) {
 // appearance phase backward-data (dynamic: MLP_Fea_late_view; static: MLP_Fea | TimeEmbedding)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
-  __shared__ __attribute__((aligned(16))) float lds[pkb::K3_SIZE];
-  lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_SIZE);
+  // the basis^T pack (used once per tile) stays in L2; its LDS space holds the line accumulators
+  __shared__ __attribute__((aligned(16))) float lds[pkb::K3_BASIST];
+  __shared__ float lacc[K3_LINES_MAX];
+  const int nla = lines_floats(w.app);
+  const bool use_lacc = nla <= K3_LINES_MAX;
+  if (use_lacc)
+    for (int i = threadIdx.x; i < nla; i += blockDim.x) lacc[i] = 0.f;
+  const LdsLines lla = make_lds_lines(use_lacc ? lacc : nullptr, w.app);
+  lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_BASIST);
+  const float* basisT = a.pk + pkb::REG_K3 + pkb::K3_BASIST;
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int count = a.sp.hdr->count;
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
     {
       f32x16 acc[7];
       acc_zero<7>(acc);
-      mfma_seg<7, 16>(acc, dF, lds + pkb::K3_BASIST, lane);
+      mfma_seg<7, 16>(acc, dF, basisT, lane);
       const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
                   xw2 = a.sp.xw[(size_t)idx * 3 + 2];
       {  // compaction keeps ray order, so neighbouring lanes still share texels: run-reduce
@@ -348,7 +397,7 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
         for (int o = 0; o < 27; ++o) {
           f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
                       acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, act, s, dw0, dw1, dw2);
+          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, act, s, dw0, dw1, dw2, lla);
         }
       }
     }
@@ -359,6 +408,10 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
       a.dxn_app[(size_t)idx * 3 + 0] = dn0; a.dxn_app[(size_t)idx * 3 + 1] = dn1;
       a.dxn_app[(size_t)idx * 3 + 2] = dn2;
     }
+  }
+  if (use_lacc) {
+    __syncthreads();
+    flush_lds_lines(lacc, w.app, gw.app);
   }
 }
 
@@ -568,6 +621,13 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
 __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::K1_SIZE];
   __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
+  __shared__ float lacc[K1_LINES_MAX];  // line-gradient accumulators (density | blending)
+  const int nld = lines_floats(w.density);
+  const bool use_lacc = 2 * nld <= K1_LINES_MAX;
+  if (use_lacc)
+    for (int i = threadIdx.x; i < 2 * nld; i += blockDim.x) lacc[i] = 0.f;
+  const LdsLines lld = make_lds_lines(use_lacc ? lacc : nullptr, w.density);
+  const LdsLines llb = make_lds_lines(use_lacc ? lacc + nld : nullptr, w.blending);
   lds_fill(lds, a.pk + pkb::REG_K1, pkb::K1_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -665,9 +725,9 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
             f32x4 dq = {accF[o >> 2][(o & 3) * 4 + 0], accF[o >> 2][(o & 3) * 4 + 1],
                         accF[o >> 2][(o & 3) * 4 + 2], accF[o >> 2][(o & 3) * 4 + 3]};
             if (head == 0)
-              gather_quad_bwd<4, 1, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2);
+              gather_quad_bwd<4, 1, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2, lld);
             else
-              gather_quad_bwd<4, 1, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2);
+              gather_quad_bwd<4, 1, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2, llb);
           }
         }
       }
@@ -754,6 +814,11 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
       for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
       if (s == 0) a.dtout[(size_t)n * 32 + elem_of(i, h)] = v;
     }
+  }
+  if (use_lacc) {
+    __syncthreads();
+    flush_lds_lines(lacc, w.density, gw.density);
+    flush_lds_lines(lacc + nld, w.blending, gw.blending);
   }
 }
 
