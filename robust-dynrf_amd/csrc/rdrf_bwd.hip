@@ -333,15 +333,6 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
       const float g = (act && a.g_rgb) ? a.g_rgb[(size_t)idx * 3 + o] : 0.f;
       dzv[o] = g * r * (1.0f - r);
       if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
-      // view-direction columns and bias of the output layer (tiny: wave reduce + one atomic)
-      const float m = h == 0 ? dzv[o] : 0.f;
-      const float sb = wave_sum(m), s0 = wave_sum(m * vx), s1 = wave_sum(m * vy), s2 = wave_sum(m * vz);
-      if (lane == 0) {
-        BIAS_ATOMIC(gw.rbv + o, sb);
-        BIAS_ATOMIC(gw.rwv + o * 131 + 128, s0);
-        BIAS_ATOMIC(gw.rwv + o * 131 + 129, s1);
-        BIAS_ATOMIC(gw.rwv + o * 131 + 130, s2);
-      }
     }
     float dz2[64];
 #pragma unroll
@@ -444,17 +435,6 @@ __global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, St
       const float g = (act && a.g_rgb) ? a.g_rgb[(size_t)idx * 3 + o] : 0.f;
       dzv[o] = g * r * (1.0f - r);
       if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
-      const float m = h == 0 ? dzv[o] : 0.f;
-      const float sb = wave_sum(m);
-      if (lane == 0) BIAS_ATOMIC(gw.b3 + o, sb);
-      if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING) {
-        const float s0 = wave_sum(m * vx), s1 = wave_sum(m * vy), s2 = wave_sum(m * vz);
-        if (lane == 0) {
-          BIAS_ATOMIC(gw.w3 + o * 131 + 128, s0);
-          BIAS_ATOMIC(gw.w3 + o * 131 + 129, s1);
-          BIAS_ATOMIC(gw.w3 + o * 131 + 130, s2);
-        }
-      }
     }
     float dz2[64];
 #pragma unroll
@@ -747,16 +727,6 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         gb[(size_t)(sv::K1G_SM + 2) * 32 + s] = dd2; gb[(size_t)(sv::K1G_SM + 3) * 32 + s] = g_fd;
         gb[(size_t)(sv::K1G_SM + 4) * 32 + s] = g_fb;
       }
-      {  // biases of the small layers
-        const float m0 = h == 0 ? dd0 : 0.f, m1 = h == 0 ? dd1 : 0.f, m2 = h == 0 ? dd2 : 0.f;
-        const float m3 = h == 0 ? g_fd : 0.f, m4 = h == 0 ? g_fb : 0.f;
-        const float r0 = wave_sum(m0), r1 = wave_sum(m1), r2 = wave_sum(m2), r3 = wave_sum(m3),
-                    r4 = wave_sum(m4);
-        if (lane == 0) {
-          BIAS_ATOMIC(gw.l5b + 0, r0); BIAS_ATOMIC(gw.l5b + 1, r1); BIAS_ATOMIC(gw.l5b + 2, r2);
-          BIAS_ATOMIC(gw.db2, r3); BIAS_ATOMIC(gw.bb2, r4);
-        }
-      }
       // ---- warp MLP backward: layer5 (VALU) -> layer4 -> layer3
       float dz4[32];
       {
@@ -931,8 +901,6 @@ __global__ __launch_bounds__(512) void k_scene_flow_bwd(int N, int S, Box box,
       const float* gsrc = o < 3 ? g_f : g_b;
       dz6[o] = (act && gsrc) ? gsrc[(size_t)idx * 3 + (o % 3)] : 0.f;
       if (h == 0) gb[(size_t)(sv::SFG_DZ6 + o) * 32 + s] = dz6[o];
-      const float r = wave_sum(h == 0 ? dz6[o] : 0.f);
-      if (lane == 0) BIAS_ATOMIC(g_sfb6 + o, r);
     }
     float dz[32], Hh[32];
     load_rows<32>(svb, sv::SF_H4, Hh, s, h);
@@ -1238,8 +1206,9 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     DwJobs D;
     D.n = 0;
     dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZV, 1, 3, 0, a.sp.act3, sv::S3_ROWS, 128,
-           fea ? 128 : 131, G->w3, nullptr, cnt, 0);
+           fea ? 128 : 131, G->w3, G->b3, cnt, 0);
     for (int i = 0; i < 4; ++i) dw_blk(D, sv::S3_H2 + 32 * i, SEG_IDENT, 32 * i);
+    if (!fea) dw_blk(D, sv::S3_VD, SEG_VIEW3, 0);
     dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZ2, 4, 128, 0, a.sp.act3, sv::S3_ROWS, 128, 128, G->w2,
            G->b2, cnt, 0);
     for (int i = 0; i < 4; ++i) dw_blk(D, sv::S3_H1 + 32 * i, SEG_IDENT, 32 * i);
@@ -1300,8 +1269,9 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
     const Geo g = geo_for_units((long)t3);
     RDRF_LAUNCH("dyn_app_bwd", k_dyn_app_bwd, dim3(g.grid), dim3(g.block), stream, a, w, gw);
     dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZV, 1, 3, 0, a.sp.act3, sv::K3_ROWS, 128, 131, G->rwv,
-           nullptr, cnt, 0);
+           G->rbv, cnt, 0);
     for (int i = 0; i < 4; ++i) dw_blk(D, sv::K3_H2 + 32 * i, SEG_IDENT, 32 * i);
+    dw_blk(D, sv::K3_VD, SEG_VIEW3, 0);
     dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZ2, 4, 128, 0, a.sp.act3, sv::K3_ROWS, 128, 128, G->rw2,
            G->rb2, cnt, 0);
     for (int i = 0; i < 4; ++i) dw_blk(D, sv::K3_H1 + 32 * i, SEG_IDENT, 32 * i);
@@ -1333,15 +1303,15 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
     dw_blk(D, sv::K1_H3 + 32, SEG_IDENT, 32);
     // small layers share one dz block: rows 0..2 -> layer5, row 3 -> density_layer2, row 4 -> blending_layer2
     dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 3, 0, a.sp.act1, sv::K1_ROWS, 64, 64, G->l5w,
-           nullptr, nullptr, T1);
+           G->l5b, nullptr, T1);
     dw_blk(D, sv::K1_H4, SEG_IDENT, 0);
     dw_blk(D, sv::K1_H4 + 32, SEG_IDENT, 32);
     dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 3, a.sp.act1, sv::K1_ROWS, 64, 64, G->dw2,
-           nullptr, nullptr, T1);
+           G->db2, nullptr, T1);
     dw_blk(D, sv::K1_HD, SEG_IDENT, 0);
     dw_blk(D, sv::K1_HD + 32, SEG_IDENT, 32);
     dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, a.sp.act1, sv::K1_ROWS, 64, 64, G->bw2,
-           nullptr, nullptr, T1);
+           G->bb2, nullptr, T1);
     dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
     dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
     for (int head = 0; head < 2; ++head) {
@@ -1385,7 +1355,7 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
   const int T = (int)tiles;
   DwJobs D;
   D.n = 0;
-  dw_add(D, grows, sv::SFG_ROWS, sv::SFG_DZ6, 1, 6, 0, act, sv::SF_ROWS, 64, 64, G->sfw[3], nullptr,
+  dw_add(D, grows, sv::SFG_ROWS, sv::SFG_DZ6, 1, 6, 0, act, sv::SF_ROWS, 64, 64, G->sfw[3], G->sfb[3],
          nullptr, T);
   dw_blk(D, sv::SF_H4, SEG_IDENT, 0);
   dw_blk(D, sv::SF_H4 + 32, SEG_IDENT, 32);

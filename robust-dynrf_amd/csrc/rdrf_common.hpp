@@ -50,6 +50,7 @@ enum SegId {
   SEG_STAT1_P_TE,
   SEG_SF_X,          // scene flow layer0 (64,36): [xn3, sin12, cos12, t, sin4, cos4]
   SEG_IDENT72,       // the 72 VM features of density/blending layer1 (cols 0..71)
+  SEG_VIEW3,         // view-direction columns 128..130 of a (3,131) output layer
   SEG_COUNT
 };
 
@@ -66,6 +67,7 @@ RDRF_HD int seg_imap(int seg, int e, int in_dim) {
   switch (seg) {
     case SEG_IDENT: return e < in_dim ? e : -1;
     case SEG_IDENT72: return e < 72 ? e : -1;
+    case SEG_VIEW3: return e < 3 ? 128 + e : -1;
     case SEG_WARP3_X0: return e < 64 ? x0_col(e, 0, 3, 33, -1) : -1;
     case SEG_WARP3_T: return e < 30 ? 63 + e : -1;
     case SEG_DEN1_X0: return e < 64 ? x0_col(e, 72, 75, 105, 135) : -1;

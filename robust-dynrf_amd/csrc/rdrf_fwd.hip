@@ -118,6 +118,10 @@ __global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
       if (h == 0) F[15] = vx;
       else { F[12] = vy; F[13] = vz; }
     }
+    if (svb != nullptr && h == 0) {
+      svb[(size_t)(sv::S3_VD + 0) * 32 + s] = vx; svb[(size_t)(sv::S3_VD + 1) * 32 + s] = vy;
+      svb[(size_t)(sv::S3_VD + 2) * 32 + s] = vz;
+    }
     save_rows<36>(svb, sv::S3_G, G, s, h);
     save_rows<16>(svb, sv::S3_F, F, s, h);
     save_rows<64>(svb, sv::S3_P, P, s, h);
@@ -352,6 +356,10 @@ __global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
     float X0[32], X1[8];
     fill_x0(X0, xn0, xn1, xn2, t, h);
     fill_x1(X1, t, h);
+    if (svb != nullptr && h == 0) {
+      svb[(size_t)(sv::K3_VD + 0) * 32 + s] = vx; svb[(size_t)(sv::K3_VD + 1) * 32 + s] = vy;
+      svb[(size_t)(sv::K3_VD + 2) * 32 + s] = vz;
+    }
     save_rows<16>(svb, sv::K3_F, F, s, h);
     save_rows<32>(svb, sv::K3_X0, X0, s, h);
     save_rows<8>(svb, sv::K3_X1, X1, s, h);

@@ -71,9 +71,10 @@ namespace sv {
 constexpr int K1_X0 = 0, K1_X1 = 64, K1_T = 96, K1_H3 = 128, K1_H4 = 192, K1_FD = 256, K1_HD = 352,
               K1_FB = 416, K1_HB = 512, K1_ROWS = 576;
 // dynamic appearance phase (compacted tiles)
-constexpr int K3_A = 0, K3_F = 224, K3_X0 = 256, K3_X1 = 320, K3_H1 = 352, K3_H2 = 480, K3_ROWS = 608;
+constexpr int K3_A = 0, K3_F = 224, K3_X0 = 256, K3_X1 = 320, K3_H1 = 352, K3_H2 = 480, K3_VD = 608,
+              K3_ROWS = 640;
 // static appearance phase
-constexpr int S3_G = 0, S3_F = 96, S3_P = 128, S3_H1 = 256, S3_H2 = 384, S3_ROWS = 512;
+constexpr int S3_G = 0, S3_F = 96, S3_P = 128, S3_H1 = 256, S3_H2 = 384, S3_VD = 512, S3_ROWS = 544;
 // scene flow
 constexpr int SF_X = 0, SF_H0 = 64, SF_H2 = 128, SF_H4 = 192, SF_ROWS = 256;
 // gradient rows written by the backward-data kernels (workspace, same layout)
