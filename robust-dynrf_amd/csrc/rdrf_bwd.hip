@@ -106,11 +106,29 @@ struct DynG {
 // ------------------------------------------------------------------------------------------------
 // VM gather backward for one quad: scatter into plane / line (atomics) + coordinate gradients
 // ------------------------------------------------------------------------------------------------
-RDRF_D void atomic_add4(float* p, f32x4 v) {
-  atomicAdd(p + 0, v.x);
-  atomicAdd(p + 1, v.y);
-  atomicAdd(p + 2, v.z);
-  atomicAdd(p + 3, v.w);
+// fp32 atomics on MI355X: the L2 retires ~20 G atomic REQUESTS/s, where a request is one
+// (instruction, <=64-byte line) pair -- not one lane (tools/ubench/atomics.hip: one component per
+// lane per instruction 20 G updates/s; 4 adjacent lanes covering a 16-byte quad 83 G/s; 16 lanes on
+// a 64-byte texel 322 G/s).  So a quad is never sent as 4 instructions x 1 component: the wave
+// transposes through the lane crossbar so that lanes 4t..4t+3 carry components 0..3 of source lane
+// t's quad, and 4 instructions then cover all 64 lanes' quads with one request per quad.
+// Must be called by ALL lanes of the wave (uniform control flow); `ok` gates the lane's quad.
+RDRF_D void atomic_add4(float* p, f32x4 v, bool ok) {
+  const unsigned long long any = __ballot(ok);
+  if (any == 0ull) return;
+  const int lane = threadIdx.x & 63, c = lane & 3;
+  const unsigned long long pa = (unsigned long long)p;
+  const unsigned plo = (unsigned)pa, phi = (unsigned)(pa >> 32);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (((any >> (16 * k)) & 0xffffull) == 0ull) continue;  // no live quad in these 16 lanes
+    const int src = 16 * k + (lane >> 2);
+    const float a0 = __shfl(v.x, src, 64), a1 = __shfl(v.y, src, 64);
+    const float a2 = __shfl(v.z, src, 64), a3 = __shfl(v.w, src, 64);
+    const unsigned lo = __shfl(plo, src, 64), hi = __shfl(phi, src, 64);
+    const float val = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+    if ((any >> src) & 1ull) atomicAdd((float*)(((unsigned long long)hi << 32) | lo) + c, val);
+  }
 }
 RDRF_D float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -218,12 +236,12 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   const f32x4 dp = live ? dq * lvv : zero;  // grad wrt the interpolated plane quad
   const f32x4 dl = live ? dq * pv : zero;   // grad wrt the interpolated line quad
   if (MODE == 0) {
-    if (k00) atomic_add4(GP + o00, dp * (tx.w0 * ty.w0));
-    if (k01) atomic_add4(GP + o01, dp * (tx.w1 * ty.w0));
-    if (k10) atomic_add4(GP + o10, dp * (tx.w0 * ty.w1));
-    if (k11) atomic_add4(GP + o11, dp * (tx.w1 * ty.w1));
-    if (m0) atomic_add4(GL + l0, dl * tl.w0);
-    if (m1) atomic_add4(GL + l1, dl * tl.w1);
+    atomic_add4(GP + o00, dp * (tx.w0 * ty.w0), k00);
+    atomic_add4(GP + o01, dp * (tx.w1 * ty.w0), k01);
+    atomic_add4(GP + o10, dp * (tx.w0 * ty.w1), k10);
+    atomic_add4(GP + o11, dp * (tx.w1 * ty.w1), k11);
+    atomic_add4(GL + l0, dl * tl.w0, m0);
+    atomic_add4(GL + l1, dl * tl.w1, m1);
   } else {
     // the quad / plane selection is uniform over a half-wave, so the (iy, ix) pair keys the run.
     // Keys are purely geometric (a dead sample inside a run contributes zeros, it must not split
@@ -233,22 +251,24 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     const Run pr = run_of(((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff), s);
     f32x4 r;
     r = run_scan4(k00 ? dp * (tx.w0 * ty.w0) : zero, pr.start, s);
-    if (pr.tail && g00 && nz4(r)) atomic_add4(GP + o00, r);
+    atomic_add4(GP + o00, r, pr.tail && g00 && nz4(r));
     r = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pr.start, s);
-    if (pr.tail && g01 && nz4(r)) atomic_add4(GP + o01, r);
+    atomic_add4(GP + o01, r, pr.tail && g01 && nz4(r));
     r = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pr.start, s);
-    if (pr.tail && g10 && nz4(r)) atomic_add4(GP + o10, r);
+    atomic_add4(GP + o10, r, pr.tail && g10 && nz4(r));
     r = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s);
-    if (pr.tail && g11 && nz4(r)) atomic_add4(GP + o11, r);
+    atomic_add4(GP + o11, r, pr.tail && g11 && nz4(r));
     const Run lr = run_of(tl.i0 + 4, s);
     float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
     r = run_scan4(m0 ? dl * tl.w0 : zero, lr.start, s);
-    if (lr.tail && tl.ok0 && nz4(r)) {
-      if (LL) lds_add4(LL + l0, r); else atomic_add4(GL + l0, r);
+    {
+      const bool okl = lr.tail && tl.ok0 && nz4(r);
+      if (LL) { if (okl) lds_add4(LL + l0, r); } else atomic_add4(GL + l0, r, okl);
     }
     r = run_scan4(m1 ? dl * tl.w1 : zero, lr.start, s);
-    if (lr.tail && tl.ok1 && nz4(r)) {
-      if (LL) lds_add4(LL + l1, r); else atomic_add4(GL + l1, r);
+    {
+      const bool okl = lr.tail && tl.ok1 && nz4(r);
+      if (LL) { if (okl) lds_add4(LL + l1, r); } else atomic_add4(GL + l1, r, okl);
     }
   }
   // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
