@@ -92,6 +92,7 @@ struct BwdArgs {
   float* dtout;    // [N*32]
   // outputs
   float* g_xyz;
+  float* g_rays;   // [N][6] (+=): through dists (ray norm) and the static head's view directions
 };
 
 struct StaticG {
@@ -495,10 +496,33 @@ __global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, St
         dF[r] += d0 * P[4 * r + 1] - d1 * P[4 * r + 0] + 2.0f * (d2 * P[4 * r + 3] - d3 * P[4 * r + 2]);
       }
     }
-    // the view-direction slots (27..29) of the feature block are not features
-    if (HEAD == RDRF_HEAD_MLP_FEA) {
-      if (h == 0) dF[15] = 0.f;
-      else { dF[12] = 0.f; dF[13] = 0.f; }
+    // the view-direction slots (27..29) of the feature block are not features: they carry
+    // d(loss)/d(viewdir); viewdir = d/|d|  =>  g_d = (g_v - (g_v.v) v) / |d|
+    {
+      float gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
+      if (HEAD == RDRF_HEAD_MLP_FEA) {
+        if (h == 0) { gv0 = dF[15]; dF[15] = 0.f; }
+        else { gv1 = dF[12]; gv2 = dF[13]; dF[12] = 0.f; dF[13] = 0.f; }
+        gv0 += __shfl_xor(gv0, 32, 64); gv1 += __shfl_xor(gv1, 32, 64); gv2 += __shfl_xor(gv2, 32, 64);
+      } else {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+          gv0 += w.w3[o * 131 + 128] * dzv[o]; gv1 += w.w3[o * 131 + 129] * dzv[o];
+          gv2 += w.w3[o * 131 + 130] * dzv[o];
+        }
+      }
+      if (a.g_rays && act && h == 0 && a.ray_type != RDRF_RAY_OTHER) {
+        const float rx = a.rays[(size_t)n * 6 + 3], ry = a.rays[(size_t)n * 6 + 4], rz = a.rays[(size_t)n * 6 + 5];
+        const float nr = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float dotv = gv0 * vx + gv1 * vy + gv2 * vz;
+        atomicAdd(a.g_rays + (size_t)n * 6 + 3, (gv0 - dotv * vx) / nr);
+        atomicAdd(a.g_rays + (size_t)n * 6 + 4, (gv1 - dotv * vy) / nr);
+        atomicAdd(a.g_rays + (size_t)n * 6 + 5, (gv2 - dotv * vz) / nr);
+      } else if (a.g_rays && act && h == 0) {
+        atomicAdd(a.g_rays + (size_t)n * 6 + 3, gv0);
+        atomicAdd(a.g_rays + (size_t)n * 6 + 4, gv1);
+        atomicAdd(a.g_rays + (size_t)n * 6 + 5, gv2);
+      }
     }
     save_rows<16>(gb, sv::K3G_DF, dF, s, h);
     float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
@@ -560,7 +584,7 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
     }
   }
   __syncthreads();
-  float sufcarry = 0.f;
+  float sufcarry = 0.f, g_nrm = 0.f;
   const int ntile = (a.S + 63) >> 6;
   for (int tl = ntile - 1; tl >= 0; --tl) {
     const int j0 = tl << 6;
@@ -595,6 +619,10 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
     }
     float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
     g_sigma += g_alpha * ds * (1.0f - alpha);
+    if (a.g_rays && act) {  // dists = dz * |d| * scale: d(loss)/d|d|
+      const float g_ds = (a.g_dists ? a.g_dists[idx] : 0.f) + g_alpha * sigma * (1.0f - alpha);
+      g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+    }
     const float gf = vld ? g_sigma * act_grad(f, a.act, a.density_shift) : 0.f;
     {
       const bool live = vld && gf != 0.f;
@@ -612,6 +640,10 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
         atomicAdd(a.g_xyz + (size_t)idx * 3 + 2, d2 * a.box.inv[2]);
       }
     }
+  }
+  if (a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
+    g_nrm = wave_sum(g_nrm);
+    if (lane < 3) atomicAdd(a.g_rays + (size_t)n * 6 + 3 + lane, g_nrm * (lane == 0 ? vx : (lane == 1 ? vy : vz)));
   }
 }
 
@@ -652,7 +684,7 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         carry *= __shfl(scan_mul32(p, s), 31, 32);
       }
     }
-    float sufcarry = 0.f;
+    float sufcarry = 0.f, g_nrm = 0.f;
     float dTacc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dTacc[i] = 0.f;
@@ -692,6 +724,10 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
       }
       float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
       g_sigma += g_alpha * ds * (1.0f - alpha);
+      if (a.g_rays && act && h == 0) {
+        const float g_ds = (a.g_dists ? a.g_dists[idx] : 0.f) + g_alpha * sigma * (1.0f - alpha);
+        g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+      }
       const float g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
       const float bl = sigmoidf_(fb);
       const float g_fb = (vld && a.g_blending) ? a.g_blending[idx] * bl * (1.0f - bl) : 0.f;
@@ -803,6 +839,10 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
       if (s == 0) a.dtout[(size_t)n * 32 + elem_of(i, h)] = v;
+    }
+    if (a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
+      g_nrm = wave_sum(g_nrm);
+      if (lane < 3) atomicAdd(a.g_rays + (size_t)n * 6 + 3 + lane, g_nrm * (lane == 0 ? vx : (lane == 1 ? vy : vz)));
     }
   }
   if (use_lacc) {
@@ -1191,13 +1231,12 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 2048, -1, "static_bwd: bad arguments (S <= 2048)");
-  // dists depends on z and rays only: g_dists matters only when g_z / g_rays are requested
-  RDRF_CHECK(g_z == nullptr && g_rays == nullptr, -38,
-             "static_bwd: gradients through dists / view directions (g_z, g_rays) are not built yet");
-  (void)g_dists;
+  // z_vals never depends on a trainable quantity in the reference (linspace + jitter)
+  RDRF_CHECK(g_z == nullptr, -38, "static_bwd: gradient wrt z_vals (g_z) is not built");
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_xyz = g_xyz;
+  a.g_rays = g_rays; a.g_dists = g_dists;
   RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 0, N, S), -3, "static_bwd: saved buffer too small");
   BwdWs b;
   int rc = carve_bwd(b, ws, ws_bytes, N, S, 0);
@@ -1242,7 +1281,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     rc = dw_launch(D, stream, "dw_static");
     if (rc) return rc;
   }
-  if (g_sigma != nullptr || g_weight != nullptr)
+  if (g_sigma != nullptr || g_weight != nullptr || (g_rays != nullptr && g_dists != nullptr))
     RDRF_LAUNCH("static_density_bwd", k_static_density_bwd, dim3(N), dim3(64), stream, a, w, gw);
   return 0;
 }
@@ -1257,13 +1296,11 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 1024, -1, "dynamic_bwd: bad arguments (S <= 1024)");
-  RDRF_CHECK(g_z == nullptr && g_rays == nullptr, -38,
-             "dynamic_bwd: gradients through dists (g_z, g_rays) are not built yet");
-  (void)g_dists;
+  RDRF_CHECK(g_z == nullptr, -38, "dynamic_bwd: gradient wrt z_vals (g_z) is not built");
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_blending = g_blending;
-  a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz;
+  a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz; a.g_rays = g_rays; a.g_dists = g_dists;
   RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 1, N, S), -3, "dynamic_bwd: saved buffer too small");
   BwdWs b;
   int rc = carve_bwd(b, ws, ws_bytes, N, S, 1);
@@ -1398,7 +1435,96 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
 // not built yet (round 2): ray-generation / sampler backward, fused render
 // ------------------------------------------------------------------------------------------------
 #define NOT_YET(name) do { rdrf_set_error(name ": not implemented yet"); return -38; } while (0)
-extern "C" int rdrf_generate_rays_bwd(const int64_t*, const float*, const float*, int, int, int, int, int, float, const float*, float*, float*, rdrf_stream_t) { NOT_YET("generate_rays_bwd"); }
+// ray generation backward: hand-written adjoint of k_generate_rays (rdrf_misc.hip)
+__global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float* __restrict__ poses9,
+                                    const float* __restrict__ focal_p, int N, int T, int H, int W,
+                                    int ndc, float near, const float* __restrict__ g_rays,
+                                    float* __restrict__ g_poses, float* __restrict__ g_focal) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  float gf = 0.f;
+  if (n < N) {
+    const long id = ids[n];
+    const int col = (int)(id % W), row = (int)((id / W) % H);
+    int view = (int)(id / ((long)W * H));
+    view = view < 0 ? 0 : (view >= T ? T - 1 : view);
+    const float f = focal_p[0];
+    const float dir[3] = {((float)col + 0.5f - 0.5f * W) / f, -((float)row + 0.5f - 0.5f * H) / f, -1.0f};
+    const float* p = poses9 + view * 9;
+    float b1[3] = {p[0], p[1], p[2]};
+    const float n1 = sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
+    for (int k = 0; k < 3; ++k) b1[k] /= n1;
+    const float dt = b1[0] * p[3] + b1[1] * p[4] + b1[2] * p[5];
+    float u[3] = {p[3] - dt * b1[0], p[4] - dt * b1[1], p[5] - dt * b1[2]};
+    const float n2 = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2],
+                         b1[0] * b2[1] - b1[1] * b2[0]};
+    float d[3], o[3] = {p[6], p[7], p[8]};
+    for (int r = 0; r < 3; ++r) d[r] = dir[0] * b1[r] + dir[1] * b2[r] + dir[2] * b3[r];
+    const float* g = g_rays + (size_t)n * 6;
+    float go[3] = {g[0], g[1], g[2]}, gd[3] = {g[3], g[4], g[5]};
+    if (ndc) {
+      const float t = -(near + o[2]) / d[2];
+      const float op[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+      const float kw = -2.0f * f / (float)W, kh = -2.0f * f / (float)H;
+      const float aa = op[0] / op[2], bb = op[1] / op[2], ra = d[0] / d[2], rb = d[1] / d[2];
+      const float g_kw = go[0] * aa + gd[0] * (ra - aa), g_kh = go[1] * bb + gd[1] * (rb - bb);
+      gf += g_kw * (-2.0f / (float)W) + g_kh * (-2.0f / (float)H);
+      const float g_a = kw * (go[0] - gd[0]), g_b = kh * (go[1] - gd[1]);
+      const float g_ra = kw * gd[0], g_rb = kh * gd[1];
+      float gop[3];
+      gop[0] = g_a / op[2];
+      gop[1] = g_b / op[2];
+      gop[2] = -(g_a * aa + g_b * bb) / op[2] - 2.0f * near * go[2] / (op[2] * op[2]) +
+               2.0f * near * gd[2] / (op[2] * op[2]);
+      float gdd[3] = {g_ra / d[2], g_rb / d[2], -(g_ra * ra + g_rb * rb) / d[2]};
+      const float g_t = gop[0] * d[0] + gop[1] * d[1] + gop[2] * d[2];
+      for (int k = 0; k < 3; ++k) { go[k] = gop[k]; gdd[k] += t * gop[k]; }
+      go[2] += -g_t / d[2];
+      gdd[2] += -g_t * t / d[2];
+      for (int k = 0; k < 3; ++k) gd[k] = gdd[k];
+    }
+    // d = sum_c dir_c b_c
+    float gb1[3], gb2[3], gb3[3], gdir[3];
+    for (int k = 0; k < 3; ++k) { gb1[k] = dir[0] * gd[k]; gb2[k] = dir[1] * gd[k]; gb3[k] = dir[2] * gd[k]; }
+    gdir[0] = gd[0] * b1[0] + gd[1] * b1[1] + gd[2] * b1[2];
+    gdir[1] = gd[0] * b2[0] + gd[1] * b2[1] + gd[2] * b2[2];
+    gf += -gdir[0] * dir[0] / f - gdir[1] * dir[1] / f;
+    // b3 = b1 x b2:  g_b1 += b2 x g_b3,  g_b2 += g_b3 x b1
+    gb1[0] += b2[1] * gb3[2] - b2[2] * gb3[1]; gb1[1] += b2[2] * gb3[0] - b2[0] * gb3[2];
+    gb1[2] += b2[0] * gb3[1] - b2[1] * gb3[0];
+    gb2[0] += gb3[1] * b1[2] - gb3[2] * b1[1]; gb2[1] += gb3[2] * b1[0] - gb3[0] * b1[2];
+    gb2[2] += gb3[0] * b1[1] - gb3[1] * b1[0];
+    // b2 = u/|u|
+    const float dot2 = gb2[0] * b2[0] + gb2[1] * b2[1] + gb2[2] * b2[2];
+    float gu[3];
+    for (int k = 0; k < 3; ++k) gu[k] = (gb2[k] - dot2 * b2[k]) / n2;
+    float gp1[3];
+    float g_dt = 0.f;
+    for (int k = 0; k < 3; ++k) { gp1[k] = gu[k]; g_dt -= gu[k] * b1[k]; gb1[k] -= dt * gu[k]; }
+    for (int k = 0; k < 3; ++k) { gb1[k] += g_dt * p[3 + k]; gp1[k] += g_dt * b1[k]; }
+    const float dot1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
+    float* gp = g_poses + view * 9;
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(gp + k, (gb1[k] - dot1 * b1[k]) / n1);
+      atomicAdd(gp + 3 + k, gp1[k]);
+      atomicAdd(gp + 6 + k, go[k]);
+    }
+  }
+  gf = wave_sum(gf);
+  if ((threadIdx.x & 63) == 0 && gf != 0.f) atomicAdd(g_focal, gf);
+}
+
+extern "C" int rdrf_generate_rays_bwd(const int64_t* ids, const float* poses9, const float* focal,
+                                      int N, int T, int H, int W, int ndc, float near,
+                                      const float* grad_rays, float* grad_poses9, float* grad_focal,
+                                      rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && T > 0 && grad_rays && grad_poses9 && grad_focal, -1, "generate_rays_bwd: bad arguments");
+  RDRF_LAUNCH("generate_rays_bwd", k_generate_rays_bwd, dim3((N + 255) / 256), dim3(256), stream, ids,
+              poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9, grad_focal);
+  return 0;
+}
 extern "C" size_t rdrf_render_workspace_bytes(int N, int S) { return 0; }
 extern "C" int rdrf_render_fwd(const RdrfStaticParams*, const RdrfFieldCfg*, const RdrfDynamicParams*, const RdrfFieldCfg*, const float*, const float*, int, int, float, float, float*, float*, void*, size_t, rdrf_stream_t) { NOT_YET("render_fwd"); }
 extern "C" int rdrf_selftest_mlp(const float*, const float*, const float*, int, int, int, float*, void*, size_t, rdrf_stream_t) { NOT_YET("selftest_mlp"); }
