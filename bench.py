@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-render", action="store_true")
     args = ap.parse_args()
 
     P = importlib.import_module("robust-dynrf_amd.parallel")
@@ -239,6 +240,30 @@ def main():
             "sum_kernel_ms_per_step": tot_ms,
             "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s},
         }
+    if rank == 0 and not args.no_render:
+        # secondary metric of BASELINE.json: render Mpix/s -- whole 240x135 frames through the
+        # no-grad chunk loop of renderer.py:740-812 (one C-ABI call per chunk of 8192 rays)
+        R = importlib.import_module("robust-dynrf_amd.renderer")
+        H, W = cfg["H"], cfg["W"]
+        ids = torch.arange(H * W, device=dev)
+        rays_f = trainer.rays_for(ids + 3 * H * W)
+        ts_f = trainer.data.ts_of(ids + 3 * H * W)
+        chunk = 8192
+
+        def frame():
+            for c0 in range(0, H * W, chunk):
+                R.render_rays(trainer.st, trainer.dy, rays_f[c0:c0 + chunk], ts_f[c0:c0 + chunk],
+                              N_samples=cfg["n_samples"], ray_type=cfg["ray_type"])
+        frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        NF = 5
+        for _ in range(NF):
+            frame()
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t0) / NF
+        out["render"] = {"value": H * W / dtf / 1e6, "unit": "Mpix/s", "frame": [H, W],
+                         "chunk": chunk, "samples_per_ray": cfg["n_samples"], "ms_per_frame": dtf * 1e3}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, cfg["n_samples"])
     if rank == 0:

@@ -11,8 +11,8 @@ Importing this package loads librodynrf.so and raises if it is missing: there is
 """
 from . import _lib
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding, TensorBase
-from .renderer import sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays
+from .renderer import sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays, render_rays
 from .ray_utils import generate_rays, ids2pixel
 
 __all__ = ["TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
-           "OctreeRender_trilinear_fast", "sample_rays", "generate_rays", "ids2pixel"]
+           "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "generate_rays", "ids2pixel"]

@@ -1432,9 +1432,6 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
 }
 
 // ------------------------------------------------------------------------------------------------
-// not built yet (round 2): ray-generation / sampler backward, fused render
-// ------------------------------------------------------------------------------------------------
-#define NOT_YET(name) do { rdrf_set_error(name ": not implemented yet"); return -38; } while (0)
 // ray generation backward: hand-written adjoint of k_generate_rays (rdrf_misc.hip)
 __global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float* __restrict__ poses9,
                                     const float* __restrict__ focal_p, int N, int T, int H, int W,
@@ -1525,6 +1522,3 @@ extern "C" int rdrf_generate_rays_bwd(const int64_t* ids, const float* poses9, c
               poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9, grad_focal);
   return 0;
 }
-extern "C" size_t rdrf_render_workspace_bytes(int N, int S) { return 0; }
-extern "C" int rdrf_render_fwd(const RdrfStaticParams*, const RdrfFieldCfg*, const RdrfDynamicParams*, const RdrfFieldCfg*, const float*, const float*, int, int, float, float, float*, float*, void*, size_t, rdrf_stream_t) { NOT_YET("render_fwd"); }
-extern "C" int rdrf_selftest_mlp(const float*, const float*, const float*, int, int, int, float*, void*, size_t, rdrf_stream_t) { NOT_YET("selftest_mlp"); }

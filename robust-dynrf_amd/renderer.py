@@ -141,3 +141,28 @@ def OctreeRender_trilinear_fast(rays, ts, timeembeddings, tensorf, xyz_sampled, 
     cat = lambda l: None if any(v is None for v in l) else torch.cat(l)
     r = [cat(k) for k in keys]
     return (r[0], r[1], r[2], r[3], r[4], r[5], None, r[6], r[7], r[8], r[9])
+
+
+@torch.no_grad()
+def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc"):
+    """No-grad render of a ray chunk through ONE C-ABI call (rdrf_render_fwd): the loop body of
+    renderer.py:740-812.  Returns (rgb_map_full[N,3], depth_map_full[N])."""
+    from .fields import _cfg_struct, _dynamic_struct, _static_struct
+    L.require_device(rays, ts)
+    rays, ts = L.f32c(rays), L.f32c(ts)
+    N = rays.shape[0]
+    S = int(N_samples) if N_samples and N_samples > 0 else tensorf.nSamples
+    dev = rays.device
+    rgb = torch.empty(N, 3, device=dev)
+    depth = torch.empty(N, device=dev)
+    nbytes = int(L.lib.rdrf_render_workspace_bytes(N, S))
+    ws = L.workspace(dev, nbytes)
+    PS = _static_struct(tensorf_static._param_list())
+    PD = _dynamic_struct(tensorf._param_list())
+    cs, cd = _cfg_struct(tensorf_static, ray_type), _cfg_struct(tensorf, ray_type)
+    near, far = tensorf.near_far
+    L.check(L.lib.rdrf_render_fwd(C.byref(PS), C.byref(cs), C.byref(PD), C.byref(cd), L.ptr(rays),
+                                  L.ptr(ts), N, S, C.c_float(near), C.c_float(far), L.ptr(rgb),
+                                  L.ptr(depth), L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(rays)),
+            "rdrf_render_fwd")
+    return rgb, depth

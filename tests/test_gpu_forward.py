@@ -126,3 +126,35 @@ def test_oracle_forward_balloon_shapes(N, S, grid):
             assert_close(a, b, "c." + k, rtol=2e-4)
         frac = float((r_d[4] > 1e-4).float().mean())
         print(f"app_mask fraction dynamic {frac:.3f} static {float((r_s[4] > 1e-4).float().mean()):.3f}")
+
+
+def test_selftest_mfma_layer():
+    """The MFMA layer primitive (pack -> LDS -> v_mfma_f32_32x32x2_f32 chain) against a matmul with
+    an ASYMMETRIC weight (catches operand / output transposes)."""
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("robust-dynrf_amd._lib")
+    g = torch.Generator().manual_seed(0)
+    M = 77
+    x = torch.randn(M, 64, generator=g).cuda()
+    w = (torch.randn(64, 64, generator=g) + torch.arange(64)[:, None] * 0.01).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    y = torch.empty(M, 64, device="cuda")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    L.check(L.lib.rdrf_selftest_mlp(L.ptr(x), L.ptr(w), L.ptr(b), M, 64, 64, L.ptr(y), L.ptr(ws),
+                                    C.c_size_t(ws.numel()), L.stream_of(x)), "selftest")
+    ref = torch.relu(x.double() @ w.double().T + b.double())
+    assert_close(y, ref, "mfma layer", rtol=1e-5)
+
+
+def test_fused_render_matches_unfused():
+    import rodynrf
+    from _gpu_util import fields_from_case
+    g, st, dy, _ = fields_from_case("ndc_relu")
+    dev = "cuda"
+    rays = torch.from_numpy(g["rays"]).to(dev)
+    ts = torch.from_numpy(g["ts"]).to(dev)
+    S = g["z"].shape[1]
+    rgb, depth = rodynrf.render_rays(st, dy, rays, ts, N_samples=S, ray_type="ndc")
+    assert_close(rgb, g["ce.rgb_map_full"], "render rgb")
+    assert_close(depth, g["ce.depth_map_full"], "render depth")
