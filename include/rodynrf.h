@@ -18,9 +18,11 @@
  *   - return 0 on success, a negative code on failure; rdrf_last_error() gives the message
  *     (thread local). No entry point throws, allocates device memory, or synchronises: outputs and
  *     the workspace are caller-allocated, work is enqueued on `stream`.
- *   - VM factors are CHANNEL-LAST: plane i is [H_i][W_i][C_i] (the reference's (1,C,H,W) tensor
- *     with channels_last strides), line i is [L_i][C_i].  plane 0/1/2 = XY/XZ/YZ,
- *     line 0/1/2 = Z/Y/X (matMode/vecMode, models/tensorBase.py:326-327).
+ *   - VM factors are CHANNEL-LAST: the reference's (1,C,H,W) plane tensors with the component
+ *     axis contiguous and explicit h/w strides (RdrfVM); line i is [L_i][C_i].  plane 0/1/2 =
+ *     XY/XZ/YZ, line 0/1/2 = Z/Y/X (matMode/vecMode, models/tensorBase.py:326-327).  The host
+ *     mirror stores plane 0 as [y][x][C] and planes 1,2 as [x|y][z][C] (z fastest: consecutive
+ *     samples of a forward-facing ray then touch adjacent texels).
  *   - gradients are ACCUMULATED (+=) into the caller's (zero-initialised) buffers.
  */
 #ifndef RODYNRF_H
@@ -40,13 +42,16 @@ enum { RDRF_RAY_NDC = 0, RDRF_RAY_CONTRACT = 1, RDRF_RAY_OTHER = 2 };
 enum { RDRF_ACT_RELU = 0, RDRF_ACT_SOFTPLUS = 1 };
 enum { RDRF_HEAD_MLP_FEA = 0, RDRF_HEAD_MLP_FEA_TIMEEMBEDDING = 1 };
 
-/* One vector-matrix factor set (3 planes + 3 lines), channel-last. */
+/* One vector-matrix factor set (3 planes + 3 lines).  Components are always contiguous (channel
+ * stride 1); the texel strides are explicit so that the planes containing the ray-marching axis can
+ * be stored with that axis fastest: element (c,h,w) of plane i lives at h*sH[i] + w*sW[i] + c. */
 typedef struct {
-  float* plane[3]; /* [H][W][C] */
+  float* plane[3]; /* logical (C,H,W) */
   float* line[3];  /* [L][C]    */
   int C[3];        /* components per plane/line pair: {16,4,4} or {48,12,12} */
   int H[3], W[3];  /* plane i: H = grid[matMode[i][1]], W = grid[matMode[i][0]] */
   int L[3];        /* line i:  L = grid[vecMode[i]] */
+  int sH[3], sW[3]; /* float strides of one step in h / w */
 } RdrfVM;
 
 /* Scalars the path reads from the field object (models/tensorBase.py:282-339, get_kwargs). */

@@ -20,7 +20,8 @@ fp = C.POINTER(C.c_float)
 
 class RdrfVM(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("line", C.c_void_p * 3), ("C", C.c_int * 3),
-                ("H", C.c_int * 3), ("W", C.c_int * 3), ("L", C.c_int * 3)]
+                ("H", C.c_int * 3), ("W", C.c_int * 3), ("L", C.c_int * 3),
+                ("sH", C.c_int * 3), ("sW", C.c_int * 3)]
 
 
 class RdrfFieldCfg(C.Structure):

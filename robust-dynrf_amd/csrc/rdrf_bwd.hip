@@ -215,15 +215,17 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   const int H = pi == 0 ? vm.H[0] : (pi == 1 ? vm.H[1] : vm.H[2]);
   const int W = pi == 0 ? vm.W[0] : (pi == 1 ? vm.W[1] : vm.W[2]);
   const int L = pi == 0 ? vm.L[0] : (pi == 1 ? vm.L[1] : vm.L[2]);
+  const int sH = pi == 0 ? vm.sH[0] : (pi == 1 ? vm.sH[1] : vm.sH[2]);
+  const int sW = pi == 0 ? vm.sW[0] : (pi == 1 ? vm.sW[1] : vm.sW[2]);
   const int lv = sl.level, st = 1 << lv;
   const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
   Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
   const int C = sl.C, qo = 4 * sl.q;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const size_t o00 = (size_t)((ty.i0 << lv) * W + (tx.i0 << lv)) * C + qo;
-  const size_t o01 = (size_t)((ty.i0 << lv) * W + ((tx.i0 + 1) << lv)) * C + qo;
-  const size_t o10 = (size_t)(((ty.i0 + 1) << lv) * W + (tx.i0 << lv)) * C + qo;
-  const size_t o11 = (size_t)(((ty.i0 + 1) << lv) * W + ((tx.i0 + 1) << lv)) * C + qo;
+  const size_t o00 = (size_t)((ty.i0 << lv) * sH + (tx.i0 << lv) * sW) + qo;
+  const size_t o01 = (size_t)((ty.i0 << lv) * sH + ((tx.i0 + 1) << lv) * sW) + qo;
+  const size_t o10 = (size_t)(((ty.i0 + 1) << lv) * sH + (tx.i0 << lv) * sW) + qo;
+  const size_t o11 = (size_t)(((ty.i0 + 1) << lv) * sH + ((tx.i0 + 1) << lv) * sW) + qo;
   const bool k00 = live && ty.ok0 && tx.ok0, k01 = live && ty.ok0 && tx.ok1,
              k10 = live && ty.ok1 && tx.ok0, k11 = live && ty.ok1 && tx.ok1;
   const bool m0 = live && tl.ok0, m1 = live && tl.ok1;

@@ -284,6 +284,8 @@ RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, fl
   const int H = pi == 0 ? vm.H[0] : (pi == 1 ? vm.H[1] : vm.H[2]);
   const int W = pi == 0 ? vm.W[0] : (pi == 1 ? vm.W[1] : vm.W[2]);
   const int L = pi == 0 ? vm.L[0] : (pi == 1 ? vm.L[1] : vm.L[2]);
+  const int sH = pi == 0 ? vm.sH[0] : (pi == 1 ? vm.sH[1] : vm.sH[2]);
+  const int sW = pi == 0 ? vm.sW[0] : (pi == 1 ? vm.sW[1] : vm.sW[2]);
   const int lv = s.level, st = 1 << lv;
   const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
   Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
@@ -292,10 +294,10 @@ RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, fl
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   {
     const int xa = tx.i0 << lv, xb = (tx.i0 + 1) << lv, ya = ty.i0 << lv, yb = (ty.i0 + 1) << lv;
-    if (ty.ok0 && tx.ok0) acc += ld4(P + (size_t)(ya * W + xa) * C + qo) * (tx.w0 * ty.w0);
-    if (ty.ok0 && tx.ok1) acc += ld4(P + (size_t)(ya * W + xb) * C + qo) * (tx.w1 * ty.w0);
-    if (ty.ok1 && tx.ok0) acc += ld4(P + (size_t)(yb * W + xa) * C + qo) * (tx.w0 * ty.w1);
-    if (ty.ok1 && tx.ok1) acc += ld4(P + (size_t)(yb * W + xb) * C + qo) * (tx.w1 * ty.w1);
+    if (ty.ok0 && tx.ok0) acc += ld4(P + (size_t)(ya * sH + xa * sW) + qo) * (tx.w0 * ty.w0);
+    if (ty.ok0 && tx.ok1) acc += ld4(P + (size_t)(ya * sH + xb * sW) + qo) * (tx.w1 * ty.w0);
+    if (ty.ok1 && tx.ok0) acc += ld4(P + (size_t)(yb * sH + xa * sW) + qo) * (tx.w0 * ty.w1);
+    if (ty.ok1 && tx.ok1) acc += ld4(P + (size_t)(yb * sH + xb * sW) + qo) * (tx.w1 * ty.w1);
   }
   r.pv = acc;
   f32x4 l = {0.f, 0.f, 0.f, 0.f};
@@ -307,6 +309,9 @@ RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, fl
 
 template <int C0Q, int C1Q>
 RDRF_D f32x4 gather_quad(const RdrfVM& vm, int g, float x0, float x1, float x2) {
+#ifdef RDRF_ABL_NOGATHER
+  return f32x4{x0, x1, x2, (float)g};
+#endif
   QuadTaps t = gather_quad_taps<C0Q, C1Q>(vm, g, x0, x1, x2);
   return t.pv * t.lv;
 }
@@ -328,7 +333,11 @@ RDRF_D void fill_x0(float (&X0)[32], float xn0, float xn1, float xn2, float t, i
         const int d = j / 10, f = j - d * 10;
         const float x = d == 0 ? xn0 : (d == 1 ? xn1 : xn2);
         float sv, cv;
+#ifdef RDRF_ABL_FASTSIN
+        __sincosf(ldexpf(x, f), &sv, &cv);
+#else
         sincosf(ldexpf(x, f), &sv, &cv);
+#endif
         X0[o * 4 + 2 * p] = sv;
         X0[o * 4 + 2 * p + 1] = cv;
       }

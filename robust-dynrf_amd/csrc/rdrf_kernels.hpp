@@ -86,6 +86,9 @@ constexpr int SFG_DZ6 = 0, SFG_DZ4 = 32, SFG_DZ2 = 96, SFG_DZ0 = 160, SFG_ROWS =
 template <int KK>
 RDRF_D void save_rows(float* __restrict__ tile_base, int row0, const float (&v)[KK], int s, int h) {
   if (tile_base == nullptr) return;
+#ifdef RDRF_ABL_NOSAVE
+  return;
+#endif
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) tile_base[(size_t)(row0 + elem_of(kk, h)) * 32 + s] = v[kk];
 }

@@ -70,17 +70,19 @@ class MLPRender_Fea_late_view(_Head):
         nn.init.constant_(self.mlp_view[-1].bias, 0)
 
 
-def channel_last_(t):
-    """Re-stride a (1,C,H,W) tensor as an [H][W][C] array (values preserved)."""
+def channel_last_(t, h_fast=False):
+    """Re-stride a (1,C,H,W) tensor with the component axis contiguous (values preserved):
+    [H][W][C] by default, [W][H][C] when `h_fast` (used for the XZ / YZ planes, whose H axis is z:
+    consecutive samples of a forward-facing ray then read / update adjacent texels)."""
     _, c, h, w = t.shape
-    out = torch.empty_strided(t.shape, (c * h * w, 1, w * c, c), dtype=t.dtype, device=t.device)
+    strides = (c * h * w, 1, c, h * c) if h_fast else (c * h * w, 1, w * c, c)
+    out = torch.empty_strided(t.shape, strides, dtype=t.dtype, device=t.device)
     out.copy_(t)
     return out
 
 
 def _is_channel_last(t):
-    _, c, h, w = t.shape
-    return t.stride()[1:] == (1, w * c, c) or (t.numel() == 0)
+    return t.stride(1) == 1 or t.numel() == 0
 
 
 # --------------------------------------------------------------------------------------------
@@ -96,6 +98,8 @@ def _vm_struct(planes, lines):
         vm.H[i] = p.shape[2]
         vm.W[i] = p.shape[3]
         vm.L[i] = l.shape[2]
+        vm.sH[i] = p.stride(2)
+        vm.sW[i] = p.stride(3)
     return vm
 
 
@@ -374,7 +378,7 @@ class TensorBase(nn.Module):
             m0, m1 = MAT_MODE[i]
             p = scale * torch.randn((1, n_component[i], gs[m1], gs[m0]))
             l = scale * torch.randn((1, n_component[i], gs[vec_id], 1))
-            plane_coef.append(nn.Parameter(channel_last_(p.to(device))))
+            plane_coef.append(nn.Parameter(channel_last_(p.to(device), h_fast=i > 0)))
             line_coef.append(nn.Parameter(channel_last_(l.to(device))))
         return nn.ParameterList(plane_coef), nn.ParameterList(line_coef)
 
@@ -384,8 +388,9 @@ class TensorBase(nn.Module):
             key = prefix + name
             if key in state_dict and ("_plane." in name or "_line." in name) \
                     and state_dict[key].shape != p.shape:
-                new = channel_last_(state_dict[key].to(p.device).float())
                 mod, attr = name.split(".")
+                new = channel_last_(state_dict[key].to(p.device).float(),
+                                    h_fast="_plane" in mod and int(attr) > 0)
                 getattr(self, mod)[int(attr)] = nn.Parameter(new)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
@@ -444,7 +449,7 @@ class TensorBase(nn.Module):
                               mode="bilinear", align_corners=True)
             l = F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1), mode="bilinear",
                               align_corners=True)
-            plane_coef[i] = nn.Parameter(channel_last_(p))
+            plane_coef[i] = nn.Parameter(channel_last_(p, h_fast=i > 0))
             line_coef[i] = nn.Parameter(channel_last_(l))
         return plane_coef, line_coef
 

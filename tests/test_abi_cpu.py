@@ -45,7 +45,10 @@ def test_state_dict_contract_and_layout():
             assert torch.equal(v.contiguous(), sd[k]), k
     p = dy.density_plane[0]
     _, c, h, w = p.shape
-    assert p.stride() == (c * h * w, 1, w * c, c)  # [H][W][C] storage
+    assert p.stride() == (c * h * w, 1, w * c, c)  # XY plane: [y][x][C] storage
+    p = dy.density_plane[1]
+    _, c, h, w = p.shape
+    assert p.stride() == (c * h * w, 1, c, h * c)  # XZ plane: [x][z][C] storage (z fastest)
     assert len(st.get_optparam_groups()) == 6 and len(dy.get_optparam_groups()) == 18
     assert st.nSamples == dy.nSamples
 
