@@ -229,10 +229,21 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   const bool k00 = live && ty.ok0 && tx.ok0, k01 = live && ty.ok0 && tx.ok1,
              k10 = live && ty.ok1 && tx.ok0, k11 = live && ty.ok1 && tx.ok1;
   const bool m0 = live && tl.ok0, m1 = live && tl.ok1;
-  const f32x4 v00 = k00 ? ld4(P + o00) : zero, v01 = k01 ? ld4(P + o01) : zero;
-  const f32x4 v10 = k10 ? ld4(P + o10) : zero, v11 = k11 ? ld4(P + o11) : zero;
+  // unconditional loads from clamped addresses (no per-tap branch + wait); out-of-range taps are
+  // zeroed afterwards, exactly like zero padding
+  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
+  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
+  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
+  f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo), v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+  f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo), v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
   const size_t l0 = (size_t)(tl.i0 << lv) * C + qo, l1 = (size_t)((tl.i0 + 1) << lv) * C + qo;
-  const f32x4 a0 = m0 ? ld4(Lp + l0) : zero, a1 = m1 ? ld4(Lp + l1) : zero;
+  f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo), a1 = ld4(Lp + (size_t)l1c * C + qo);
+  if (!k00) v00 = zero;
+  if (!k01) v01 = zero;
+  if (!k10) v10 = zero;
+  if (!k11) v11 = zero;
+  if (!m0) a0 = zero;
+  if (!m1) a1 = zero;
   const f32x4 pv = v00 * (tx.w0 * ty.w0) + v01 * (tx.w1 * ty.w0) + v10 * (tx.w0 * ty.w1) +
                    v11 * (tx.w1 * ty.w1);
   const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;

@@ -289,21 +289,26 @@ RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, fl
   const int lv = s.level, st = 1 << lv;
   const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
   Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
-  const int C = s.C, qo = 4 * s.q;
+  const int qo = 4 * s.q;
+  const int C = s.C;
   QuadTaps r;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  {
-    const int xa = tx.i0 << lv, xb = (tx.i0 + 1) << lv, ya = ty.i0 << lv, yb = (ty.i0 + 1) << lv;
-    if (ty.ok0 && tx.ok0) acc += ld4(P + (size_t)(ya * sH + xa * sW) + qo) * (tx.w0 * ty.w0);
-    if (ty.ok0 && tx.ok1) acc += ld4(P + (size_t)(ya * sH + xb * sW) + qo) * (tx.w1 * ty.w0);
-    if (ty.ok1 && tx.ok0) acc += ld4(P + (size_t)(yb * sH + xa * sW) + qo) * (tx.w0 * ty.w1);
-    if (ty.ok1 && tx.ok1) acc += ld4(P + (size_t)(yb * sH + xb * sW) + qo) * (tx.w1 * ty.w1);
-  }
-  r.pv = acc;
-  f32x4 l = {0.f, 0.f, 0.f, 0.f};
-  if (tl.ok0) l += ld4(Lp + (size_t)(tl.i0 << lv) * C + qo) * tl.w0;
-  if (tl.ok1) l += ld4(Lp + (size_t)((tl.i0 + 1) << lv) * C + qo) * tl.w1;
-  r.lv = l;
+  // All six taps are loaded UNCONDITIONALLY from clamped (always valid) addresses and validity is
+  // folded into the weights: a predicated tap (`if (ok) acc += load * w`) compiles to a branch +
+  // load + wait per tap, i.e. six serialized memory round trips per quad.
+  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
+  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
+  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
+  const f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo);
+  const f32x4 v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+  const f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo);
+  const f32x4 v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
+  const f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo);
+  const f32x4 a1 = ld4(Lp + (size_t)l1c * C + qo);
+  const float wx0 = tx.ok0 ? tx.w0 : 0.f, wx1 = tx.ok1 ? tx.w1 : 0.f;
+  const float wy0 = ty.ok0 ? ty.w0 : 0.f, wy1 = ty.ok1 ? ty.w1 : 0.f;
+  const float wl0 = tl.ok0 ? tl.w0 : 0.f, wl1 = tl.ok1 ? tl.w1 : 0.f;
+  r.pv = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+  r.lv = a0 * wl0 + a1 * wl1;
   return r;
 }
 
