@@ -95,12 +95,7 @@ __global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
     const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
     const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
     float G[36];
-#pragma unroll
-    for (int o = 0; o < 9; ++o) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, x0, x1, x2);
-      G[o * 4 + 0] = v.x; G[o * 4 + 1] = v.y; G[o * 4 + 2] = v.z; G[o * 4 + 3] = v.w;
-    }
+    gather_feats<12, 3, 9>(G, w.app, h, x0, x1, x2, act);
     f32x16 accF[1];
     acc_bias<1>(accF, nullptr, h);
     mfma_seg<1, 36>(accF, G, pkw + pk::S3_BASIS, lane);
@@ -245,12 +240,7 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
     float fd, fb;
     {
       float Fv[36];
-#pragma unroll
-      for (int o = 0; o < 9; ++o) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vld) v = gather_quad<4, 1>(w.density, 2 * o + h, xw0, xw1, xw2);
-        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
-      }
+      gather_feats<4, 1, 9>(Fv, w.density, h, xw0, xw1, xw2, vld);
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BD1, h);
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_DEN1_F, lane);
@@ -264,12 +254,7 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
     }
     {
       float Fv[36];
-#pragma unroll
-      for (int o = 0; o < 9; ++o) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vld) v = gather_quad<4, 1>(w.blending, 2 * o + h, xw0, xw1, xw2);
-        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
-      }
+      gather_feats<4, 1, 9>(Fv, w.blending, h, xw0, xw1, xw2, vld);
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BB1, h);
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_BLE1_F, lane);
@@ -341,12 +326,7 @@ __global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
     float F[16];
     {
       float A[108];
-#pragma unroll
-      for (int o = 0; o < 27; ++o) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, xw0, xw1, xw2);
-        A[o * 4 + 0] = v.x; A[o * 4 + 1] = v.y; A[o * 4 + 2] = v.z; A[o * 4 + 3] = v.w;
-      }
+      gather_feats<12, 3, 27>(A, w.app, h, xw0, xw1, xw2, act);
       f32x16 accF[1];
       acc_bias<1>(accF, nullptr, h);
       mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
