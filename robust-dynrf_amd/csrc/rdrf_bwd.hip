@@ -200,11 +200,16 @@ RDRF_D void flush_lds_lines(const float* acc, const RdrfVM& vm, const RdrfVM& gv
 }
 
 template <int C0Q, int C1Q, int MODE>
-RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, const QuadState& qs, f32x4 dq,
-                            bool live, int s, float& dx0, float& dx1, float& dx2,
-                            const LdsLines ll = LdsLines{nullptr, {0, 0, 0}}) {
+RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
+                            float x2, f32x4 dq, bool live, int s, float& dx0, float& dx1,
+                            float& dx2, const LdsLines ll = LdsLines{nullptr, {0, 0, 0}}) {
   QuadSel<C0Q, C1Q> sl = quad_sel<C0Q, C1Q>(g);
   const int pi = sl.pi;
+  const float cx = pi == 2 ? x1 : x0;
+  const float cy = pi == 0 ? x1 : x2;
+  const float cl = pi == 0 ? x2 : (pi == 1 ? x1 : x0);
+  const float* P = pi == 0 ? vm.plane[0] : (pi == 1 ? vm.plane[1] : vm.plane[2]);
+  const float* Lp = pi == 0 ? vm.line[0] : (pi == 1 ? vm.line[1] : vm.line[2]);
   float* GP = pi == 0 ? gvm.plane[0] : (pi == 1 ? gvm.plane[1] : gvm.plane[2]);
   float* GL = pi == 0 ? gvm.line[0] : (pi == 1 ? gvm.line[1] : gvm.line[2]);
   const int H = pi == 0 ? vm.H[0] : (pi == 1 ? vm.H[1] : vm.H[2]);
@@ -214,7 +219,7 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, const Qu
   const int sW = pi == 0 ? vm.sW[0] : (pi == 1 ? vm.sW[1] : vm.sW[2]);
   const int lv = sl.level, st = 1 << lv;
   const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
-  const Tap1 tx = qs.tx, ty = qs.ty, tl = qs.tl;
+  Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
   const int C = sl.C, qo = 4 * sl.q;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const size_t o00 = (size_t)((ty.i0 << lv) * sH + (tx.i0 << lv) * sW) + qo;
@@ -224,10 +229,21 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, const Qu
   const bool k00 = live && ty.ok0 && tx.ok0, k01 = live && ty.ok0 && tx.ok1,
              k10 = live && ty.ok1 && tx.ok0, k11 = live && ty.ok1 && tx.ok1;
   const bool m0 = live && tl.ok0, m1 = live && tl.ok1;
+  // unconditional loads from clamped addresses (no per-tap branch + wait); out-of-range taps are
+  // zeroed afterwards, exactly like zero padding
+  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
+  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
+  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
+  f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo), v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+  f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo), v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
   const size_t l0 = (size_t)(tl.i0 << lv) * C + qo, l1 = (size_t)((tl.i0 + 1) << lv) * C + qo;
-  const f32x4 v00 = k00 ? qs.v00 : zero, v01 = k01 ? qs.v01 : zero;
-  const f32x4 v10 = k10 ? qs.v10 : zero, v11 = k11 ? qs.v11 : zero;
-  const f32x4 a0 = m0 ? qs.a0 : zero, a1 = m1 ? qs.a1 : zero;
+  f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo), a1 = ld4(Lp + (size_t)l1c * C + qo);
+  if (!k00) v00 = zero;
+  if (!k01) v01 = zero;
+  if (!k10) v10 = zero;
+  if (!k11) v11 = zero;
+  if (!m0) a0 = zero;
+  if (!m1) a1 = zero;
   const f32x4 pv = v00 * (tx.w0 * ty.w0) + v01 * (tx.w1 * ty.w0) + v10 * (tx.w0 * ty.w1) +
                    v11 * (tx.w1 * ty.w1);
   const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
@@ -315,7 +331,7 @@ RDRF_D void acc_zero(f32x16 (&acc)[NB]) {
 // ------------------------------------------------------------------------------------------------
 // appearance phase backward-data (dynamic: MLP_Fea_late_view; static: MLP_Fea | TimeEmbedding)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
   // the basis^T pack (used once per tile) stays in L2; its LDS space holds the line accumulators
   __shared__ __attribute__((aligned(16))) float lds[pkb::K3_BASIST];
   __shared__ float lacc[K3_LINES_MAX];
@@ -401,17 +417,12 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
       mfma_seg<7, 16>(acc, dF, basisT, lane);
       const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
                   xw2 = a.sp.xw[(size_t)idx * 3 + 2];
-      {  // compaction keeps ray order, so neighbouring lanes still share texels: run-reduce.
-        // quad o+1's taps are fetched before quad o's atomics are issued (see QuadState)
-        QuadState cur = quad_fetch<12, 3>(w.app, h, xw0, xw1, xw2);
+      {  // compaction keeps ray order, so neighbouring lanes still share texels: run-reduce
 #pragma unroll
         for (int o = 0; o < 27; ++o) {
-          QuadState nxt;
-          if (o + 1 < 27) nxt = quad_fetch<12, 3>(w.app, 2 * (o + 1) + h, xw0, xw1, xw2);
           f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
                       acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, cur, dq, act, s, dw0, dw1, dw2, lla);
-          if (o + 1 < 27) cur = nxt;
+          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, act, s, dw0, dw1, dw2, lla);
         }
       }
     }
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(512) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw)
 }
 
 template <int HEAD>
-__global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, StaticG gw) {
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, StaticW w, StaticG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::S3_SIZE];
   lds_fill(lds, a.pk + pkb::REG_S3, pkb::S3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
@@ -536,15 +547,11 @@ __global__ __launch_bounds__(512) void k_static_app_bwd(BwdArgs a, StaticW w, St
       const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
       const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
       {
-        QuadState cur = quad_fetch<12, 3>(w.app, h, x0, x1, x2);
 #pragma unroll
         for (int o = 0; o < 9; ++o) {
-          QuadState nxt;
-          if (o + 1 < 9) nxt = quad_fetch<12, 3>(w.app, 2 * (o + 1) + h, x0, x1, x2);
           f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
                       acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, cur, dq, act, s, dw0, dw1, dw2);
-          if (o + 1 < 9) cur = nxt;
+          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, x0, x1, x2, dq, act, s, dw0, dw1, dw2);
         }
       }
     }
@@ -637,14 +644,9 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
       const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
       float d0 = 0.f, d1 = 0.f, d2 = 0.f;
       const f32x4 dq = {gf, gf, gf, gf};
-      QuadState cur = quad_fetch<4, 1>(w.density, 0, x0, x1, x2);
 #pragma unroll
-      for (int g = 0; g < 6; ++g) {
-        QuadState nxt;
-        if (g + 1 < 6) nxt = quad_fetch<4, 1>(w.density, g + 1, x0, x1, x2);
-        gather_quad_bwd<4, 1, 1>(w.density, gw.density, g, cur, dq, live, lane & 31, d0, d1, d2);
-        if (g + 1 < 6) cur = nxt;
-      }
+      for (int g = 0; g < 6; ++g)
+        gather_quad_bwd<4, 1, 1>(w.density, gw.density, g, x0, x1, x2, dq, live, lane & 31, d0, d1, d2);
       if (live && a.g_xyz) {
         atomicAdd(a.g_xyz + (size_t)idx * 3 + 0, d0 * a.box.inv[0]);
         atomicAdd(a.g_xyz + (size_t)idx * 3 + 1, d1 * a.box.inv[1]);
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
 // ------------------------------------------------------------------------------------------------
 // dynamic field, density / blending / warp backward-data: wave per ray, 32-sample tiles
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::K1_SIZE];
   __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
   __shared__ float lacc[K1_LINES_MAX];  // line-gradient accumulators (density | blending)
@@ -767,17 +769,14 @@ __global__ __launch_bounds__(512) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG
         mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1_DEN1T_F : pkb::K1_BLE1T_F), lane);
         mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1_DEN1T_X0 : pkb::K1_BLE1T_X0), lane);
         {
-          const RdrfVM& vmh = head == 0 ? w.density : w.blending;
-          const RdrfVM& gvh = head == 0 ? gw.density : gw.blending;
-          QuadState cur = quad_fetch<4, 1>(vmh, h, xw0, xw1, xw2);
 #pragma unroll
           for (int o = 0; o < 9; ++o) {
-            QuadState nxt;
-            if (o + 1 < 9) nxt = quad_fetch<4, 1>(vmh, 2 * (o + 1) + h, xw0, xw1, xw2);
             f32x4 dq = {accF[o >> 2][(o & 3) * 4 + 0], accF[o >> 2][(o & 3) * 4 + 1],
                         accF[o >> 2][(o & 3) * 4 + 2], accF[o >> 2][(o & 3) * 4 + 3]};
-            gather_quad_bwd<4, 1, 1>(vmh, gvh, 2 * o + h, cur, dq, vld, s, dw0, dw1, dw2, head == 0 ? lld : llb);
-            if (o + 1 < 9) cur = nxt;
+            if (head == 0)
+              gather_quad_bwd<4, 1, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2, lld);
+            else
+              gather_quad_bwd<4, 1, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2, llb);
           }
         }
       }
@@ -949,7 +948,7 @@ RDRF_D void sf_x_bwd(const float (&X)[20], const float (&dX)[20], int h, float& 
   }
 }
 
-__global__ __launch_bounds__(512) void k_scene_flow_bwd(int N, int S, Box box,
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_scene_flow_bwd(int N, int S, Box box,
                                                         const float* __restrict__ pkg,
                                                         const float* __restrict__ act_rows,
                                                         float* __restrict__ grows,
@@ -1184,7 +1183,7 @@ static Geo geo_for_units(long units) {
   Geo g;
   const int ncu = 256;
   int waves = (int)((units + ncu - 1) / ncu);
-  waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
+  waves = waves < 1 ? 1 : (waves > RDRF_MAXW ? RDRF_MAXW : waves);
   g.block = waves * 64;
   long blocks = (units + waves - 1) / waves;
   g.grid = (int)(blocks < 1 ? 1 : (blocks > ncu ? ncu : blocks));

@@ -21,6 +21,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// waves per persistent workgroup of the fused MLP kernels: 8 -> 2 waves/SIMD with a 256-VGPR
+// budget, 4 -> 1 wave/SIMD with 512 VGPRs (A/B-tested on MI355X: 8 wins overall)
+#ifndef RDRF_MAXW
+#define RDRF_MAXW 8
+#endif
 #define RDRF_HD __host__ __device__ __forceinline__
 #define RDRF_D __device__ __forceinline__
 
@@ -265,21 +270,15 @@ RDRF_D QuadSel<C0Q, C1Q> quad_sel(int g) {
   return s;
 }
 
-// One quad's six taps in flight: geometry + values.  quad_fetch() issues the six 16-byte loads
-// UNCONDITIONALLY from clamped (always valid) addresses -- a predicated tap (`if (ok) acc +=
-// load*w`) compiles to a branch + load + wait per tap, six serialized round trips per quad -- and
-// returns without touching the values, so callers can fetch quad q+1 before consuming quad q
-// (explicit software pipelining; on CDNA4 vmcnt also counts stores and atomics, so a wait placed
-// after a scatter would otherwise drain every atomic still in flight).
-struct QuadState {
-  f32x4 v00, v01, v10, v11, a0, a1;
-  Tap1 tx, ty, tl;
+struct QuadTaps {  // everything the backward needs as well
+  f32x4 pv;        // interpolated plane quad
+  f32x4 lv;        // interpolated line quad
 };
 
 RDRF_D f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
 template <int C0Q, int C1Q>
-RDRF_D QuadState quad_fetch(const RdrfVM& vm, int g, float x0, float x1, float x2) {
+RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, float x2) {
   QuadSel<C0Q, C1Q> s = quad_sel<C0Q, C1Q>(g);
   const int pi = s.pi;
   const float cx = pi == 2 ? x1 : x0;
@@ -294,52 +293,37 @@ RDRF_D QuadState quad_fetch(const RdrfVM& vm, int g, float x0, float x1, float x
   const int sW = pi == 0 ? vm.sW[0] : (pi == 1 ? vm.sW[1] : vm.sW[2]);
   const int lv = s.level, st = 1 << lv;
   const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
-  QuadState q;
-  q.tx = tap1d(cx, Ws);
-  q.ty = tap1d(cy, Hs);
-  q.tl = tap1d(cl, Ls);
-  const int qo = 4 * s.q, C = s.C;
-  const int x0c = min(max(q.tx.i0, 0), Ws - 1) << lv, x1c = min(max(q.tx.i0 + 1, 0), Ws - 1) << lv;
-  const int y0c = min(max(q.ty.i0, 0), Hs - 1) << lv, y1c = min(max(q.ty.i0 + 1, 0), Hs - 1) << lv;
-  const int l0c = min(max(q.tl.i0, 0), Ls - 1) << lv, l1c = min(max(q.tl.i0 + 1, 0), Ls - 1) << lv;
-  q.v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo);
-  q.v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
-  q.v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo);
-  q.v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
-  q.a0 = ld4(Lp + (size_t)l0c * C + qo);
-  q.a1 = ld4(Lp + (size_t)l1c * C + qo);
-  return q;
-}
-
-// interpolated plane quad * interpolated line quad (zero padding folded into the weights)
-RDRF_D f32x4 quad_combine(const QuadState& q) {
-  const float wx0 = q.tx.ok0 ? q.tx.w0 : 0.f, wx1 = q.tx.ok1 ? q.tx.w1 : 0.f;
-  const float wy0 = q.ty.ok0 ? q.ty.w0 : 0.f, wy1 = q.ty.ok1 ? q.ty.w1 : 0.f;
-  const float wl0 = q.tl.ok0 ? q.tl.w0 : 0.f, wl1 = q.tl.ok1 ? q.tl.w1 : 0.f;
-  const f32x4 pv = q.v00 * (wx0 * wy0) + q.v01 * (wx1 * wy0) + q.v10 * (wx0 * wy1) + q.v11 * (wx1 * wy1);
-  const f32x4 lv = q.a0 * wl0 + q.a1 * wl1;
-  return pv * lv;
+  Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
+  const int qo = 4 * s.q;
+  const int C = s.C;
+  QuadTaps r;
+  // All six taps are loaded UNCONDITIONALLY from clamped (always valid) addresses and validity is
+  // folded into the weights: a predicated tap (`if (ok) acc += load * w`) compiles to a branch +
+  // load + wait per tap, i.e. six serialized memory round trips per quad.
+  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
+  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
+  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
+  const f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo);
+  const f32x4 v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+  const f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo);
+  const f32x4 v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
+  const f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo);
+  const f32x4 a1 = ld4(Lp + (size_t)l1c * C + qo);
+  const float wx0 = tx.ok0 ? tx.w0 : 0.f, wx1 = tx.ok1 ? tx.w1 : 0.f;
+  const float wy0 = ty.ok0 ? ty.w0 : 0.f, wy1 = ty.ok1 ? ty.w1 : 0.f;
+  const float wl0 = tl.ok0 ? tl.w0 : 0.f, wl1 = tl.ok1 ? tl.w1 : 0.f;
+  r.pv = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+  r.lv = a0 * wl0 + a1 * wl1;
+  return r;
 }
 
 template <int C0Q, int C1Q>
 RDRF_D f32x4 gather_quad(const RdrfVM& vm, int g, float x0, float x1, float x2) {
-  return quad_combine(quad_fetch<C0Q, C1Q>(vm, g, x0, x1, x2));
-}
-
-// gather NQ quads (g = 2*o + h, o = 0..NQ-1) into F[4*NQ] with a one-quad prefetch
-template <int C0Q, int C1Q, int NQ>
-RDRF_D void gather_feats(float (&F)[4 * NQ], const RdrfVM& vm, int h, float x0, float x1, float x2,
-                         bool live) {
-  QuadState cur = quad_fetch<C0Q, C1Q>(vm, h, x0, x1, x2);
-#pragma unroll
-  for (int o = 0; o < NQ; ++o) {
-    QuadState nxt;
-    if (o + 1 < NQ) nxt = quad_fetch<C0Q, C1Q>(vm, 2 * (o + 1) + h, x0, x1, x2);
-    f32x4 v = quad_combine(cur);
-    if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    F[o * 4 + 0] = v.x; F[o * 4 + 1] = v.y; F[o * 4 + 2] = v.z; F[o * 4 + 3] = v.w;
-    if (o + 1 < NQ) cur = nxt;
-  }
+#ifdef RDRF_ABL_NOGATHER
+  return f32x4{x0, x1, x2, (float)g};
+#endif
+  QuadTaps t = gather_quad_taps<C0Q, C1Q>(vm, g, x0, x1, x2);
+  return t.pv * t.lv;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
 // static field, appearance phase: 32-sample MFMA tiles over the compacted list
 // ------------------------------------------------------------------------------------------------
 template <int HEAD>
-__global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, StaticW w) {
   __shared__ __attribute__((aligned(16))) float lds[pk::S3_SIZE];
   lds_fill(lds, a.pk + pk::REG_S3, pk::S3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
@@ -95,7 +95,12 @@ __global__ __launch_bounds__(512) void k_static_app(FieldArgs a, StaticW w) {
     const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
     const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
     float G[36];
-    gather_feats<12, 3, 9>(G, w.app, h, x0, x1, x2, act);
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, x0, x1, x2);
+      G[o * 4 + 0] = v.x; G[o * 4 + 1] = v.y; G[o * 4 + 2] = v.z; G[o * 4 + 3] = v.w;
+    }
     f32x16 accF[1];
     acc_bias<1>(accF, nullptr, h);
     mfma_seg<1, 36>(accF, G, pkw + pk::S3_BASIS, lane);
@@ -172,7 +177,7 @@ __global__ void k_time_branch(const float* __restrict__ ts, DynW w, int N, float
 // ------------------------------------------------------------------------------------------------
 // dynamic field, density/blending phase: one wave per ray, tiles of 32 samples, 2 lanes / sample
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, DynW w) {
   __shared__ __attribute__((aligned(16))) float lds[pk::K1_SIZE];
   lds_fill(lds, a.pk + pk::REG_K1, pk::K1_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
@@ -240,7 +245,12 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
     float fd, fb;
     {
       float Fv[36];
-      gather_feats<4, 1, 9>(Fv, w.density, h, xw0, xw1, xw2, vld);
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.density, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BD1, h);
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_DEN1_F, lane);
@@ -254,7 +264,12 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
     }
     {
       float Fv[36];
-      gather_feats<4, 1, 9>(Fv, w.blending, h, xw0, xw1, xw2, vld);
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.blending, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BB1, h);
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_BLE1_F, lane);
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(512) void k_dyn_density(FieldArgs a, DynW w) {
 // ------------------------------------------------------------------------------------------------
 // dynamic field, appearance phase (models/tensoRF.py:734-811 + MLPRender_Fea_late_view)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app(FieldArgs a, DynW w) {
   __shared__ __attribute__((aligned(16))) float lds[pk::K3_SIZE];
   lds_fill(lds, a.pk + pk::REG_K3, pk::K3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
@@ -326,7 +341,12 @@ __global__ __launch_bounds__(512) void k_dyn_app(FieldArgs a, DynW w) {
     float F[16];
     {
       float A[108];
-      gather_feats<12, 3, 27>(A, w.app, h, xw0, xw1, xw2, act);
+#pragma unroll
+      for (int o = 0; o < 27; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, xw0, xw1, xw2);
+        A[o * 4 + 0] = v.x; A[o * 4 + 1] = v.y; A[o * 4 + 2] = v.z; A[o * 4 + 3] = v.w;
+      }
       f32x16 accF[1];
       acc_bias<1>(accF, nullptr, h);
       mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
@@ -390,7 +410,7 @@ RDRF_D void fill_sf_x(float (&X)[20], float xn0, float xn1, float xn2, float t, 
   }
 }
 
-__global__ __launch_bounds__(512) void k_scene_flow(const float* __restrict__ pts,
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_scene_flow(const float* __restrict__ pts,
                                                    const float* __restrict__ ts, int N, int S,
                                                    Box box, const float* __restrict__ pkg, DynW w,
                                                    float* __restrict__ sf_f,
@@ -564,7 +584,7 @@ static Geo geo_for_units(long units) {
   Geo g;
   const int ncu = 256;
   int waves = (int)((units + ncu - 1) / ncu);
-  waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
+  waves = waves < 1 ? 1 : (waves > RDRF_MAXW ? RDRF_MAXW : waves);
   g.block = waves * 64;
   long blocks = (units + waves - 1) / waves;
   g.grid = (int)(blocks < 1 ? 1 : (blocks > ncu ? ncu : blocks));
