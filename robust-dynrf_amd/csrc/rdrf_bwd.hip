@@ -1060,31 +1060,36 @@ __global__ __launch_bounds__(256) void k_dw(DwJobs jobs) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   float bsum = 0.f;
+  // per tile: ALL row loads (A block + up to four B blocks, 20 x 16 bytes per lane) are issued up
+  // front from unconditional (clamped-block) addresses, then the 16..64 MFMAs run; with the loads
+  // inside `if (b < nb)` blocks hipcc waited after every block (25 % MFMA issue efficiency).
+  int brow[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) brow[b] = J.blk_row0[b0 + (b < nb ? b : nb - 1)];
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const float* ap = J.A + ((size_t)t * J.A_stride + J.A_row0 + bo * 32 + li) * 32 + h * 16;
-    float av[16];
+    const float* bbase = J.B + ((size_t)t * J.B_stride + li) * 32 + h * 16;
+    f32x4 av4[4], bv4[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = ld4(ap + q * 4);
-      av[q * 4 + 0] = v.x; av[q * 4 + 1] = v.y; av[q * 4 + 2] = v.z; av[q * 4 + 3] = v.w;
-    }
+    for (int q = 0; q < 4; ++q) av4[q] = ld4(ap + q * 4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv4[b][q] = ld4(bbase + (size_t)brow[b] * 32 + q * 4);
     if (grp == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bsum += av[r];
+      for (int q = 0; q < 4; ++q) bsum += av4[q].x + av4[q].y + av4[q].z + av4[q].w;
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (b < nb) {
-        const float* bp = J.B + ((size_t)t * J.B_stride + J.blk_row0[b0 + b] + li) * 32 + h * 16;
-        float bv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 v = ld4(bp + q * 4);
-          bv[q * 4 + 0] = v.x; bv[q * 4 + 1] = v.y; bv[q * 4 + 2] = v.z; bv[q * 4 + 3] = v.w;
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].x, bv4[b][q].x, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].y, bv4[b][q].y, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].z, bv4[b][q].z, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].w, bv4[b][q].w, acc[b], 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[r], acc[b], 0, 0, 0);
       }
     }
   }
