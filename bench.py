@@ -210,7 +210,7 @@ def main():
         torch.cuda.synchronize()
         ns = args.rays_per_gpu * cfg["n_samples"]
         flops = {
-            "dyn_density": ns * F_DYN_DENSITY, "dyn_density_bwd": ns * F_DYN_DENSITY,
+            "dyn_density": ns * F_DYN_DENSITY, "dyn_heads_bwd": ns * (19584 + 19584), "dyn_warp_bwd": ns * 26496,
             "dyn_app": ns * f_d * F_DYN_APP, "dyn_app_bwd": ns * f_d * F_DYN_APP,
             "static_app": ns * f_s * F_STAT_APP, "static_app_bwd": ns * f_s * F_STAT_APP,
             "dw_dyn": ns * (F_DYN_DENSITY + f_d * F_DYN_APP), "dw_static": ns * f_s * F_STAT_APP,
@@ -219,8 +219,9 @@ def main():
         table, tot_ms = {}, 0.0
         for k in ["pack", "generate_rays", "sample_ndc", "static_density", "static_app", "time_branch",
                   "dyn_density", "dyn_app", "composite", "scene_flow", "composite_bwd", "dyn_app_bwd",
-                  "dyn_density_bwd", "time_branch_bwd", "dw_dyn", "static_app_bwd", "static_density_bwd",
-                  "dw_static", "scene_flow_bwd", "dw_sf"]:
+                  "scatter_dyn_app", "dyn_heads_bwd", "scatter_dyn_density", "dyn_warp_bwd",
+                  "time_branch_bwd", "dw_dyn", "static_app_bwd", "scatter_static_app",
+                  "static_density_bwd", "dw_static", "scene_flow_bwd", "dw_sf"]:
             msk, n = prof_get(L, k)
             if n:
                 table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}

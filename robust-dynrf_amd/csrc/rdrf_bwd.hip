@@ -24,18 +24,20 @@
 // backward LDS images (transposed packs + small layers), float offsets inside each region
 // ------------------------------------------------------------------------------------------------
 namespace pkb {
-// dynamic density phase
-constexpr int K1_W5 = 0;                          // small 3 x [2][32]
-constexpr int K1_DEN2 = K1_W5 + 3 * 64;           // small 1
-constexpr int K1_BLE2 = K1_DEN2 + 64;
-constexpr int K1_W4T = K1_BLE2 + 64;              // NBI 2 x KK 32
-constexpr int K1_W3T_X0 = K1_W4T + 2 * 32 * 64;   // NBI 2
-constexpr int K1_W3T_T = K1_W3T_X0 + 2 * 32 * 64; // NBI 1
-constexpr int K1_DEN1T_F = K1_W3T_T + 1 * 32 * 64;  // NBI 3
-constexpr int K1_DEN1T_X0 = K1_DEN1T_F + 3 * 32 * 64;
-constexpr int K1_BLE1T_F = K1_DEN1T_X0 + 2 * 32 * 64;
-constexpr int K1_BLE1T_X0 = K1_BLE1T_F + 3 * 32 * 64;
-constexpr int K1_SIZE = K1_BLE1T_X0 + 2 * 32 * 64;
+// dynamic density phase, heads kernel image
+constexpr int K1H_DEN2 = 0;                           // small 1 x [2][32]
+constexpr int K1H_BLE2 = K1H_DEN2 + 64;
+constexpr int K1H_DEN1T_F = K1H_BLE2 + 64;            // NBI 3 x KK 32
+constexpr int K1H_DEN1T_X0 = K1H_DEN1T_F + 3 * 32 * 64;
+constexpr int K1H_BLE1T_F = K1H_DEN1T_X0 + 2 * 32 * 64;
+constexpr int K1H_BLE1T_X0 = K1H_BLE1T_F + 3 * 32 * 64;
+constexpr int K1H_SIZE = K1H_BLE1T_X0 + 2 * 32 * 64;
+// dynamic density phase, warp kernel image
+constexpr int K1W_W5 = 0;                             // small 3 x [2][32]
+constexpr int K1W_W4T = K1W_W5 + 3 * 64;              // NBI 2 x KK 32
+constexpr int K1W_W3T_X0 = K1W_W4T + 2 * 32 * 64;     // NBI 2
+constexpr int K1W_W3T_T = K1W_W3T_X0 + 2 * 32 * 64;   // NBI 1
+constexpr int K1W_SIZE = K1W_W3T_T + 1 * 32 * 64;
 // dynamic appearance phase
 constexpr int K3_RGBV = 0;                        // small 3 x [2][64]
 constexpr int K3_RGB2T = K3_RGBV + 3 * 128;       // NBI 4 x KK 64
@@ -56,18 +58,16 @@ constexpr int SF_W4T = SF_W6 + 6 * 64;
 constexpr int SF_W2T = SF_W4T + 2 * 32 * 64;
 constexpr int SF_W0T = SF_W2T + 2 * 32 * 64;      // NBI 2 (40 -> 64)
 constexpr int SF_SIZE = SF_W0T + 2 * 32 * 64;
-constexpr int REG_K1 = 0, REG_K3 = REG_K1 + K1_SIZE, REG_SF = REG_K3 + K3_SIZE,
-              REG_DYN_END = REG_SF + SF_SIZE;
+constexpr int REG_K1H = 0, REG_K1W = REG_K1H + K1H_SIZE, REG_K3 = REG_K1W + K1W_SIZE,
+              REG_SF = REG_K3 + K3_SIZE, REG_DYN_END = REG_SF + SF_SIZE;
 constexpr int REG_S3 = 0, REG_STAT_END = S3_SIZE;
-static_assert(K1_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
+static_assert(K1H_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
               "backward weight images must fit the LDS");
 }  // namespace pkb
 
 // ------------------------------------------------------------------------------------------------
 // argument block of the backward kernels
 // ------------------------------------------------------------------------------------------------
-#define K1_LINES_MAX 8192   /* floats: 124 KB weight image + 1 KB carries + 32 KB lines < 160 KB */
-#define K3_LINES_MAX 11264  /* floats: 117 KB weight image (basis^T read from L2) + 44 KB lines */
 
 struct BwdArgs {
   const float* rays;
@@ -115,6 +115,9 @@ struct DynG {
 // t's quad, and 4 instructions then cover all 64 lanes' quads with one request per quad.
 // Must be called by ALL lanes of the wave (uniform control flow); `ok` gates the lane's quad.
 RDRF_D void atomic_add4(float* p, f32x4 v, bool ok) {
+#if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOGLOBAL)
+  return;
+#endif
   const unsigned long long any = __ballot(ok);
   if (any == 0ull) return;
   const int lane = threadIdx.x & 63, c = lane & 3;
@@ -153,6 +156,9 @@ RDRF_D Run run_of(int key, int s) {
   return r;
 }
 RDRF_D f32x4 run_scan4(f32x4 v, int start, int s) {
+#ifdef RDRF_ABL_NOSCAN
+  return v;
+#endif
 #pragma unroll
   for (int d = 1; d < 32; d <<= 1) {
     const float ox = __shfl_up(v.x, d, 32), oy = __shfl_up(v.y, d, 32);
@@ -174,6 +180,9 @@ struct LdsLines {
   int off[3];    // float offset of line 0/1/2 inside it
 };
 RDRF_D void lds_add4(float* p, f32x4 v) {
+#if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOLDS)
+  return;
+#endif
   atomicAdd(p + 0, v.x);
   atomicAdd(p + 1, v.y);
   atomicAdd(p + 2, v.z);
@@ -203,6 +212,9 @@ template <int C0Q, int C1Q, int MODE>
 RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
                             float x2, f32x4 dq, bool live, int s, float& dx0, float& dx1,
                             float& dx2, const LdsLines ll = LdsLines{nullptr, {0, 0, 0}}) {
+#ifdef RDRF_ABL_NOGBWD
+  dx0 += dq.x; return;
+#endif
   QuadSel<C0Q, C1Q> sl = quad_sel<C0Q, C1Q>(g);
   const int pi = sl.pi;
   const float cx = pi == 2 ? x1 : x0;
@@ -332,16 +344,9 @@ RDRF_D void acc_zero(f32x16 (&acc)[NB]) {
 // appearance phase backward-data (dynamic: MLP_Fea_late_view; static: MLP_Fea | TimeEmbedding)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
-  // the basis^T pack (used once per tile) stays in L2; its LDS space holds the line accumulators
-  __shared__ __attribute__((aligned(16))) float lds[pkb::K3_BASIST];
-  __shared__ float lacc[K3_LINES_MAX];
-  const int nla = lines_floats(w.app);
-  const bool use_lacc = nla <= K3_LINES_MAX;
-  if (use_lacc)
-    for (int i = threadIdx.x; i < nla; i += blockDim.x) lacc[i] = 0.f;
-  const LdsLines lla = make_lds_lines(use_lacc ? lacc : nullptr, w.app);
-  lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_BASIST);
-  const float* basisT = a.pk + pkb::REG_K3 + pkb::K3_BASIST;
+  __shared__ __attribute__((aligned(16))) float lds[pkb::K3_SIZE];
+  lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_SIZE);
+  const float* basisT = lds + pkb::K3_BASIST;
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int count = a.sp.hdr->count;
@@ -409,34 +414,19 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
       x0_bwd(X0, dX0, h, dn0, dn1, dn2);
     }
     dn0 += __shfl_xor(dn0, 32, 64); dn1 += __shfl_xor(dn1, 32, 64); dn2 += __shfl_xor(dn2, 32, 64);
-    // ---- basis backward + gather backward at the warped coordinate
-    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+    // ---- basis backward: d(app features) rows for the scatter kernel
     {
       f32x16 acc[7];
       acc_zero<7>(acc);
       mfma_seg<7, 16>(acc, dF, basisT, lane);
-      const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
-                  xw2 = a.sp.xw[(size_t)idx * 3 + 2];
-      {  // compaction keeps ray order, so neighbouring lanes still share texels: run-reduce
-#pragma unroll
-        for (int o = 0; o < 27; ++o) {
-          f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
-                      acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, xw0, xw1, xw2, dq, act, s, dw0, dw1, dw2, lla);
-        }
-      }
+      float dA[112];
+      acc_copy<7>(dA, acc);
+      save_rows<112>(gb, sv::K3G_DA, dA, s, h);
     }
-    dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
     if (act && h == 0) {
-      a.dxw_app[(size_t)idx * 3 + 0] = dw0; a.dxw_app[(size_t)idx * 3 + 1] = dw1;
-      a.dxw_app[(size_t)idx * 3 + 2] = dw2;
       a.dxn_app[(size_t)idx * 3 + 0] = dn0; a.dxn_app[(size_t)idx * 3 + 1] = dn1;
       a.dxn_app[(size_t)idx * 3 + 2] = dn2;
     }
-  }
-  if (use_lacc) {
-    __syncthreads();
-    flush_lds_lines(lacc, w.app, gw.app);
   }
 }
 
@@ -538,28 +528,13 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
       }
     }
     save_rows<16>(gb, sv::K3G_DF, dF, s, h);
-    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
     {
       f32x16 acc[3];
       acc_zero<3>(acc);
       mfma_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, lane);
-      const float x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
-      const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
-      const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
-      {
-#pragma unroll
-        for (int o = 0; o < 9; ++o) {
-          f32x4 dq = {acc[o >> 2][(o & 3) * 4 + 0], acc[o >> 2][(o & 3) * 4 + 1],
-                      acc[o >> 2][(o & 3) * 4 + 2], acc[o >> 2][(o & 3) * 4 + 3]};
-          gather_quad_bwd<12, 3, 1>(w.app, gw.app, 2 * o + h, x0, x1, x2, dq, act, s, dw0, dw1, dw2);
-        }
-      }
-    }
-    dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
-    if (act && h == 0 && a.g_xyz) {  // static coordinates are xn(xyz): straight to g_xyz
-      atomicAdd(a.g_xyz + (size_t)idx * 3 + 0, dw0 * a.box.inv[0]);
-      atomicAdd(a.g_xyz + (size_t)idx * 3 + 1, dw1 * a.box.inv[1]);
-      atomicAdd(a.g_xyz + (size_t)idx * 3 + 2, dw2 * a.box.inv[2]);
+      float dG[48];
+      acc_copy<3>(dG, acc);
+      save_rows<48>(gb, sv::K3G_DA, dG, s, h);
     }
   }
 }
@@ -661,26 +636,116 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
 }
 
 // ------------------------------------------------------------------------------------------------
-// dynamic field, density / blending / warp backward-data: wave per ray, 32-sample tiles
+// generic scatter kernel: VM gather backward of one or two factor sets from feature-gradient rows.
+// No MFMA state and no weight image -> ~100 VGPRs, several workgroups per CU: the dependent
+// shuffle-scan / atomic latency chains of different waves overlap (inside the fused MLP kernels,
+// at 2 waves/SIMD, they were 85 % of the backward-data time).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
-  __shared__ __attribute__((aligned(16))) float lds[pkb::K1_SIZE];
-  __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
-  __shared__ float lacc[K1_LINES_MAX];  // line-gradient accumulators (density | blending)
-  const int nld = lines_floats(w.density);
-  const bool use_lacc = 2 * nld <= K1_LINES_MAX;
+#define SC_LINES_MAX 12288  /* floats of LDS line-gradient accumulators per workgroup (48 KB) */
+struct ScatterArgs {
+  RdrfVM vm[2], gvm[2];
+  int nsets;
+  const float* rows;   // d(feature) rows: tile t, row r at rows + (t*stride + row0[set] + r)*32
+  int stride, row0[2];
+  const float* xw;     // [idx][3] normalised coordinates, or nullptr -> normalise xyz
+  const float* xyz;
+  Box box;
+  const int* list;     // compacted mode: sample ids (+ device count); nullptr -> ray tiles
+  const int* count;
+  const uint8_t* valid;
+  int N, S;
+  float* dxw;          // [idx][3] coordinate gradients (nullable)
+  int dxw_accumulate;
+  float* g_xyz;        // static field: g_xyz += dw * inv (nullable)
+};
+
+template <int C0Q, int C1Q, int NQ>
+__global__ __launch_bounds__(256, 3) void k_scatter(ScatterArgs a) {
+  __shared__ float lacc[SC_LINES_MAX];
+  const int nl0 = lines_floats(a.vm[0]), nl1 = a.nsets > 1 ? lines_floats(a.vm[1]) : 0;
+  const bool use_lacc = nl0 + nl1 <= SC_LINES_MAX;
   if (use_lacc)
-    for (int i = threadIdx.x; i < 2 * nld; i += blockDim.x) lacc[i] = 0.f;
-  const LdsLines lld = make_lds_lines(use_lacc ? lacc : nullptr, w.density);
-  const LdsLines llb = make_lds_lines(use_lacc ? lacc + nld : nullptr, w.blending);
-  lds_fill(lds, a.pk + pkb::REG_K1, pkb::K1_SIZE);
+    for (int i = threadIdx.x; i < nl0 + nl1; i += blockDim.x) lacc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int tpr = (a.S + 31) >> 5;
+  const int count = a.list ? *a.count : 0;
+  const int ntiles = a.list ? ((count + 31) >> 5) : a.N * tpr;
+  for (int t = blockIdx.x * nwaves + wave; t < ntiles; t += gridDim.x * nwaves) {
+    int idx;
+    bool live;
+    if (a.list) {
+      const int li = t * 32 + s;
+      live = li < count;
+      idx = live ? a.list[li] : 0;
+    } else {
+      const int n = t / tpr, j = (t - n * tpr) * 32 + s;
+      const bool act = j < a.S;
+      idx = n * a.S + (act ? j : 0);
+      live = act && a.valid[idx] != 0;
+    }
+    float x0, x1, x2;
+    if (a.xw) {
+      x0 = a.xw[(size_t)idx * 3 + 0]; x1 = a.xw[(size_t)idx * 3 + 1]; x2 = a.xw[(size_t)idx * 3 + 2];
+    } else {
+      x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    }
+    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+    for (int set = 0; set < a.nsets; ++set) {
+      const float* rb = a.rows + ((size_t)t * a.stride + a.row0[set]) * 32;
+      const LdsLines ll = make_lds_lines(use_lacc ? lacc + (set ? nl0 : 0) : nullptr, a.vm[set]);
+#pragma unroll
+      for (int o = 0; o < NQ; ++o) {
+        const float* rq = rb + (size_t)(8 * o + 4 * h) * 32 + s;
+        const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
+        gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], 2 * o + h, x0, x1, x2, dq, live, s, dw0, dw1,
+                                     dw2, ll);
+      }
+    }
+    dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
+    if (live && h == 0) {
+      if (a.dxw) {
+        float* d = a.dxw + (size_t)idx * 3;
+        if (a.dxw_accumulate) { d[0] += dw0; d[1] += dw1; d[2] += dw2; }
+        else { d[0] = dw0; d[1] = dw1; d[2] = dw2; }
+      }
+      if (a.g_xyz) {
+        a.g_xyz[(size_t)idx * 3 + 0] += dw0 * a.box.inv[0];
+        a.g_xyz[(size_t)idx * 3 + 1] += dw1 * a.box.inv[1];
+        a.g_xyz[(size_t)idx * 3 + 2] += dw2 * a.box.inv[2];
+      }
+    }
+  }
+  if (use_lacc) {
+    __syncthreads();
+    flush_lds_lines(lacc, a.vm[0], a.gvm[0]);
+    if (a.nsets > 1) flush_lds_lines(lacc + nl0, a.vm[1], a.gvm[1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic field, density / blending / warp backward-data: wave per ray, 32-sample tiles, in two
+// phases around the scatter kernel:
+//   PHASE 0 (heads): weight/sigma/blending backward, density + blending head backward ->
+//                    d(feature) rows for k_scatter, d(X0) partial rows, dz rows
+//   PHASE 1 (warp) : coordinate gradients (appearance + density + blending scatter) ->
+//                    warp MLP backward, positional-encoding backward, g_xyz, d(tout)
+// ------------------------------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
+  __shared__ __attribute__((aligned(16))) float lds[PHASE == 0 ? pkb::K1H_SIZE : pkb::K1W_SIZE];
+  __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
+  lds_fill(lds, a.pk + (PHASE == 0 ? pkb::REG_K1H : pkb::REG_K1W), PHASE == 0 ? pkb::K1H_SIZE : pkb::K1W_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = (a.S + 31) >> 5;
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
     float vx, vy, vz;
     const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-    if (a.g_weight) {  // pre-pass: transmittance at each tile start
+    if (PHASE == 0 && a.g_weight) {  // pre-pass: transmittance at each tile start
       float carry = 1.0f;
       for (int j0 = 0; j0 < a.S; j0 += 32) {
         if (lane == 0) carr[wave][j0 >> 5] = carry;
@@ -710,158 +775,155 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
       const size_t tl = (size_t)n * tpr + tli;
       const float* svb = a.sp.act1 + tl * sv::K1_ROWS * 32;
       float* gb = a.grows1 + tl * sv::K1G_ROWS * 32;
-      const float fd = a.sp.raw[(size_t)idx * 2], fb = a.sp.raw[(size_t)idx * 2 + 1];
-      const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.f;
-      const float zj = act ? a.z[idx] : 0.f;
-      const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
-      const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
-      const float alpha = 1.0f - expf(-sigma * ds);
-      const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
-      float g_alpha = 0.f;
-      if (a.g_weight) {
-        const float incl = scan_mul32(p, s);
-        float excl = __shfl_up(incl, 1, 32);
-        if (s == 0) excl = 1.0f;
-        const float T = carr[wave][tli] * excl;
-        const float gwv = act ? a.g_weight[idx] : 0.f;
-        float rinc = gwv * alpha * T;
+      if (PHASE == 0) {
+        const float fd = a.sp.raw[(size_t)idx * 2], fb = a.sp.raw[(size_t)idx * 2 + 1];
+        const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.f;
+        const float zj = act ? a.z[idx] : 0.f;
+        const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+        const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+        const float alpha = 1.0f - expf(-sigma * ds);
+        const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+        float g_alpha = 0.f;
+        if (a.g_weight) {
+          const float incl = scan_mul32(p, s);
+          float excl = __shfl_up(incl, 1, 32);
+          if (s == 0) excl = 1.0f;
+          const float T = carr[wave][tli] * excl;
+          const float gwv = act ? a.g_weight[idx] : 0.f;
+          float rinc = gwv * alpha * T;
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-          const float o = __shfl_down(rinc, d, 32);
-          if (s + d < 32) rinc += o;
+          for (int d = 1; d < 32; d <<= 1) {
+            const float o = __shfl_down(rinc, d, 32);
+            if (s + d < 32) rinc += o;
+          }
+          float rex = __shfl_down(rinc, 1, 32);
+          if (s == 31) rex = 0.f;
+          g_alpha = gwv * T - (sufcarry + rex) / p;
+          sufcarry += __shfl(rinc, 0, 32);
         }
-        float rex = __shfl_down(rinc, 1, 32);
-        if (s == 31) rex = 0.f;
-        g_alpha = gwv * T - (sufcarry + rex) / p;
-        sufcarry += __shfl(rinc, 0, 32);
-      }
-      float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
-      g_sigma += g_alpha * ds * (1.0f - alpha);
-      if (a.g_rays && act && h == 0) {
-        const float g_ds = (a.g_dists ? a.g_dists[idx] : 0.f) + g_alpha * sigma * (1.0f - alpha);
-        g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
-      }
-      const float g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
-      const float bl = sigmoidf_(fb);
-      const float g_fb = (vld && a.g_blending) ? a.g_blending[idx] * bl * (1.0f - bl) : 0.f;
-      // coordinate gradients arriving from the appearance phase
-      float dw0 = act ? a.dxw_app[(size_t)idx * 3 + 0] : 0.f, dw1 = act ? a.dxw_app[(size_t)idx * 3 + 1] : 0.f,
-            dw2 = act ? a.dxw_app[(size_t)idx * 3 + 2] : 0.f;
-      float dn0 = act ? a.dxn_app[(size_t)idx * 3 + 0] : 0.f, dn1 = act ? a.dxn_app[(size_t)idx * 3 + 1] : 0.f,
-            dn2 = act ? a.dxn_app[(size_t)idx * 3 + 2] : 0.f;
-      if (h == 1) { dw0 = dw1 = dw2 = 0.f; dn0 = dn1 = dn2 = 0.f; }  // halves are summed below
-      const float xw0 = a.sp.xw[(size_t)idx * 3 + 0], xw1 = a.sp.xw[(size_t)idx * 3 + 1],
-                  xw2 = a.sp.xw[(size_t)idx * 3 + 2];
-      f32x16 accX[2];  // d(X0) accumulated over density head, blending head and warp layer 3
-      acc_zero<2>(accX);
-      // ---- density head and blending head
+        float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
+        g_sigma += g_alpha * ds * (1.0f - alpha);
+        if (a.g_rays && act && h == 0) {
+          const float g_ds = (a.g_dists ? a.g_dists[idx] : 0.f) + g_alpha * sigma * (1.0f - alpha);
+          g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+        }
+        const float g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
+        const float bl = sigmoidf_(fb);
+        const float g_fb = (vld && a.g_blending) ? a.g_blending[idx] * bl * (1.0f - bl) : 0.f;
+        f32x16 accX[2];  // d(X0) of the density and blending heads
+        acc_zero<2>(accX);
 #pragma unroll
-      for (int head = 0; head < 2; ++head) {
-        const float gfh = head == 0 ? g_fd : g_fb;
-        float Hh[32], dzh[32];
-        load_rows<32>(svb, head == 0 ? sv::K1_HD : sv::K1_HB, Hh, s, h);
-        const float* w2 = lds + (head == 0 ? pkb::K1_DEN2 : pkb::K1_BLE2) + h * 32;
+        for (int head = 0; head < 2; ++head) {
+          const float gfh = head == 0 ? g_fd : g_fb;
+          float Hh[32], dzh[32];
+          load_rows<32>(svb, head == 0 ? sv::K1_HD : sv::K1_HB, Hh, s, h);
+          const float* w2 = lds + (head == 0 ? pkb::K1H_DEN2 : pkb::K1H_BLE2) + h * 32;
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) dzh[kk] = Hh[kk] > 0.f ? w2[kk] * gfh : 0.f;
-        save_rows<32>(gb, head == 0 ? sv::K1G_DZD : sv::K1G_DZB, dzh, s, h);
-        f32x16 accF[3];
-        acc_zero<3>(accF);
-        mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1_DEN1T_F : pkb::K1_BLE1T_F), lane);
-        mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1_DEN1T_X0 : pkb::K1_BLE1T_X0), lane);
+          for (int kk = 0; kk < 32; ++kk) dzh[kk] = Hh[kk] > 0.f ? w2[kk] * gfh : 0.f;
+          save_rows<32>(gb, head == 0 ? sv::K1G_DZD : sv::K1G_DZB, dzh, s, h);
+          f32x16 accF[3];
+          acc_zero<3>(accF);
+          mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_F : pkb::K1H_BLE1T_F), lane);
+          mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_X0 : pkb::K1H_BLE1T_X0), lane);
+          float dFh[48];
+          acc_copy<3>(dFh, accF);
+          save_rows<48>(gb, head == 0 ? sv::K1G_DFD : sv::K1G_DFB, dFh, s, h);
+        }
+        float dXh[32];
+        acc_copy<2>(dXh, accX);
+        save_rows<32>(gb, sv::K1G_DX0, dXh, s, h);
+        if (h == 0) {
+          gb[(size_t)(sv::K1G_SM + 3) * 32 + s] = g_fd;
+          gb[(size_t)(sv::K1G_SM + 4) * 32 + s] = g_fb;
+        }
+      } else {
+        // coordinate gradients: appearance phase + density/blending scatter (already summed)
+        float dw0 = act ? a.dxw_app[(size_t)idx * 3 + 0] : 0.f, dw1 = act ? a.dxw_app[(size_t)idx * 3 + 1] : 0.f,
+              dw2 = act ? a.dxw_app[(size_t)idx * 3 + 2] : 0.f;
+        float dn0 = act ? a.dxn_app[(size_t)idx * 3 + 0] : 0.f, dn1 = act ? a.dxn_app[(size_t)idx * 3 + 1] : 0.f,
+              dn2 = act ? a.dxn_app[(size_t)idx * 3 + 2] : 0.f;
+        // xw = normalize(unnormalize(xn) + delta); xyz_prime = xyz + delta
+        float dd0 = dw0 * a.box.inv[0], dd1 = dw1 * a.box.inv[1], dd2 = dw2 * a.box.inv[2];
+        float gp0 = 0.f, gp1 = 0.f, gp2 = 0.f;
+        if (act && a.g_xyz_prime) {
+          gp0 = a.g_xyz_prime[(size_t)idx * 3 + 0]; gp1 = a.g_xyz_prime[(size_t)idx * 3 + 1];
+          gp2 = a.g_xyz_prime[(size_t)idx * 3 + 2];
+        }
+        dd0 += gp0; dd1 += gp1; dd2 += gp2;
+        if (!act) { dd0 = dd1 = dd2 = 0.f; }
+        if (h == 0) {  // small-layer dz rows 0..2 (rows 3,4 were written by phase 0)
+          gb[(size_t)(sv::K1G_SM + 0) * 32 + s] = dd0; gb[(size_t)(sv::K1G_SM + 1) * 32 + s] = dd1;
+          gb[(size_t)(sv::K1G_SM + 2) * 32 + s] = dd2;
+        }
+        // ---- warp MLP backward: layer5 (VALU) -> layer4 -> layer3
+        float dz4[32];
         {
+          float H4[32];
+          load_rows<32>(svb, sv::K1_H4, H4, s, h);
+          const float* w5 = lds + pkb::K1W_W5 + h * 32;
 #pragma unroll
-          for (int o = 0; o < 9; ++o) {
-            f32x4 dq = {accF[o >> 2][(o & 3) * 4 + 0], accF[o >> 2][(o & 3) * 4 + 1],
-                        accF[o >> 2][(o & 3) * 4 + 2], accF[o >> 2][(o & 3) * 4 + 3]};
-            if (head == 0)
-              gather_quad_bwd<4, 1, 1>(w.density, gw.density, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2, lld);
-            else
-              gather_quad_bwd<4, 1, 1>(w.blending, gw.blending, 2 * o + h, xw0, xw1, xw2, dq, vld, s, dw0, dw1, dw2, llb);
+          for (int kk = 0; kk < 32; ++kk) {
+            const float d = w5[kk] * dd0 + w5[64 + kk] * dd1 + w5[128 + kk] * dd2;
+            dz4[kk] = H4[kk] > 0.f ? d : 0.f;
           }
         }
-      }
-      dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
-      // xw = normalize(unnormalize(xn) + delta); xyz_prime = xyz + delta
-      float dd0 = dw0 * a.box.inv[0], dd1 = dw1 * a.box.inv[1], dd2 = dw2 * a.box.inv[2];
-      float gp0 = 0.f, gp1 = 0.f, gp2 = 0.f;
-      if (act && a.g_xyz_prime) {
-        gp0 = a.g_xyz_prime[(size_t)idx * 3 + 0]; gp1 = a.g_xyz_prime[(size_t)idx * 3 + 1];
-        gp2 = a.g_xyz_prime[(size_t)idx * 3 + 2];
-      }
-      dd0 += gp0; dd1 += gp1; dd2 += gp2;
-      if (!act) { dd0 = dd1 = dd2 = 0.f; }
-      // small-layer dz rows: [d_delta(3), g_fd, g_fb]
-      if (h == 0) {
-        gb[(size_t)(sv::K1G_SM + 0) * 32 + s] = dd0; gb[(size_t)(sv::K1G_SM + 1) * 32 + s] = dd1;
-        gb[(size_t)(sv::K1G_SM + 2) * 32 + s] = dd2; gb[(size_t)(sv::K1G_SM + 3) * 32 + s] = g_fd;
-        gb[(size_t)(sv::K1G_SM + 4) * 32 + s] = g_fb;
-      }
-      // ---- warp MLP backward: layer5 (VALU) -> layer4 -> layer3
-      float dz4[32];
-      {
-        float H4[32];
-        load_rows<32>(svb, sv::K1_H4, H4, s, h);
-        const float* w5 = lds + pkb::K1_W5 + h * 32;
+        save_rows<32>(gb, sv::K1G_DZ4, dz4, s, h);
+        float dz3[32];
+        {
+          f32x16 acc[2];
+          acc_zero<2>(acc);
+          mfma_seg<2, 32>(acc, dz4, lds + pkb::K1W_W4T, lane);
+          float H3[32];
+          load_rows<32>(svb, sv::K1_H3, H3, s, h);
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-          const float d = w5[kk] * dd0 + w5[64 + kk] * dd1 + w5[128 + kk] * dd2;
-          dz4[kk] = H4[kk] > 0.f ? d : 0.f;
+          for (int kk = 0; kk < 32; ++kk) dz3[kk] = H3[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
+        }
+        save_rows<32>(gb, sv::K1G_DZ3, dz3, s, h);
+        f32x16 accX[2];  // d(X0): heads (from rows) + warp layer 3
+        {
+          float dXh[32];
+          load_rows<32>(gb, sv::K1G_DX0, dXh, s, h);
+#pragma unroll
+          for (int kk = 0; kk < 32; ++kk) accX[kk >> 4][kk & 15] = dXh[kk];
+        }
+        mfma_seg<2, 32>(accX, dz3, lds + pkb::K1W_W3T_X0, lane);
+        {
+          f32x16 accT[1];
+          acc_zero<1>(accT);
+          mfma_seg<1, 32>(accT, dz3, lds + pkb::K1W_W3T_T, lane);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dTacc[i] += accT[0][i];
+        }
+        // ---- positional encoding backward -> d(xn); plus the identity path xw <- xn
+        {
+          float X0[32], dX0[32];
+          load_rows<32>(svb, sv::K1_X0, X0, s, h);
+          acc_copy<2>(dX0, accX);
+          float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+          x0_bwd(X0, dX0, h, e0, e1, e2);
+          e0 += __shfl_xor(e0, 32, 64); e1 += __shfl_xor(e1, 32, 64); e2 += __shfl_xor(e2, 32, 64);
+          dn0 += e0 + dw0; dn1 += e1 + dw1; dn2 += e2 + dw2;
+        }
+        if (act && h == 0 && a.g_xyz) {
+          a.g_xyz[(size_t)idx * 3 + 0] += dn0 * a.box.inv[0] + gp0;
+          a.g_xyz[(size_t)idx * 3 + 1] += dn1 * a.box.inv[1] + gp1;
+          a.g_xyz[(size_t)idx * 3 + 2] += dn2 * a.box.inv[2] + gp2;
         }
       }
-      save_rows<32>(gb, sv::K1G_DZ4, dz4, s, h);
-      float dz3[32];
-      {
-        f32x16 acc[2];
-        acc_zero<2>(acc);
-        mfma_seg<2, 32>(acc, dz4, lds + pkb::K1_W4T, lane);
-        float H3[32];
-        load_rows<32>(svb, sv::K1_H3, H3, s, h);
+    }
+    if (PHASE == 1) {  // per-ray d(tout): sum over the samples (lanes of each half)
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) dz3[kk] = H3[kk] > 0.f ? acc[kk >> 4][kk & 15] : 0.f;
-      }
-      save_rows<32>(gb, sv::K1G_DZ3, dz3, s, h);
-      mfma_seg<2, 32>(accX, dz3, lds + pkb::K1_W3T_X0, lane);
-      {
-        f32x16 accT[1];
-        acc_zero<1>(accT);
-        mfma_seg<1, 32>(accT, dz3, lds + pkb::K1_W3T_T, lane);
+      for (int i = 0; i < 16; ++i) {
+        float v = dTacc[i];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dTacc[i] += accT[0][i];
-      }
-      // ---- positional encoding backward -> d(xn); plus the identity path xw <- xn
-      {
-        float X0[32], dX0[32];
-        load_rows<32>(svb, sv::K1_X0, X0, s, h);
-        acc_copy<2>(dX0, accX);
-        float e0 = 0.f, e1 = 0.f, e2 = 0.f;
-        x0_bwd(X0, dX0, h, e0, e1, e2);
-        e0 += __shfl_xor(e0, 32, 64); e1 += __shfl_xor(e1, 32, 64); e2 += __shfl_xor(e2, 32, 64);
-        dn0 += __shfl_xor(dn0, 32, 64); dn1 += __shfl_xor(dn1, 32, 64); dn2 += __shfl_xor(dn2, 32, 64);
-        dn0 += e0 + dw0; dn1 += e1 + dw1; dn2 += e2 + dw2;
-      }
-      if (act && h == 0 && a.g_xyz) {
-        a.g_xyz[(size_t)idx * 3 + 0] += dn0 * a.box.inv[0] + gp0;
-        a.g_xyz[(size_t)idx * 3 + 1] += dn1 * a.box.inv[1] + gp1;
-        a.g_xyz[(size_t)idx * 3 + 2] += dn2 * a.box.inv[2] + gp2;
+        for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (s == 0) a.dtout[(size_t)n * 32 + elem_of(i, h)] = v;
       }
     }
-    // per-ray d(tout): sum over the samples (lanes of each half)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = dTacc[i];
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-      if (s == 0) a.dtout[(size_t)n * 32 + elem_of(i, h)] = v;
-    }
-    if (a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
+    if (PHASE == 0 && a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
       g_nrm = wave_sum(g_nrm);
       if (lane < 3) atomicAdd(a.g_rays + (size_t)n * 6 + 3 + lane, g_nrm * (lane == 0 ? vx : (lane == 1 ? vy : vz)));
     }
-  }
-  if (use_lacc) {
-    __syncthreads();
-    flush_lds_lines(lacc, w.density, gw.density);
-    flush_lds_lines(lacc + nld, w.blending, gw.blending);
   }
 }
 
@@ -1147,17 +1209,17 @@ void fill_dyn_w(DynW& w, const RdrfDynamicParams* P);
 static void dyn_pack_jobs_bwd(PackJobs& J, const RdrfDynamicParams* P) {
   using namespace pkb;
   J.n = 0;
-  const int k1 = REG_K1, k3 = REG_K3, sf = REG_SF;
-  pack_add(J, P->l5w, 64, 3, 64, SEG_IDENT, 1, 3, 32, k1 + K1_W5);
-  pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_DEN2);
-  pack_add(J, P->bw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_BLE2);
-  pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, 2, 2, 32, k1 + K1_W4T);
-  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_X0, 2, 2, 32, k1 + K1_W3T_X0);
-  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, 2, 1, 32, k1 + K1_W3T_T);
-  pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, k1 + K1_DEN1T_F);
-  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, k1 + K1_DEN1T_X0);
-  pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, k1 + K1_BLE1T_F);
-  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, k1 + K1_BLE1T_X0);
+  const int kh = REG_K1H, kw = REG_K1W, k3 = REG_K3, sf = REG_SF;
+  pack_add(J, P->l5w, 64, 3, 64, SEG_IDENT, 1, 3, 32, kw + K1W_W5);
+  pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, 2, 2, 32, kw + K1W_W4T);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_X0, 2, 2, 32, kw + K1W_W3T_X0);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, 2, 1, 32, kw + K1W_W3T_T);
+  pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, kh + K1H_DEN2);
+  pack_add(J, P->bw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, kh + K1H_BLE2);
+  pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, kh + K1H_DEN1T_F);
+  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, kh + K1H_DEN1T_X0);
+  pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, kh + K1H_BLE1T_F);
+  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, kh + K1H_BLE1T_X0);
   pack_add(J, P->rwv, 131, 3, 128, SEG_IDENT, 1, 3, 64, k3 + K3_RGBV);
   pack_add(J, P->rw2, 128, 128, 128, SEG_IDENT, 2, 4, 64, k3 + K3_RGB2T);
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 2, 1, 64, k3 + K3_RGB1T_F);
@@ -1240,6 +1302,16 @@ static int carve_bwd(BwdWs& b, void* ws, size_t ws_bytes, int N, int S, int dyna
   return 0;
 }
 
+static void fill_scatter_common(ScatterArgs& sa, const BwdArgs& a) {
+  memset(&sa, 0, sizeof(sa));
+  sa.xyz = a.xyz; sa.box = a.box; sa.valid = a.valid; sa.N = a.N; sa.S = a.S;
+}
+static dim3 scatter_grid(long ntiles) {
+  long g = (ntiles + 3) / 4;
+  g = g < 1 ? 1 : (g > 768 ? 768 : g);
+  return dim3((unsigned)g);
+}
+
 extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                                const float* ts, const float* xyz, const float* z,
                                const uint8_t* valid, int N, int S, const float* g_rgb,
@@ -1277,6 +1349,15 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     else
       RDRF_LAUNCH("static_app_bwd", k_static_app_bwd<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING>, dim3(g.grid),
                   dim3(g.block), stream, a, w, gw);
+    {
+      ScatterArgs sa;
+      fill_scatter_common(sa, a);
+      sa.vm[0] = P->app; sa.gvm[0] = G->app; sa.nsets = 1;
+      sa.rows = b.grows3; sa.stride = sv::K3G_ROWS; sa.row0[0] = sv::K3G_DA;
+      sa.list = a.sp.list; sa.count = &a.sp.hdr->count;
+      sa.g_xyz = g_xyz;
+      RDRF_LAUNCH("scatter_static_app", (k_scatter<12, 3, 9>), scatter_grid((long)t3), dim3(256), stream, sa);
+    }
     const bool fea = cfg->static_head == RDRF_HEAD_MLP_FEA;
     const int in1 = fea ? 138 : 135;
     const int* cnt = &a.sp.hdr->count;
@@ -1343,6 +1424,15 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   if (g_rgb != nullptr) {
     const Geo g = geo_for_units((long)t3);
     RDRF_LAUNCH("dyn_app_bwd", k_dyn_app_bwd, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    {
+      ScatterArgs sa;
+      fill_scatter_common(sa, a);
+      sa.vm[0] = P->app; sa.gvm[0] = G->app; sa.nsets = 1;
+      sa.rows = b.grows3; sa.stride = sv::K3G_ROWS; sa.row0[0] = sv::K3G_DA;
+      sa.xw = a.sp.xw; sa.list = a.sp.list; sa.count = cnt;
+      sa.dxw = b.dxw; sa.dxw_accumulate = 0;
+      RDRF_LAUNCH("scatter_dyn_app", (k_scatter<12, 3, 27>), scatter_grid((long)t3), dim3(256), stream, sa);
+    }
     dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DZV, 1, 3, 0, a.sp.act3, sv::K3_ROWS, 128, 131, G->rwv,
            G->rbv, cnt, 0);
     for (int i = 0; i < 4; ++i) dw_blk(D, sv::K3_H2 + 32 * i, SEG_IDENT, 32 * i);
@@ -1362,7 +1452,18 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   }
   {
     const Geo g = geo_for_units(N);
-    RDRF_LAUNCH("dyn_density_bwd", k_dyn_density_bwd, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    RDRF_LAUNCH("dyn_heads_bwd", k_dyn_density_bwd<0>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    {
+      ScatterArgs sa;
+      fill_scatter_common(sa, a);
+      sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;
+      sa.nsets = 2;
+      sa.rows = b.grows1; sa.stride = sv::K1G_ROWS; sa.row0[0] = sv::K1G_DFD; sa.row0[1] = sv::K1G_DFB;
+      sa.xw = a.sp.xw;
+      sa.dxw = b.dxw; sa.dxw_accumulate = 1;
+      RDRF_LAUNCH("scatter_dyn_density", (k_scatter<4, 1, 9>), scatter_grid((long)t1), dim3(256), stream, sa);
+    }
+    RDRF_LAUNCH("dyn_warp_bwd", k_dyn_density_bwd<1>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
     RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((N + 127) / 128), dim3(128), stream, ts, w,
                 N, b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
     const int T1 = (int)t1;

@@ -78,8 +78,9 @@ constexpr int S3_G = 0, S3_F = 96, S3_P = 128, S3_H1 = 256, S3_H2 = 384, S3_VD =
 // scene flow
 constexpr int SF_X = 0, SF_H0 = 64, SF_H2 = 128, SF_H4 = 192, SF_ROWS = 256;
 // gradient rows written by the backward-data kernels (workspace, same layout)
-constexpr int K1G_DZ3 = 0, K1G_DZ4 = 64, K1G_SM = 128, K1G_DZD = 160, K1G_DZB = 224, K1G_ROWS = 288;
-constexpr int K3G_DZV = 0, K3G_DZ2 = 32, K3G_DZ1 = 160, K3G_DF = 288, K3G_ROWS = 320;
+constexpr int K1G_DZ3 = 0, K1G_DZ4 = 64, K1G_SM = 128, K1G_DZD = 160, K1G_DZB = 224, K1G_DFD = 288,
+              K1G_DFB = 384, K1G_DX0 = 480, K1G_ROWS = 544;  // DFD/DFB: d(features) rows for the scatter kernel
+constexpr int K3G_DZV = 0, K3G_DZ2 = 32, K3G_DZ1 = 160, K3G_DF = 288, K3G_DA = 320, K3G_ROWS = 544;
 constexpr int SFG_DZ6 = 0, SFG_DZ4 = 32, SFG_DZ2 = 96, SFG_DZ0 = 160, SFG_ROWS = 224;
 }  // namespace sv
 
