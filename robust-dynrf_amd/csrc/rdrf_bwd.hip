@@ -107,32 +107,47 @@ struct DynG {
 // ------------------------------------------------------------------------------------------------
 // VM gather backward for one quad: scatter into plane / line (atomics) + coordinate gradients
 // ------------------------------------------------------------------------------------------------
+// DPP lane movement (VALU rate, no LDS crossbar).  ctrl: quad_perm 0x00-0xFF, row_shr:n 0x110+n,
+// wave_shr:1 0x138, row_bcast:15 0x142.  Lanes without a valid source read 0.
+template <int CTRL, int ROW_MASK = 0xF>
+RDRF_D float dppf(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+RDRF_D int dppi(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+
 // fp32 atomics on MI355X: the L2 retires ~20 G atomic REQUESTS/s, where a request is one
 // (instruction, <=64-byte line) pair -- not one lane (tools/ubench/atomics.hip: one component per
 // lane per instruction 20 G updates/s; 4 adjacent lanes covering a 16-byte quad 83 G/s; 16 lanes on
-// a 64-byte texel 322 G/s).  So a quad is never sent as 4 instructions x 1 component: the wave
-// transposes through the lane crossbar so that lanes 4t..4t+3 carry components 0..3 of source lane
-// t's quad, and 4 instructions then cover all 64 lanes' quads with one request per quad.
+// a 64-byte texel 322 G/s).  So a quad is never sent as 4 instructions x 1 component: each group of
+// 4 adjacent lanes transposes its 4 quads with quad_perm DPP broadcasts, so that instruction k
+// carries, in lanes 4t..4t+3, components 0..3 of lane 4t+k's quad: one request per live quad.
 // Must be called by ALL lanes of the wave (uniform control flow); `ok` gates the lane's quad.
+template <int K>
+RDRF_D void atomic_quad_k(unsigned plo, unsigned phi, f32x4 v, int oki, int c) {
+  constexpr int QP = K * 0x55;  // quad_perm:[K,K,K,K]
+  const int o = dppi<QP>(oki);
+  if (__ballot(o != 0) == 0ull) return;
+  const float a0 = dppf<QP>(v.x), a1 = dppf<QP>(v.y), a2 = dppf<QP>(v.z), a3 = dppf<QP>(v.w);
+  const unsigned lo = (unsigned)dppi<QP>((int)plo), hi = (unsigned)dppi<QP>((int)phi);
+  const float val = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+  if (o) atomicAdd((float*)(((unsigned long long)hi << 32) | lo) + c, val);
+}
 RDRF_D void atomic_add4(float* p, f32x4 v, bool ok) {
 #if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOGLOBAL)
   return;
 #endif
-  const unsigned long long any = __ballot(ok);
-  if (any == 0ull) return;
-  const int lane = threadIdx.x & 63, c = lane & 3;
+  if (__ballot(ok) == 0ull) return;
+  const int c = threadIdx.x & 3;
   const unsigned long long pa = (unsigned long long)p;
   const unsigned plo = (unsigned)pa, phi = (unsigned)(pa >> 32);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (((any >> (16 * k)) & 0xffffull) == 0ull) continue;  // no live quad in these 16 lanes
-    const int src = 16 * k + (lane >> 2);
-    const float a0 = __shfl(v.x, src, 64), a1 = __shfl(v.y, src, 64);
-    const float a2 = __shfl(v.z, src, 64), a3 = __shfl(v.w, src, 64);
-    const unsigned lo = __shfl(plo, src, 64), hi = __shfl(phi, src, 64);
-    const float val = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-    if ((any >> src) & 1ull) atomicAdd((float*)(((unsigned long long)hi << 32) | lo) + c, val);
-  }
+  const int oki = ok ? 1 : 0;
+  atomic_quad_k<0>(plo, phi, v, oki, c);
+  atomic_quad_k<1>(plo, phi, v, oki, c);
+  atomic_quad_k<2>(plo, phi, v, oki, c);
+  atomic_quad_k<3>(plo, phi, v, oki, c);
 }
 RDRF_D float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -146,7 +161,7 @@ struct Run {
   bool tail;   // this lane is the last of its run
 };
 RDRF_D Run run_of(int key, int s) {
-  const int prev = __shfl_up(key, 1, 32);
+  const int prev = dppi<0x138>(key);  // wave_shr:1
   const bool head = (s == 0) || (prev != key);
   const unsigned long long b = __ballot(head);
   const unsigned m = (unsigned)(b >> (32 * ((threadIdx.x & 63) >> 5)));
@@ -155,15 +170,29 @@ RDRF_D Run run_of(int key, int s) {
   r.tail = (s == 31) || ((m >> (s + 1)) & 1u);
   return r;
 }
+// inclusive segmented scan over the 32 lanes of a half-wave, entirely in DPP: four row_shr steps
+// inside each 16-lane row, then lane 15's row total is added to the lanes of the next row whose
+// run started at or before lane 15 (row_bcast:15, written to rows 1 and 3 only).
 RDRF_D f32x4 run_scan4(f32x4 v, int start, int s) {
 #ifdef RDRF_ABL_NOSCAN
   return v;
 #endif
-#pragma unroll
-  for (int d = 1; d < 32; d <<= 1) {
-    const float ox = __shfl_up(v.x, d, 32), oy = __shfl_up(v.y, d, 32);
-    const float oz = __shfl_up(v.z, d, 32), ow = __shfl_up(v.w, d, 32);
-    if (s - d >= start) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }
+  const int sr = s & 15;
+#define RDRF_SCAN_STEP(D)                                                                   \
+  {                                                                                         \
+    const float ox = dppf<0x110 + D>(v.x), oy = dppf<0x110 + D>(v.y);                       \
+    const float oz = dppf<0x110 + D>(v.z), ow = dppf<0x110 + D>(v.w);                       \
+    if (sr >= D && s - D >= start) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }          \
+  }
+  RDRF_SCAN_STEP(1)
+  RDRF_SCAN_STEP(2)
+  RDRF_SCAN_STEP(4)
+  RDRF_SCAN_STEP(8)
+#undef RDRF_SCAN_STEP
+  {
+    const float ox = dppf<0x142, 0xA>(v.x), oy = dppf<0x142, 0xA>(v.y);
+    const float oz = dppf<0x142, 0xA>(v.z), ow = dppf<0x142, 0xA>(v.w);
+    if (s >= 16 && start <= 15) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }
   }
   return v;
 }
