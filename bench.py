@@ -198,7 +198,8 @@ def main():
             rays = trainer.rays_for(ids)
             ts = trainer.data.ts_of(ids)
             o_s, o_d, _, _ = S_.ray_pass(trainer.st, trainer.dy, rays, ts, cfg["n_samples"], cfg["ray_type"])
-            valid_frac = float((o_d[7] >= 0).float().mean())  # all samples processed by the density phase
+            _, _, vmask = S_.sampleXYZ(trainer.dy, rays, cfg["n_samples"], ray_type=cfg["ray_type"], is_train=True)
+            valid_frac = float(vmask.float().mean())
             f_d = float((o_d[4] > 1e-4).float().mean())
             f_s = float((o_s[4] > 1e-4).float().mean())
         L.lib.rdrf_prof_enable(1)
