@@ -10,7 +10,7 @@ for tag in ("fetch", "write", "mfma"):
         rd = csv.DictReader(f)
         for r in rd:
             k = r.get("Kernel_Name", "?")
-            k = k.split("(")[0]
+            k = k.split("(")[0].replace(",", ";")
             c = r.get("Counter_Name"); v = float(r.get("Counter_Value", 0) or 0)
             a = acc[k][c]; a[0] += v; a[1] += 1
     with open(os.path.join(out, f"pmc_{tag}.csv"), "w") as f:
