@@ -208,32 +208,55 @@ struct LdsLines {
   float* base;   // LDS accumulator (nullptr: scatter straight to global memory)
   int off[3];    // float offset of line 0/1/2 inside it
 };
-RDRF_D void lds_add4(float* p, f32x4 v) {
+// LDS accumulator layout: entry l of a line with C components starts at l*(C+4): with the natural
+// stride (16 floats for C=16) every entry maps to the same two banks and a z-line update (32 distinct
+// entries per half-wave) serialises ~16-fold; stride 20 (and 52 for C=48) walks all eight 4-bank
+// sets.  Updates use the same quad transposition as the global atomics (4 adjacent lanes = 4
+// adjacent banks).
+RDRF_D int lds_stride(int C) { return C + 4; }
+template <int K>
+RDRF_D void lds_quad_k(int addr, f32x4 v, int oki, int c, float* base) {
+  constexpr int QP = K * 0x55;
+  const int o = dppi<QP>(oki);
+  if (__ballot(o != 0) == 0ull) return;
+  const float a0 = dppf<QP>(v.x), a1 = dppf<QP>(v.y), a2 = dppf<QP>(v.z), a3 = dppf<QP>(v.w);
+  const int ad = dppi<QP>(addr);
+  const float val = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+  if (o) atomicAdd(base + ad + c, val);
+}
+// all lanes of the wave must call; `addr` = float offset of the lane's quad inside `base`
+RDRF_D void lds_add4(float* base, int addr, f32x4 v, bool ok) {
 #if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOLDS)
   return;
 #endif
-  atomicAdd(p + 0, v.x);
-  atomicAdd(p + 1, v.y);
-  atomicAdd(p + 2, v.z);
-  atomicAdd(p + 3, v.w);
+  if (__ballot(ok) == 0ull) return;
+  const int c = threadIdx.x & 3, oki = ok ? 1 : 0;
+  lds_quad_k<0>(addr, v, oki, c, base);
+  lds_quad_k<1>(addr, v, oki, c, base);
+  lds_quad_k<2>(addr, v, oki, c, base);
+  lds_quad_k<3>(addr, v, oki, c, base);
 }
-RDRF_D int lines_floats(const RdrfVM& vm) { return vm.L[0] * vm.C[0] + vm.L[1] * vm.C[1] + vm.L[2] * vm.C[2]; }
+RDRF_D int lines_floats(const RdrfVM& vm) {
+  return vm.L[0] * lds_stride(vm.C[0]) + vm.L[1] * lds_stride(vm.C[1]) + vm.L[2] * lds_stride(vm.C[2]);
+}
 RDRF_D LdsLines make_lds_lines(float* base, const RdrfVM& vm) {
   LdsLines l;
   l.base = base;
   l.off[0] = 0;
-  l.off[1] = vm.L[0] * vm.C[0];
-  l.off[2] = l.off[1] + vm.L[1] * vm.C[1];
+  l.off[1] = vm.L[0] * lds_stride(vm.C[0]);
+  l.off[2] = l.off[1] + vm.L[1] * lds_stride(vm.C[1]);
   return l;
 }
 RDRF_D void flush_lds_lines(const float* acc, const RdrfVM& vm, const RdrfVM& gvm) {
-  const int n0 = vm.L[0] * vm.C[0], n1 = vm.L[1] * vm.C[1], n2 = vm.L[2] * vm.C[2];
-  for (int i = threadIdx.x; i < n0 + n1 + n2; i += blockDim.x) {
-    const float v = acc[i];
-    if (v != 0.f) {
-      float* dst = i < n0 ? gvm.line[0] + i : (i < n0 + n1 ? gvm.line[1] + (i - n0) : gvm.line[2] + (i - n0 - n1));
-      atomicAdd(dst, v);
+  int base = 0;
+  for (int li = 0; li < 3; ++li) {
+    const int C = vm.C[li], st = lds_stride(C), n = vm.L[li] * C;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int l = i / C, c = i - l * C;
+      const float v = acc[base + l * st + c];
+      if (v != 0.f) atomicAdd(gvm.line[li] + i, v);
     }
+    base += vm.L[li] * st;
   }
 }
 
@@ -315,15 +338,16 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     atomic_add4(GP + o11, r, pr.tail && g11 && nz4(r));
     const Run lr = run_of(tl.i0 + 4, s);
     float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
+    const int lst = lds_stride(C);
     r = run_scan4(m0 ? dl * tl.w0 : zero, lr.start, s);
     {
       const bool okl = lr.tail && tl.ok0 && nz4(r);
-      if (LL) { if (okl) lds_add4(LL + l0, r); } else atomic_add4(GL + l0, r, okl);
+      if (LL) lds_add4(LL, (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL + l0, r, okl);
     }
     r = run_scan4(m1 ? dl * tl.w1 : zero, lr.start, s);
     {
       const bool okl = lr.tail && tl.ok1 && nz4(r);
-      if (LL) { if (okl) lds_add4(LL + l1, r); } else atomic_add4(GL + l1, r, okl);
+      if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL + l1, r, okl);
     }
   }
   // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
