@@ -326,16 +326,37 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     // the run); the run's last lane issues the atomics whatever its own liveness.
     const bool g00 = ty.ok0 && tx.ok0, g01 = ty.ok0 && tx.ok1, g10 = ty.ok1 && tx.ok0,
                g11 = ty.ok1 && tx.ok1;
-    const Run pr = run_of(((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff), s);
+    const int pkey = ((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff);
+    const Run pr = run_of(pkey, s);
+    f32x4 r00 = run_scan4(k00 ? dp * (tx.w0 * ty.w0) : zero, pr.start, s);
+    f32x4 r01 = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pr.start, s);
+    const f32x4 r10 = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pr.start, s);
+    const f32x4 r11 = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s);
+    // cross-run merge along the row axis: a run at row iy writes its UPPER taps to row iy+1, which
+    // is where the next run (row iy+1, same column) writes its LOWER taps.  The lower sums absorb
+    // the previous run's upper sums and the previous run skips that write: two atomic requests
+    // per chained run instead of four (the ray-marching axis advances ~one texel per sample).
+    bool up_ok = true;
+    if (pi != 0) {
+      const int pl = pr.start > 0 ? pr.start - 1 : 0;           // tail lane of the previous run
+      const int pk = __shfl(pkey, pl, 32);
+      const bool chain_prev = pr.start > 0 && pk == pkey - (1 << 16);
+      const float ux = __shfl(r10.x, pl, 32), uy = __shfl(r10.y, pl, 32), uz = __shfl(r10.z, pl, 32),
+                  uw = __shfl(r10.w, pl, 32);
+      const float vx_ = __shfl(r11.x, pl, 32), vy_ = __shfl(r11.y, pl, 32), vz_ = __shfl(r11.z, pl, 32),
+                  vw_ = __shfl(r11.w, pl, 32);
+      if (chain_prev) {
+        r00.x += ux; r00.y += uy; r00.z += uz; r00.w += uw;
+        r01.x += vx_; r01.y += vy_; r01.z += vz_; r01.w += vw_;
+      }
+      const int nk = dppi<0x130>(pkey);  // wave_shl:1 -> key of lane s+1
+      up_ok = !(s < 31 && nk == pkey + (1 << 16));
+    }
     f32x4 r;
-    r = run_scan4(k00 ? dp * (tx.w0 * ty.w0) : zero, pr.start, s);
-    atomic_add4(GP + o00, r, pr.tail && g00 && nz4(r));
-    r = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pr.start, s);
-    atomic_add4(GP + o01, r, pr.tail && g01 && nz4(r));
-    r = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pr.start, s);
-    atomic_add4(GP + o10, r, pr.tail && g10 && nz4(r));
-    r = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s);
-    atomic_add4(GP + o11, r, pr.tail && g11 && nz4(r));
+    atomic_add4(GP + o00, r00, pr.tail && g00 && nz4(r00));
+    atomic_add4(GP + o01, r01, pr.tail && g01 && nz4(r01));
+    atomic_add4(GP + o10, r10, pr.tail && up_ok && g10 && nz4(r10));
+    atomic_add4(GP + o11, r11, pr.tail && up_ok && g11 && nz4(r11));
     const Run lr = run_of(tl.i0 + 4, s);
     float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
     const int lst = lds_stride(C);
