@@ -35,6 +35,27 @@ __global__ void kC(float* buf, unsigned ntex, int iters) {
     }
   }
 }
+// E: like B but only every 4th quad is live (16 of 64 lanes active): same instruction count as B,
+// 4x fewer requests.  E ~ B  => bound by atomic INSTRUCTION issue; E ~ B/4 => bound by requests.
+__global__ void kE(float* buf, unsigned ntex, int iters) {
+  unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < iters; ++i) {
+    for (int k = 0; k < 4; ++k) {
+      unsigned tex = hash(((t >> 2) * 4 + k) * 977u + i) % ntex;
+      if (((t >> 2) & 3) == 0) atomicAdd(buf + (size_t)tex * 4 + (t & 3), 1.f);
+    }
+  }
+}
+// F: like B with only ONE quad live per instruction (4 lanes)
+__global__ void kF(float* buf, unsigned ntex, int iters) {
+  unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < iters; ++i) {
+    for (int k = 0; k < 4; ++k) {
+      unsigned tex = hash(((t >> 2) * 4 + k) * 977u + i) % ntex;
+      if (((t >> 2) & 15) == 0) atomicAdd(buf + (size_t)tex * 4 + (t & 3), 1.f);
+    }
+  }
+}
 // D: A without atomics (plain read-modify-write, racy) as a bandwidth reference
 __global__ void kD(float* buf, unsigned ntex, int iters) {
   unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +73,7 @@ int main() {
     const int blocks = 2048, threads = 256, iters = 16;
     const double natom = (double)blocks * threads * iters * 4;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int kind = 0; kind < 4; ++kind) {
+    for (int kind = 0; kind < 6; ++kind) {
       float best = 1e9;
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
@@ -60,10 +81,12 @@ int main() {
         if (kind == 1) kB<<<blocks, threads>>>(buf, ntex, iters);
         if (kind == 2) kC<<<blocks, threads>>>(buf, ntex, iters);
         if (kind == 3) kD<<<blocks, threads>>>(buf, ntex, iters);
+        if (kind == 4) kE<<<blocks, threads>>>(buf, ntex, iters);
+        if (kind == 5) kF<<<blocks, threads>>>(buf, ntex, iters);
         hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
       }
-      printf("ntex %8u  kernel %c  %.3f ms  %.1f G scalar-updates/s\n", ntex, "ABCD"[kind], best, natom / best / 1e6);
+      printf("ntex %8u  kernel %c  %.3f ms  %.1f G scalar-updates/s (if all lanes live)  %.2f G wave-instr/s\n", ntex, "ABCDEF"[kind], best, natom / best / 1e6, natom / 64.0 / best / 1e6);
     }
     CHECK(hipFree(buf));
   }
