@@ -109,45 +109,57 @@ struct DynG {
 // ------------------------------------------------------------------------------------------------
 // DPP lane movement (VALU rate, no LDS crossbar).  ctrl: quad_perm 0x00-0xFF, row_shr:n 0x110+n,
 // wave_shr:1 0x138, row_bcast:15 0x142.  Lanes without a valid source read 0.
+// bound_ctrl:1 makes lanes without a valid source read 0 WITHOUT a `v_mov dst, 0` preload, and lets
+// LLVM's DPP combiner fold the move into the consuming v_add / v_cndmask (one VALU op per step).
 template <int CTRL, int ROW_MASK = 0xF>
 RDRF_D float dppf(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  if constexpr (ROW_MASK == 0xF)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+  else  // masked rows keep `old`: pass the lane's own value so that no zero has to be materialised
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
 template <int CTRL, int ROW_MASK = 0xF>
 RDRF_D int dppi(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+  if constexpr (ROW_MASK == 0xF)
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+  else
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
 }
 
 // fp32 atomics on MI355X: the L2 retires ~20 G atomic REQUESTS/s, where a request is one
 // (instruction, <=64-byte line) pair -- not one lane (tools/ubench/atomics.hip: one component per
 // lane per instruction 20 G updates/s; 4 adjacent lanes covering a 16-byte quad 83 G/s; 16 lanes on
 // a 64-byte texel 322 G/s).  So a quad is never sent as 4 instructions x 1 component: each group of
-// 4 adjacent lanes transposes its 4 quads with quad_perm DPP broadcasts, so that instruction k
-// carries, in lanes 4t..4t+3, components 0..3 of lane 4t+k's quad: one request per live quad.
-// Must be called by ALL lanes of the wave (uniform control flow); `ok` gates the lane's quad.
+// 4 adjacent lanes transposes its 4x4 (lane x component) block with two rounds of quad_perm
+// exchanges (8 v_cndmask_dpp), so that instruction k carries, in lanes 4t..4t+3, components 0..3 of
+// lane 4t+k's quad: one request per live quad.  `off` = float offset from `base` (uniform over the
+// 4-lane group; 0xffffffff = nothing to add).  Must be called by ALL lanes of the wave.
 template <int K>
-RDRF_D void atomic_quad_k(unsigned plo, unsigned phi, f32x4 v, int oki, int c) {
+RDRF_D void atomic_quad_k(float* base, unsigned off, float val, int c) {
   constexpr int QP = K * 0x55;  // quad_perm:[K,K,K,K]
-  const int o = dppi<QP>(oki);
-  if (__ballot(o != 0) == 0ull) return;
-  const float a0 = dppf<QP>(v.x), a1 = dppf<QP>(v.y), a2 = dppf<QP>(v.z), a3 = dppf<QP>(v.w);
-  const unsigned lo = (unsigned)dppi<QP>((int)plo), hi = (unsigned)dppi<QP>((int)phi);
-  const float val = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-  if (o) atomicAdd((float*)(((unsigned long long)hi << 32) | lo) + c, val);
+  const unsigned o = (unsigned)dppi<QP>((int)off);
+  if (__ballot(o != 0xffffffffu) == 0ull) return;
+  if (o != 0xffffffffu) atomicAdd(base + (size_t)o + c, val);
 }
-RDRF_D void atomic_add4(float* p, f32x4 v, bool ok) {
+RDRF_D void atomic_add4(float* p_base, size_t p_off, f32x4 v, bool ok) {
 #if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOGLOBAL)
   return;
 #endif
   if (__ballot(ok) == 0ull) return;
-  const int c = threadIdx.x & 3;
-  const unsigned long long pa = (unsigned long long)p;
-  const unsigned plo = (unsigned)pa, phi = (unsigned)(pa >> 32);
-  const int oki = ok ? 1 : 0;
-  atomic_quad_k<0>(plo, phi, v, oki, c);
-  atomic_quad_k<1>(plo, phi, v, oki, c);
-  atomic_quad_k<2>(plo, phi, v, oki, c);
-  atomic_quad_k<3>(plo, phi, v, oki, c);
+  const int lane = threadIdx.x, c = lane & 3;
+  const bool a = lane & 1, b = lane & 2;
+  // round 1: 2x2 blocks between lanes i and i^1   (quad_perm [1,0,3,2] = 0xB1)
+  // (DPP moves are convergent: issue them for ALL lanes, select afterwards)
+  const float px = dppf<0xB1>(v.x), py = dppf<0xB1>(v.y), pz = dppf<0xB1>(v.z), pw = dppf<0xB1>(v.w);
+  const float n0 = a ? py : v.x, n1 = a ? v.y : px, n2 = a ? pw : v.z, n3 = a ? v.w : pz;
+  // round 2: between lanes i and i^2               (quad_perm [2,3,0,1] = 0x4E)
+  const float q0 = dppf<0x4E>(n0), q1 = dppf<0x4E>(n1), q2 = dppf<0x4E>(n2), q3 = dppf<0x4E>(n3);
+  const float t0 = b ? q2 : n0, t1 = b ? q3 : n1, t2 = b ? n2 : q0, t3 = b ? n3 : q1;
+  const unsigned off = ok ? (unsigned)p_off : 0xffffffffu;
+  atomic_quad_k<0>(p_base, off, t0, c);
+  atomic_quad_k<1>(p_base, off, t1, c);
+  atomic_quad_k<2>(p_base, off, t2, c);
+  atomic_quad_k<3>(p_base, off, t3, c);
 }
 RDRF_D float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -182,7 +194,9 @@ RDRF_D f32x4 run_scan4(f32x4 v, int start, int s) {
   {                                                                                         \
     const float ox = dppf<0x110 + D>(v.x), oy = dppf<0x110 + D>(v.y);                       \
     const float oz = dppf<0x110 + D>(v.z), ow = dppf<0x110 + D>(v.w);                       \
-    if (sr >= D && s - D >= start) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }          \
+    const bool take = sr >= D && s - D >= start;                                            \
+    const float tx_ = v.x + ox, ty_ = v.y + oy, tz_ = v.z + oz, tw_ = v.w + ow;             \
+    v.x = take ? tx_ : v.x; v.y = take ? ty_ : v.y; v.z = take ? tz_ : v.z; v.w = take ? tw_ : v.w; \
   }
   RDRF_SCAN_STEP(1)
   RDRF_SCAN_STEP(2)
@@ -192,7 +206,9 @@ RDRF_D f32x4 run_scan4(f32x4 v, int start, int s) {
   {
     const float ox = dppf<0x142, 0xA>(v.x), oy = dppf<0x142, 0xA>(v.y);
     const float oz = dppf<0x142, 0xA>(v.z), ow = dppf<0x142, 0xA>(v.w);
-    if (s >= 16 && start <= 15) { v.x += ox; v.y += oy; v.z += oz; v.w += ow; }
+    const bool take = s >= 16 && start <= 15;
+    const float tx_ = v.x + ox, ty_ = v.y + oy, tz_ = v.z + oz, tw_ = v.w + ow;
+    v.x = take ? tx_ : v.x; v.y = take ? ty_ : v.y; v.z = take ? tz_ : v.z; v.w = take ? tw_ : v.w;
   }
   return v;
 }
@@ -215,14 +231,11 @@ struct LdsLines {
 // adjacent banks).
 RDRF_D int lds_stride(int C) { return C + 4; }
 template <int K>
-RDRF_D void lds_quad_k(int addr, f32x4 v, int oki, int c, float* base) {
+RDRF_D void lds_quad_k(float* base, int addr, float val, int c) {
   constexpr int QP = K * 0x55;
-  const int o = dppi<QP>(oki);
-  if (__ballot(o != 0) == 0ull) return;
-  const float a0 = dppf<QP>(v.x), a1 = dppf<QP>(v.y), a2 = dppf<QP>(v.z), a3 = dppf<QP>(v.w);
   const int ad = dppi<QP>(addr);
-  const float val = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-  if (o) atomicAdd(base + ad + c, val);
+  if (__ballot(ad >= 0) == 0ull) return;
+  if (ad >= 0) atomicAdd(base + ad + c, val);
 }
 // all lanes of the wave must call; `addr` = float offset of the lane's quad inside `base`
 RDRF_D void lds_add4(float* base, int addr, f32x4 v, bool ok) {
@@ -230,11 +243,18 @@ RDRF_D void lds_add4(float* base, int addr, f32x4 v, bool ok) {
   return;
 #endif
   if (__ballot(ok) == 0ull) return;
-  const int c = threadIdx.x & 3, oki = ok ? 1 : 0;
-  lds_quad_k<0>(addr, v, oki, c, base);
-  lds_quad_k<1>(addr, v, oki, c, base);
-  lds_quad_k<2>(addr, v, oki, c, base);
-  lds_quad_k<3>(addr, v, oki, c, base);
+  const int lane = threadIdx.x, c = lane & 3;
+  const bool a = lane & 1, b = lane & 2;
+  // (DPP moves are convergent: issue them for ALL lanes, select afterwards)
+  const float px = dppf<0xB1>(v.x), py = dppf<0xB1>(v.y), pz = dppf<0xB1>(v.z), pw = dppf<0xB1>(v.w);
+  const float n0 = a ? py : v.x, n1 = a ? v.y : px, n2 = a ? pw : v.z, n3 = a ? v.w : pz;
+  const float q0 = dppf<0x4E>(n0), q1 = dppf<0x4E>(n1), q2 = dppf<0x4E>(n2), q3 = dppf<0x4E>(n3);
+  const float t0 = b ? q2 : n0, t1 = b ? q3 : n1, t2 = b ? n2 : q0, t3 = b ? n3 : q1;
+  const int ad = ok ? addr : -1;
+  lds_quad_k<0>(base, ad, t0, c);
+  lds_quad_k<1>(base, ad, t1, c);
+  lds_quad_k<2>(base, ad, t2, c);
+  lds_quad_k<3>(base, ad, t3, c);
 }
 RDRF_D int lines_floats(const RdrfVM& vm) {
   return vm.L[0] * lds_stride(vm.C[0]) + vm.L[1] * lds_stride(vm.C[1]) + vm.L[2] * lds_stride(vm.C[2]);
@@ -314,12 +334,12 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   const f32x4 dp = live ? dq * lvv : zero;  // grad wrt the interpolated plane quad
   const f32x4 dl = live ? dq * pv : zero;   // grad wrt the interpolated line quad
   if (MODE == 0) {
-    atomic_add4(GP + o00, dp * (tx.w0 * ty.w0), k00);
-    atomic_add4(GP + o01, dp * (tx.w1 * ty.w0), k01);
-    atomic_add4(GP + o10, dp * (tx.w0 * ty.w1), k10);
-    atomic_add4(GP + o11, dp * (tx.w1 * ty.w1), k11);
-    atomic_add4(GL + l0, dl * tl.w0, m0);
-    atomic_add4(GL + l1, dl * tl.w1, m1);
+    atomic_add4(GP, o00, dp * (tx.w0 * ty.w0), k00);
+    atomic_add4(GP, o01, dp * (tx.w1 * ty.w0), k01);
+    atomic_add4(GP, o10, dp * (tx.w0 * ty.w1), k10);
+    atomic_add4(GP, o11, dp * (tx.w1 * ty.w1), k11);
+    atomic_add4(GL, l0, dl * tl.w0, m0);
+    atomic_add4(GL, l1, dl * tl.w1, m1);
   } else {
     // the quad / plane selection is uniform over a half-wave, so the (iy, ix) pair keys the run.
     // Keys are purely geometric (a dead sample inside a run contributes zeros, it must not split
@@ -353,22 +373,22 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
       up_ok = !(s < 31 && nk == pkey + (1 << 16));
     }
     f32x4 r;
-    atomic_add4(GP + o00, r00, pr.tail && g00 && nz4(r00));
-    atomic_add4(GP + o01, r01, pr.tail && g01 && nz4(r01));
-    atomic_add4(GP + o10, r10, pr.tail && up_ok && g10 && nz4(r10));
-    atomic_add4(GP + o11, r11, pr.tail && up_ok && g11 && nz4(r11));
+    atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00));
+    atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01));
+    atomic_add4(GP, o10, r10, pr.tail && up_ok && g10 && nz4(r10));
+    atomic_add4(GP, o11, r11, pr.tail && up_ok && g11 && nz4(r11));
     const Run lr = run_of(tl.i0 + 4, s);
     float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
     const int lst = lds_stride(C);
     r = run_scan4(m0 ? dl * tl.w0 : zero, lr.start, s);
     {
       const bool okl = lr.tail && tl.ok0 && nz4(r);
-      if (LL) lds_add4(LL, (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL + l0, r, okl);
+      if (LL) lds_add4(LL, (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL, l0, r, okl);
     }
     r = run_scan4(m1 ? dl * tl.w1 : zero, lr.start, s);
     {
       const bool okl = lr.tail && tl.ok1 && nz4(r);
-      if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL + l1, r, okl);
+      if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, l1, r, okl);
     }
   }
   // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
@@ -771,7 +791,10 @@ __global__ __launch_bounds__(256, 3) void k_scatter(ScatterArgs a) {
     for (int set = 0; set < a.nsets; ++set) {
       const float* rb = a.rows + ((size_t)t * a.stride + a.row0[set]) * 32;
       const LdsLines ll = make_lds_lines(use_lacc ? lacc + (set ? nl0 : 0) : nullptr, a.vm[set]);
-#pragma unroll
+#ifndef RDRF_SC_UNROLL
+#define RDRF_SC_UNROLL 1
+#endif
+#pragma unroll RDRF_SC_UNROLL
       for (int o = 0; o < NQ; ++o) {
         const float* rq = rb + (size_t)(8 * o + 4 * h) * 32 + s;
         const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
