@@ -242,6 +242,21 @@ def main():
             "sum_kernel_ms_per_step": tot_ms,
             "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s},
         }
+        # SURVEY.md section 8(d) canonical constants: per sample B_fwd(f) = 4032 + 6912 f bytes,
+        # F_fwd(f) = 66004 + 145362 f FLOP (f = app-mask fraction averaged over both fields); one
+        # training ray-pass = S * (4 B_fwd, 3 F_fwd); training ray = 5 ray-passes (Nvidia.txt).
+        f_avg = 0.5 * (f_d + f_s)
+        Sn = cfg["n_samples"]
+        F_ray = 5 * Sn * 3 * (66004 + 145362 * f_avg)
+        B_ray = 5 * Sn * 4 * (4032 + 6912 * f_avg)
+        t_meas = ms * 1e-3 / args.rays_per_gpu
+        t_star = max(F_ray / (PEAK_F32_MFMA_TFLOPS * 1e12), B_ray / 8e12)
+        out["roofline"]["survey_canonical"] = {
+            "f_app": f_avg, "flop_per_training_ray": F_ray, "gather_bytes_per_training_ray": B_ray,
+            "achieved": t_star / t_meas, "frac_flop": F_ray / (PEAK_F32_MFMA_TFLOPS * 1e12 * t_meas),
+            "frac_bytes": B_ray / (8e12 * t_meas),
+            "note": "SURVEY 8(d) constants with 5 ray-passes per training ray; gather bytes are "
+                    "L2/MALL-resident algorithmic bytes, not HBM traffic"}
     if rank == 0 and not args.no_render:
         # secondary metric of BASELINE.json: render Mpix/s -- whole 240x135 frames through the
         # no-grad chunk loop of renderer.py:740-812 (one C-ABI call per chunk of 8192 rays)

@@ -1229,12 +1229,22 @@ __global__ __launch_bounds__(256) void k_dw(DwJobs jobs) {
     const float* ap = J.A + ((size_t)t * J.A_stride + J.A_row0 + bo * 32 + li) * 32 + h * 16;
     const float* bbase = J.B + ((size_t)t * J.B_stride + li) * 32 + h * 16;
     f32x4 av4[4], bv4[4][4];
+#ifdef RDRF_ABL_DW_NOLOAD
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av4[q] = f32x4{(float)t, 1.f, 2.f, (float)q};
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv4[b][q] = f32x4{(float)t, (float)b, 2.f, (float)q};
+    (void)ap; (void)bbase;
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) av4[q] = ld4(ap + q * 4);
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv4[b][q] = ld4(bbase + (size_t)brow[b] * 32 + q * 4);
+#endif
     if (grp == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bsum += av4[q].x + av4[q].y + av4[q].z + av4[q].w;
@@ -1244,10 +1254,14 @@ __global__ __launch_bounds__(256) void k_dw(DwJobs jobs) {
       if (b < nb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#ifdef RDRF_ABL_DW_NOMFMA
+          acc[b][q] += av4[q].x * bv4[b][q].x + av4[q].y * bv4[b][q].y + av4[q].z * bv4[b][q].z + av4[q].w * bv4[b][q].w;
+#else
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].x, bv4[b][q].x, acc[b], 0, 0, 0);
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].y, bv4[b][q].y, acc[b], 0, 0, 0);
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].z, bv4[b][q].z, acc[b], 0, 0, 0);
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].w, bv4[b][q].w, acc[b], 0, 0, 0);
+#endif
         }
       }
     }
