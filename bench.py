@@ -34,6 +34,29 @@ F_DYN_APP = 11664 + 60946                  # basis + late-view head
 F_STAT_APP = 72752                         # basis + MLP_Fea head
 F_SCENE_FLOW = 21760
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak (~6.3 TB/s achievable)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (tools/profile.sh -> profiles/r01_pmc_{fetch,write}.csv; FETCH_SIZE / WRITE_SIZE are KB, and on
+    gfx950 FETCH_SIZE under-reports 16 B/lane streaming reads by 2x: MI355X_MICROARCH.md, HBM).
+    None when the profile is absent."""
+    import csv
+    tot = 0.0
+    for tag, ctr, corr in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
+        fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_{tag}.csv")
+        if not os.path.exists(fn):
+            return None
+        got = None
+        for line in open(fn).read().splitlines()[1:]:
+            parts = line.rsplit(",", 4)
+            if len(parts) == 5 and parts[0] == kernel and parts[1] == ctr:
+                got = float(parts[3])
+        if got is None:
+            return None
+        tot += got * 1024.0 * corr
+    return tot
 
 
 def prof_get(L, name):
@@ -228,14 +251,29 @@ def main():
                 table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}
                 tot_ms += msk / NP
         L.lib.rdrf_prof_enable(0)
-        dom = max((k for k in table if k in flops), key=lambda k: table[k]["ms_per_step"])
-        avg_s = table[dom]["avg_us"] * 1e-6
-        ach = flops[dom] / avg_s / 1e12
         step_flops = sum(flops[k] * table[k]["launches_per_step"] for k in table if k in flops)
+        # Dominant kernel = k_dw (weight-gradient GEMMs; launches dw_dyn / dw_static / dw_sf).  It
+        # streams the saved activation rows and the d(pre-activation) rows of every 32-sample tile
+        # exactly once per (out-block, in-group) item and is HBM-bound (ablation in DESIGN.md s9:
+        # loads only 4.15 ms, MFMA only 3.34 ms, both 5.0 ms per step): its roofline is bytes.
+        # Algorithmic bytes = UNIQUE rows the jobs read x 128 B (rows are [32 samples] fp32).
+        t1 = args.rays_per_gpu * ((cfg["n_samples"] + 31) // 32)
+        t3d, t3s = (ns * f_d + 31) // 32, (ns * f_s + 31) // 32
+        dw_bytes = {"dw_dyn": (864 * t1 + 960 * t3d) * 128.0, "dw_static": 864 * t3s * 128.0,
+                    "dw_sf": 480 * t1 * 128.0}
+        dw_keys = [k for k in dw_bytes if k in table]
+        dw_launch = sum(table[k]["launches_per_step"] for k in dw_keys)
+        dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
+        dw_b = sum(dw_bytes[k] * table[k]["launches_per_step"] for k in dw_keys)
+        dw_f = sum(flops[k] * table[k]["launches_per_step"] for k in dw_keys)
+        ach_gbs = dw_b / (dw_ms * 1e-3) / 1e9
         out["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom,
-            "kernel_avg_us": table[dom]["avg_us"], "algorithmic_flop_per_launch": flops[dom],
+            "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach_gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("k_dw"), "kernel": "k_dw",
+            "kernel_avg_us": dw_ms / dw_launch * 1e3, "launches_per_step": dw_launch,
+            "algorithmic_bytes_per_launch": dw_b / dw_launch,
+            "mfma": {"achieved_tflops": dw_f / (dw_ms * 1e-3) / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
+                     "frac": dw_f / (dw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
             "step_algorithmic_tflop": step_flops / 1e12,
             "step_frac_of_peak": step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in table.items()},
