@@ -169,7 +169,7 @@ def main():
     cfg["batch_size"] = args.rays_per_gpu * world   # weak scaling: fixed rays per GPU
     trainer = S_.Trainer(cfg, dev, weights=args.weights)
     params = [p for g in trainer.opt.param_groups for p in g["params"]]
-    bucket = P.GradBucket(params)
+    bucket = P.GradBucket(params, flats=lambda: trainer.grad_flats)
     shard = (rank, world)
 
     def one_step():

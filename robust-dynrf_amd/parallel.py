@@ -37,12 +37,15 @@ def flat_view(t):
 class GradBucket:
     """One flat fp32 buffer holding every parameter gradient; all-reduced once per iteration."""
 
-    def __init__(self, params):
+    def __init__(self, params, flats=None):
+        """`flats`: callable returning the fields' fused flat gradient buffers (TensorBase.fused_grads):
+        when given they are all-reduced in place, no gather/scatter copies."""
+        self.flats = flats
         self.params = [p for p in params]
         self.sizes = [p.numel() for p in self.params]
         total = sum(self.sizes)
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat = None if flats is not None else torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets = []
         o = 0
         for n in self.sizes:
@@ -50,12 +53,20 @@ class GradBucket:
             o += n
 
     def nbytes(self):
+        if self.flats is not None:
+            return sum(f.numel() for f in self.flats()) * 4
         return self.flat.numel() * 4
 
     @torch.no_grad()
     def allreduce_(self, average=False):
         """sum (or mean) the gradients across ranks in place."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        if self.flats is not None:
+            for f in self.flats():
+                dist.all_reduce(f, op=dist.ReduceOp.SUM)
+                if average:
+                    f.div_(dist.get_world_size())
             return
         for p, o, n in zip(self.params, self.offsets, self.sizes):
             if p.grad is None:

@@ -175,6 +175,9 @@ class Trainer:
             self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99))
         self.it = 0
         self.coin = torch.Generator().manual_seed(7)
+        # backward passes accumulate straight into p.grad (views of one flat buffer per field)
+        self.st.fused_grad = self.dy.fused_grad = True
+        self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
 
     def rays_for(self, ids):
         c = self.cfg
@@ -226,7 +229,7 @@ class Trainer:
         m = (1.0 - fg)[:, None]
         loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
         loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
-        self.opt.zero_grad(set_to_none=True)
+        self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
         loss.backward()
         return loss
 

@@ -182,3 +182,52 @@ def test_golden_ray_gradients(case):
     L = _golden_loss(g, o_s, o_d, outs, sf_f, sf_b, dev)
     L.backward()
     assert_close(rays.grad, g["g.rays"], "g.rays", rtol=5e-4)
+
+
+def test_fused_grad_accumulation_matches_autograd():
+    """TensorBase.fused_grad: every backward pass adds straight into p.grad (views of one flat
+    buffer per field).  Two passes + scene flow must give the gradients plain autograd gives."""
+    import rodynrf
+    from _gpu_util import fields_from_case
+    g, st, dy, _ = fields_from_case("ndc_relu")
+    dev = "cuda"
+    rays = torch.from_numpy(g["rays"]).to(dev)
+    ts = torch.from_numpy(g["ts"]).to(dev)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    z = torch.from_numpy(g["z"]).to(dev)
+    valid = torch.from_numpy(g["valid"]).to(dev)
+    S = z.shape[1]
+
+    def loss_of():
+        L = 0.0
+        for k, tt in enumerate((ts, (ts * 0.5).contiguous())):
+            o_s = st(rays, tt, None, xyz, z, valid, is_train=True, ray_type="ndc", N_samples=S)
+            o_d = dy(rays, tt, None, xyz, z, valid, is_train=True, ray_type="ndc", N_samples=S)
+            outs = rodynrf.raw2outputs(o_s[6], o_s[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], rays,
+                                       is_train=True, ray_type="ndc", add_white_bg=bool(k))
+            L = L + (outs[0] ** 2).sum() + outs[9].sum() + (o_d[5] ** 2).mean()
+        sf_f, sf_b = dy.get_forward_backward_scene_flow(o_d[3], ts)
+        return L + (sf_f ** 2).sum() + sf_b.abs().sum()
+
+    loss_of().backward()
+    ref = {id(p): p.grad.detach().clone() for m in (st, dy) for p in m.parameters() if p.grad is not None}
+    for m in (st, dy):
+        for p in m.parameters():
+            p.grad = None
+        m.fused_grad = True
+        flat = m.zero_grad_fused()
+        assert flat.dim() == 1
+    loss_of().backward()
+    n = 0
+    for m in (st, dy):
+        views = m.fused_grads()
+        for p, v in zip(m._param_list(), views):
+            assert p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == p.stride()
+            if id(p) in ref:
+                assert_close(p.grad, ref[id(p)].cpu().numpy(), "fused grad", rtol=2e-5)
+                n += 1
+    assert n > 40
+    # zero_grad_fused really clears everything with the one memset
+    for m in (st, dy):
+        m.zero_grad_fused()
+        assert all(float(p.grad.abs().max()) == 0.0 for p in m._param_list())

@@ -38,6 +38,20 @@ def _worker(rank, world, port, q):
     ok = torch.allclose(plane.grad, plane2.grad, rtol=1e-5, atol=1e-6) and \
         torch.allclose(lin.grad, lin2.grad, rtol=1e-5, atol=1e-6) and \
         plane.grad.stride() == plane.stride()
+    # fused path: the field-style flat gradient buffer is all-reduced in place (no copies)
+    flat = torch.zeros(64 + plane.numel())
+    gl = flat[:lin.numel()].view_as(lin)
+    gp = torch.as_strided(flat, plane.size(), plane.stride(), 64)
+    lin3 = torch.nn.Parameter(lin.detach().clone())
+    plane3 = torch.nn.Parameter(F.channel_last_(plane.detach().clone()))
+    loss3 = ((x[lo:hi] @ lin3.T) ** 2).sum() + (plane3.sum() * x[lo:hi].sum()) ** 2
+    loss3.backward()
+    gl.copy_(lin3.grad)
+    gp.copy_(plane3.grad)
+    b2 = P.GradBucket([plane3, lin3], flats=lambda: [flat])
+    b2.allreduce_()
+    ok = ok and torch.allclose(gl, lin2.grad, rtol=1e-5, atol=1e-6) and \
+        torch.allclose(gp, plane2.grad, rtol=1e-5, atol=1e-6) and b2.nbytes() == flat.numel() * 4
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
