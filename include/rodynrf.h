@@ -182,6 +182,21 @@ int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, const float* rg
                        int add_white_bg, const float* const g_out13[13], float* const g_in8[8],
                        rdrf_stream_t stream);
 
+/* ---- induced optical flow / disparity of the rendered 3-D point (renderer.py:1334-1392
+ * render_3d_point + induce_flow; NDC2world :1266, world2NDC :1276, contract2world :1286).
+ * P = sum_s w p + (1 - sum_s w) * far(rays); world = NDC2world(P) | contract2world(P); projected
+ * with the neighbour pose c2w[N][3][4] and focal; flow = pixel - pts_2d, disp = 1 + 2/z_cam.
+ * focal: DEVICE pointer to one float (it is a trained scalar). H, W: image size.
+ * render_single_3d_point / induce_flow_single (renderer.py:1301, :1381) are the S = 1, w = 1 case.
+ * bwd: gradient buffers accumulate (+=); g_rays, g_c2w[N][12], g_focal[1] may be NULL. */
+int rdrf_induce_flow_fwd(int H, int W, const float* focal, const float* c2w, const float* weights,
+                         const float* pts, const float* pts_2d, const float* rays, int N, int S,
+                         int ray_type, float* flow, float* disp, rdrf_stream_t stream);
+int rdrf_induce_flow_bwd(int H, int W, const float* focal, const float* c2w, const float* weights,
+                         const float* pts, const float* rays, int N, int S, int ray_type,
+                         const float* g_flow, const float* g_disp, float* g_weights, float* g_pts,
+                         float* g_rays, float* g_c2w, float* g_focal, rdrf_stream_t stream);
+
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
  * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].
  * scratch for the per-sample tensors comes out of ws (rdrf_render_workspace_bytes). */

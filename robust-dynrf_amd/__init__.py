@@ -4,15 +4,17 @@ Hand-written HIP kernels for gfx950 behind a C ABI (include/rodynrf.h, librodynr
 through the reference's own call surface:
 
     TensorVMSplit, TensorVMSplit_TimeEmbedding     (models/tensoRF.py)
-    sampleXYZ, raw2outputs, OctreeRender_trilinear_fast   (renderer.py)
+    sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, induce_flow, render_3d_point   (renderer.py)
     generate_rays                                  (train.py ray-generation block)
 
 Importing this package loads librodynrf.so and raises if it is missing: there is no fallback.
 """
 from . import _lib
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding, TensorBase
-from .renderer import sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays, render_rays
+from .renderer import (sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays, render_rays,
+                       induce_flow, induce_flow_single, render_3d_point, render_single_3d_point)
 from .ray_utils import generate_rays, ids2pixel
 
-__all__ = ["TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
+__all__ = ["induce_flow", "induce_flow_single", "render_3d_point", "render_single_3d_point",
+           "TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
            "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "generate_rays", "ids2pixel"]

@@ -538,3 +538,227 @@ extern "C" int rdrf_sample_bwd(const float* rays, const float* z, int N, int S, 
               grad_rays);
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// induced flow / disparity (renderer.py:1334-1392): wave per ray.  Forward: strided reduction of
+// sum w and sum w*p over the S samples, then ~40 scalar operations per ray.  Backward recomputes the
+// reduction (16 B/sample read, 16 B/sample written: HBM-trivial) and differentiates the per-ray
+// chain by hand; torch's max() subgradient (the arg-max component) is used for the L-inf norms.
+// ------------------------------------------------------------------------------------------------
+struct FlowRay {
+  float far[3], P[3], world[3], q[3], cam[3];
+  float acc, c, pz;            // NDC: clamped P.z and 2/(c-1)
+  float fn, fs; int fk;        // contract far point: norm, scale g(n), arg-max component (fk<0: inside)
+  float wn, wsc; int wk;       // contract2world: norm, scale s(m), arg-max (wk<0: identity)
+};
+RDRF_D int argmax_abs3(const float (&v)[3], float& n) {
+  int k = 0;
+  n = fabsf(v[0]);
+  if (fabsf(v[1]) > n) { n = fabsf(v[1]); k = 1; }
+  if (fabsf(v[2]) > n) { n = fabsf(v[2]); k = 2; }
+  return k;
+}
+RDRF_D void flow_ray_fwd(FlowRay& r, const float* ray, const float* c2w, float acc, const float (&ps)[3],
+                         int H, int W, float f, int ray_type, float& u, float& v, float& disp) {
+#pragma clang fp contract(off)
+  r.acc = acc;
+  if (ray_type == RDRF_RAY_NDC) {
+    for (int i = 0; i < 3; ++i) r.far[i] = ray[i] + ray[3 + i];
+    r.fk = -1;
+  } else {
+    float f0[3];
+    for (int i = 0; i < 3; ++i) f0[i] = ray[i] + ray[3 + i] * 256.0f;
+    const int k = argmax_abs3(f0, r.fn);
+    if (r.fn > 1.0f) {
+      r.fk = k;
+      r.fs = (2.0f - 1.0f / r.fn);
+      for (int i = 0; i < 3; ++i) r.far[i] = r.fs * (f0[i] / r.fn);
+    } else {
+      r.fk = -1;
+      for (int i = 0; i < 3; ++i) r.far[i] = f0[i];
+    }
+  }
+  for (int i = 0; i < 3; ++i) r.P[i] = ps[i] + (1.0f - acc) * r.far[i];
+  if (ray_type == RDRF_RAY_NDC) {
+    r.c = fminf(fmaxf(r.P[2], -1.0f), 1.0f - 1e-6f);
+    r.pz = 2.0f / (r.c - 1.0f);
+    r.world[0] = -r.P[0] * r.pz * (float)W / 2.0f / f;
+    r.world[1] = -r.P[1] * r.pz * (float)H / 2.0f / f;
+    r.world[2] = r.pz;
+    r.wk = -1;
+  } else {
+    const int k = argmax_abs3(r.P, r.wn);
+    if (r.wn > 1.0f) {
+      r.wk = k;
+      r.wsc = -1.0f / (r.wn - 2.0f);
+      for (int i = 0; i < 3; ++i) r.world[i] = r.P[i] / r.wn * r.wsc;
+    } else {
+      r.wk = -1;
+      for (int i = 0; i < 3; ++i) r.world[i] = r.P[i];
+    }
+  }
+  for (int j = 0; j < 3; ++j) r.q[j] = r.world[j] - c2w[j * 4 + 3];
+  for (int i = 0; i < 3; ++i)   // cam_i = sum_j q_j R[j][i]  (w2c = R^T)
+    r.cam[i] = r.q[0] * c2w[0 * 4 + i] + r.q[1] * c2w[1 * 4 + i] + r.q[2] * c2w[2 * 4 + i];
+  u = r.cam[0] / (-r.cam[2]) * f + (float)W * 0.5f;
+  v = -r.cam[1] / (-r.cam[2]) * f + (float)H * 0.5f;
+  disp = 1.0f + 2.0f / r.cam[2];
+}
+
+__global__ __launch_bounds__(64) void k_induce_flow(int H, int W, const float* __restrict__ focal,
+                                                    const float* __restrict__ c2w,
+                                                    const float* __restrict__ weights,
+                                                    const float* __restrict__ pts,
+                                                    const float* __restrict__ pts_2d,
+                                                    const float* __restrict__ rays, int N, int S,
+                                                    int ray_type, float* __restrict__ flow,
+                                                    float* __restrict__ disp) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float acc = 0.f, ps[3] = {0.f, 0.f, 0.f};
+  for (int s = lane; s < S; s += 64) {
+    const float w = weights[(size_t)n * S + s];
+    const float* p = pts + ((size_t)n * S + s) * 3;
+    acc += w; ps[0] += w * p[0]; ps[1] += w * p[1]; ps[2] += w * p[2];
+  }
+  acc = wave_sum(acc); ps[0] = wave_sum(ps[0]); ps[1] = wave_sum(ps[1]); ps[2] = wave_sum(ps[2]);
+  if (lane == 0) {
+    FlowRay r;
+    float u, v, d;
+    flow_ray_fwd(r, rays + (size_t)n * 6, c2w + (size_t)n * 12, acc, ps, H, W, focal[0], ray_type, u, v, d);
+    flow[(size_t)n * 2 + 0] = u - pts_2d[(size_t)n * 2 + 0];
+    flow[(size_t)n * 2 + 1] = v - pts_2d[(size_t)n * 2 + 1];
+    disp[n] = d;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_induce_flow_bwd(int H, int W, const float* __restrict__ focal,
+                                                        const float* __restrict__ c2w,
+                                                        const float* __restrict__ weights,
+                                                        const float* __restrict__ pts,
+                                                        const float* __restrict__ rays, int N, int S,
+                                                        int ray_type, const float* __restrict__ g_flow,
+                                                        const float* __restrict__ g_disp,
+                                                        float* __restrict__ g_weights,
+                                                        float* __restrict__ g_pts,
+                                                        float* __restrict__ g_rays,
+                                                        float* __restrict__ g_c2w,
+                                                        float* __restrict__ g_focal) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float acc = 0.f, ps[3] = {0.f, 0.f, 0.f};
+  for (int s = lane; s < S; s += 64) {
+    const float w = weights[(size_t)n * S + s];
+    const float* p = pts + ((size_t)n * S + s) * 3;
+    acc += w; ps[0] += w * p[0]; ps[1] += w * p[1]; ps[2] += w * p[2];
+  }
+  acc = wave_sum(acc); ps[0] = wave_sum(ps[0]); ps[1] = wave_sum(ps[1]); ps[2] = wave_sum(ps[2]);
+  // every lane runs the (cheap) per-ray chain so that dP / dacc are wave-uniform without shuffles
+  const float* ray = rays + (size_t)n * 6;
+  const float* M = c2w + (size_t)n * 12;
+  const float f = focal[0];
+  FlowRay r;
+  float u, v, d;
+  flow_ray_fwd(r, ray, M, acc, ps, H, W, f, ray_type, u, v, d);
+  const float gu = g_flow ? g_flow[(size_t)n * 2 + 0] : 0.f, gv = g_flow ? g_flow[(size_t)n * 2 + 1] : 0.f;
+  const float gd = g_disp ? g_disp[n] : 0.f;
+  const float c2 = r.cam[2], ic2 = 1.0f / c2;
+  float gcam[3];
+  gcam[0] = -gu * f * ic2;                      // u = -cam0/cam2 f + W/2
+  gcam[1] = gv * f * ic2;                       // v =  cam1/cam2 f + H/2
+  gcam[2] = (gu * r.cam[0] - gv * r.cam[1]) * f * ic2 * ic2 - 2.0f * gd * ic2 * ic2;
+  float gf = -gu * r.cam[0] * ic2 + gv * r.cam[1] * ic2;
+  float gq[3], gM[12];
+  for (int j = 0; j < 3; ++j) {
+    gq[j] = gcam[0] * M[j * 4 + 0] + gcam[1] * M[j * 4 + 1] + gcam[2] * M[j * 4 + 2];
+    for (int i = 0; i < 3; ++i) gM[j * 4 + i] = r.q[j] * gcam[i];
+    gM[j * 4 + 3] = 0.f;
+  }
+  for (int j = 0; j < 3; ++j) gM[j * 4 + 3] = -gq[j];
+  float gP[3];
+  if (ray_type == RDRF_RAY_NDC) {
+    const float sx = (float)W / 2.0f / f, sy = (float)H / 2.0f / f;
+    gP[0] = -gq[0] * r.pz * sx;
+    gP[1] = -gq[1] * r.pz * sy;
+    const float gpz = -gq[0] * r.P[0] * sx - gq[1] * r.P[1] * sy + gq[2];
+    gf += -(r.world[0] * gq[0] + r.world[1] * gq[1]) / f;
+    const float gc = gpz * (-2.0f / ((r.c - 1.0f) * (r.c - 1.0f)));
+    gP[2] = (r.P[2] >= -1.0f && r.P[2] <= 1.0f - 1e-6f) ? gc : 0.f;
+  } else if (r.wk >= 0) {
+    // world = P * s(m), s = 1/(m (2-m)), m = |P_k|
+    const float m = r.wn, sc = r.wsc / m;
+    const float ds = (2.0f * m - 2.0f) / ((m * (2.0f - m)) * (m * (2.0f - m)));
+    const float dot = gq[0] * r.P[0] + gq[1] * r.P[1] + gq[2] * r.P[2];
+    for (int i = 0; i < 3; ++i) gP[i] = gq[i] * sc;
+    gP[r.wk] += dot * ds * (r.P[r.wk] >= 0.f ? 1.0f : -1.0f);
+  } else {
+    for (int i = 0; i < 3; ++i) gP[i] = gq[i];
+  }
+  const float gacc = -(gP[0] * r.far[0] + gP[1] * r.far[1] + gP[2] * r.far[2]);
+  for (int s = lane; s < S; s += 64) {
+    const size_t o = (size_t)n * S + s;
+    const float w = weights[o];
+    const float* p = pts + o * 3;
+    if (g_weights) g_weights[o] += gP[0] * p[0] + gP[1] * p[1] + gP[2] * p[2] + gacc;
+    if (g_pts) { g_pts[o * 3 + 0] += w * gP[0]; g_pts[o * 3 + 1] += w * gP[1]; g_pts[o * 3 + 2] += w * gP[2]; }
+  }
+  if (lane == 0) {
+    if (g_rays) {
+      float gfar[3], go[3], gdr[3];
+      for (int i = 0; i < 3; ++i) gfar[i] = (1.0f - acc) * gP[i];
+      if (ray_type == RDRF_RAY_NDC) {
+        for (int i = 0; i < 3; ++i) { go[i] = gfar[i]; gdr[i] = gfar[i]; }
+      } else {
+        float g0[3];
+        if (r.fk >= 0) {
+          // far = g(n) f0, g = (2n-1)/n^2, dg/dn = (2-2n)/n^3, n = |f0_k|
+          const float nn = r.fn, gsc = r.fs / nn;
+          float f0[3];
+          for (int i = 0; i < 3; ++i) f0[i] = ray[i] + ray[3 + i] * 256.0f;
+          const float dot = gfar[0] * f0[0] + gfar[1] * f0[1] + gfar[2] * f0[2];
+          for (int i = 0; i < 3; ++i) g0[i] = gfar[i] * gsc;
+          g0[r.fk] += dot * (2.0f - 2.0f * nn) / (nn * nn * nn) * (f0[r.fk] >= 0.f ? 1.0f : -1.0f);
+        } else {
+          for (int i = 0; i < 3; ++i) g0[i] = gfar[i];
+        }
+        for (int i = 0; i < 3; ++i) { go[i] = g0[i]; gdr[i] = 256.0f * g0[i]; }
+      }
+      for (int i = 0; i < 3; ++i) { g_rays[(size_t)n * 6 + i] += go[i]; g_rays[(size_t)n * 6 + 3 + i] += gdr[i]; }
+    }
+    if (g_c2w)
+      for (int i = 0; i < 12; ++i) g_c2w[(size_t)n * 12 + i] += gM[i];
+  }
+  if (g_focal) {
+    // one atomic per wave: lanes hold identical gf, only lane 0 contributes
+    if (lane == 0) atomicAdd(g_focal, gf);
+  }
+}
+
+extern "C" int rdrf_induce_flow_fwd(int H, int W, const float* focal, const float* c2w,
+                                    const float* weights, const float* pts, const float* pts_2d,
+                                    const float* rays, int N, int S, int ray_type, float* flow,
+                                    float* disp, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 0 && H > 0 && W > 0 && focal && c2w && weights && pts && pts_2d && rays && flow && disp,
+             -1, "induce_flow_fwd: bad arguments");
+  RDRF_CHECK(ray_type == RDRF_RAY_NDC || ray_type == RDRF_RAY_CONTRACT, -1,
+             "induce_flow_fwd: ray_type must be ndc or contract (renderer.py:1343-1361)");
+  RDRF_LAUNCH("induce_flow", k_induce_flow, dim3(N), dim3(64), stream, H, W, focal, c2w, weights, pts,
+              pts_2d, rays, N, S, ray_type, flow, disp);
+  return 0;
+}
+
+extern "C" int rdrf_induce_flow_bwd(int H, int W, const float* focal, const float* c2w,
+                                    const float* weights, const float* pts, const float* rays, int N,
+                                    int S, int ray_type, const float* g_flow, const float* g_disp,
+                                    float* g_weights, float* g_pts, float* g_rays, float* g_c2w,
+                                    float* g_focal, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && S > 0 && H > 0 && W > 0 && focal && c2w && weights && pts && rays, -1,
+             "induce_flow_bwd: bad arguments");
+  RDRF_CHECK(ray_type == RDRF_RAY_NDC || ray_type == RDRF_RAY_CONTRACT, -1,
+             "induce_flow_bwd: ray_type must be ndc or contract");
+  RDRF_CHECK(g_flow || g_disp, -1, "induce_flow_bwd: no output gradient given");
+  RDRF_LAUNCH("induce_flow_bwd", k_induce_flow_bwd, dim3(N), dim3(64), stream, H, W, focal, c2w, weights,
+              pts, rays, N, S, ray_type, g_flow, g_disp, g_weights, g_pts, g_rays, g_c2w, g_focal);
+  return 0;
+}

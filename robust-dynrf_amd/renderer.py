@@ -166,3 +166,86 @@ def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc")
                                   L.ptr(depth), L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(rays)),
             "rdrf_render_fwd")
     return rgb, depth
+
+
+# --------------------------------------------------------------------------------------------
+# induced optical flow / disparity (renderer.py:1266-1392) -- SURVEY.md 8f rank 1
+# --------------------------------------------------------------------------------------------
+def _focal_tensor(focal, dev):
+    if torch.is_tensor(focal):
+        L.require_device(focal)
+        return focal.reshape(1).float()
+    return torch.full((1,), float(focal), device=dev)
+
+
+class _InduceFlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, W, focal, c2w, weights, pts, pts_2d, rays, ray_type):
+        L.require_device(c2w, weights, pts, pts_2d, rays)
+        c2w, weights, pts, pts_2d, rays = (L.f32c(t) for t in (c2w, weights, pts, pts_2d, rays))
+        focal = L.f32c(focal)
+        N, S = weights.shape
+        if c2w.shape != (N, 3, 4) or pts.shape != (N, S, 3) or rays.shape != (N, 6) or pts_2d.shape != (N, 2):
+            raise L.RdrfError("induce_flow: expected pose [N,3,4], weights [N,S], pts [N,S,3], pts_2d [N,2], "
+                              "rays [N,6]")
+        if ray_type not in ("ndc", "contract"):
+            raise L.RdrfError("induce_flow: ray_type must be 'ndc' or 'contract' (renderer.py:1343-1361)")
+        flow = torch.empty(N, 2, device=weights.device)
+        disp = torch.empty(N, 1, device=weights.device)
+        L.check(L.lib.rdrf_induce_flow_fwd(int(H), int(W), L.ptr(focal), L.ptr(c2w), L.ptr(weights),
+                                           L.ptr(pts), L.ptr(pts_2d), L.ptr(rays), N, S,
+                                           L.RAY_TYPES[ray_type], L.ptr(flow), L.ptr(disp),
+                                           L.stream_of(weights)), "rdrf_induce_flow_fwd")
+        ctx.hw, ctx.ray_type = (int(H), int(W)), ray_type
+        ctx.save_for_backward(focal, c2w, weights, pts, rays)
+        return flow, disp
+
+    @staticmethod
+    def backward(ctx, g_flow, g_disp):
+        focal, c2w, weights, pts, rays = ctx.saved_tensors
+        N, S = weights.shape
+        need = ctx.needs_input_grad     # H, W, focal, c2w, weights, pts, pts_2d, rays, ray_type
+        g_focal = torch.zeros_like(focal) if need[2] else None
+        g_c2w = torch.zeros_like(c2w) if need[3] else None
+        g_w = torch.zeros_like(weights) if need[4] else None
+        g_pts = torch.zeros_like(pts) if need[5] else None
+        g_rays = torch.zeros_like(rays) if need[7] else None
+        g_flow = None if g_flow is None else L.f32c(g_flow)
+        g_disp = None if g_disp is None else L.f32c(g_disp)
+        L.check(L.lib.rdrf_induce_flow_bwd(ctx.hw[0], ctx.hw[1], L.ptr(focal), L.ptr(c2w), L.ptr(weights),
+                                           L.ptr(pts), L.ptr(rays), N, S, L.RAY_TYPES[ctx.ray_type],
+                                           L.ptr(g_flow), L.ptr(g_disp), L.ptr(g_w), L.ptr(g_pts),
+                                           L.ptr(g_rays), L.ptr(g_c2w), L.ptr(g_focal),
+                                           L.stream_of(weights)), "rdrf_induce_flow_bwd")
+        g_p2d = None if (not need[6] or g_flow is None) else -g_flow
+        return (None, None, g_focal, g_c2w, g_w, g_pts, g_p2d, g_rays, None)
+
+
+def render_3d_point(H, W, f, c2w, weights, pts, rays, ray_type="ndc"):
+    """renderer.py:1334-1378: weight-averaged 3-D point along each ray, projected into the camera
+    c2w [N,3,4]; returns (pixel coordinates [N,2], NDC depth [N,1])."""
+    dev = weights.device
+    zero = torch.zeros(weights.shape[0], 2, device=dev)
+    flow, disp = _InduceFlowFn.apply(H, W, _focal_tensor(f, dev), c2w, weights, pts, zero, rays, ray_type)
+    return flow, disp
+
+
+def induce_flow(H, W, focal, pose_neighbor, weights, pts_3d_neighbor, pts_2d, rays, ray_type="ndc"):
+    """renderer.py:1381-1392: (induced_flow [N,2], induced_disp [N,1])."""
+    return _InduceFlowFn.apply(H, W, _focal_tensor(focal, weights.device), pose_neighbor, weights,
+                               pts_3d_neighbor, pts_2d, rays, ray_type)
+
+
+def render_single_3d_point(H, W, f, c2w, pt_NDC):
+    """renderer.py:1301-1331: the S = 1, weight 1 case; disparity is returned as (z_ndc + 1) / 2."""
+    N = pt_NDC.shape[0]
+    dev = pt_NDC.device
+    one = torch.ones(N, 1, device=dev)
+    plane, d = _InduceFlowFn.apply(H, W, _focal_tensor(f, dev), c2w, one, pt_NDC.reshape(N, 1, 3),
+                                   torch.zeros(N, 2, device=dev), torch.zeros(N, 6, device=dev), "ndc")
+    return plane, (d + 1.0) / 2.0
+
+
+def induce_flow_single(H, W, focal, pose_neighbor, pts_3d_neighbor, pts_2d):
+    """renderer.py:1381-1386 (induce_flow_single)."""
+    return render_single_3d_point(H, W, focal, pose_neighbor, pts_3d_neighbor)[0] - pts_2d

@@ -244,8 +244,65 @@ def gen_raygen(mods):
     print("raygen: ok")
 
 
+def gen_induce_flow(mods):
+    """renderer.py:1266-1392: induce_flow / render_3d_point / render_single_3d_point, both ray
+    types, with gradients wrt every differentiable input (weights, pts, rays, c2w, focal)."""
+    _, _, R, _, camera = mods
+    out = {}
+    for rt, seed in (("ndc", 501), ("contract", 502)):
+        g = torch.Generator().manual_seed(seed)
+        N, S, H, W = 24, 19, 27, 48
+        focal = torch.tensor(max(H, W) / 2.0 * 1.7320508, requires_grad=True)
+        p9 = torch.zeros(N, 9)
+        p9[:, 0] = 1
+        p9[:, 4] = 1
+        p9 = p9 + 0.05 * torch.randn(N, 9, generator=g)
+        c2w = camera.pose_to_mtx(p9).detach().clone().requires_grad_(True)     # [N,3,4]
+        w = torch.rand(N, S, generator=g)
+        w = w / w.sum(-1, keepdim=True) * torch.rand(N, 1, generator=g)         # acc in (0,1)
+        w[:3] = 0.0                                                              # empty rays
+        if rt == "ndc":
+            pts = torch.empty(N, S, 3).uniform_(-0.9, 0.9, generator=g)
+            pts[..., 2] = torch.empty(N, S).uniform_(-0.95, 0.97, generator=g)
+            pts[5, :, 2] = 1.5       # beyond the clamp of NDC2world
+            rays = torch.cat([torch.empty(N, 2).uniform_(-0.8, 0.8, generator=g), -torch.ones(N, 1),
+                              torch.empty(N, 2).uniform_(-0.1, 0.1, generator=g), 2 * torch.ones(N, 1)], -1)
+        else:
+            pts = torch.empty(N, S, 3).uniform_(-1.9, 1.9, generator=g)
+            pts[:6] *= 0.3           # inside the unit box: identity branch of contract2world
+            rays = torch.cat([torch.empty(N, 3).uniform_(-0.2, 0.2, generator=g),
+                              torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)], -1)
+            rays[7, 3:] *= 1e-3      # farthest point stays inside the unit box
+        w.requires_grad_(True)
+        pts.requires_grad_(True)
+        rays.requires_grad_(True)
+        p2d = torch.stack([torch.rand(N, generator=g) * W, torch.rand(N, generator=g) * H], -1)
+        flow, disp = R.induce_flow(H, W, focal, c2w, w, pts.clone() if rt == "contract" else pts, p2d, rays,
+                                   ray_type=rt)
+        lf, ld = torch.randn(flow.shape, generator=g), torch.randn(disp.shape, generator=g)
+        gw, gp, gr, gc, gf = torch.autograd.grad((flow * lf).sum() + (disp * ld).sum(),
+                                                 [w, pts, rays, c2w, focal])
+        pre = f"{rt}."
+        for k, v in dict(H=H, W=W, focal=focal, c2w=c2w, weights=w, pts=pts, pts_2d=p2d, rays=rays,
+                         flow=flow, disp=disp, lw_flow=lf, lw_disp=ld, g_weights=gw, g_pts=gp,
+                         g_rays=gr, g_c2w=gc, g_focal=gf).items():
+            out[pre + k] = v.detach().numpy() if torch.is_tensor(v) else v
+        if rt == "ndc":
+            pt = pts.detach()[:, 0].clone().requires_grad_(True)
+            pl, dd = R.render_single_3d_point(H, W, focal.detach(), c2w.detach(), pt)
+            out["single.pt"] = pt.detach().numpy()
+            out["single.plane"] = pl.detach().numpy()
+            out["single.disp"] = dd.detach().numpy()
+            out["single.flow"] = R.induce_flow_single(H, W, focal.detach(), c2w.detach(), pt, p2d).detach().numpy()
+    np.savez(os.path.join(HERE, "induce_flow.npz"), **out)
+    print("induce_flow: ok")
+
+
 if __name__ == "__main__":
     mods = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "induce_flow":
+        gen_induce_flow(mods)
+        sys.exit(0)
     gen_case("ndc_relu", mods, "ndc", "relu", "MLP_Fea", [18, 19, 11], 32, 13, 20211202, -10.0, False)
     gen_case("ndc_relu_long", mods, "ndc", "relu", "MLP_Fea", [10, 11, 7], 6, 130, 20211203, -10.0, True)
     gen_case("ndc_softplus", mods, "ndc", "softplus", "MLP_Fea", [10, 12, 7], 16, 13, 20211204, -1.0, True)
@@ -254,3 +311,4 @@ if __name__ == "__main__":
     gen_case("contract_softplus_te", mods, "contract", "softplus", "MLP_Fea_TimeEmbedding", [8, 8, 8],
              12, 13, 20211206, -1.0, False)
     gen_raygen(mods)
+    gen_induce_flow(mods)

@@ -56,6 +56,31 @@ __global__ void kF(float* buf, unsigned ntex, int iters) {
     }
   }
 }
+// G: like B, but the 4-lane group at lanes l (half 0) and l+32 (half 1) hit two ADJACENT quads of the
+// same 64-byte texel.  G ~ B/2 => the coalescer merges same-line lanes across the whole wave.
+__global__ void kG(float* buf, unsigned ntex, int iters) {
+  unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned lane = threadIdx.x & 63, hh = lane >> 5;
+  unsigned tq = (t & ~63u) | (lane & 31);   // same id for lane and lane+32
+  for (int i = 0; i < iters; ++i) {
+    for (int k = 0; k < 4; ++k) {
+      unsigned tex = hash(((tq >> 2) * 4 + k) * 977u + i) % (ntex / 4);
+      atomicAdd(buf + (size_t)tex * 16 + hh * 4 + (t & 3), 1.f);
+    }
+  }
+}
+// H: like G but the two halves hit quads of DIFFERENT 64-byte texels (control: same address math)
+__global__ void kH(float* buf, unsigned ntex, int iters) {
+  unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned lane = threadIdx.x & 63, hh = lane >> 5;
+  unsigned tq = (t & ~63u) | (lane & 31);
+  for (int i = 0; i < iters; ++i) {
+    for (int k = 0; k < 4; ++k) {
+      unsigned tex = hash(((tq >> 2) * 4 + k) * 977u + i + hh * 7919u) % (ntex / 4);
+      atomicAdd(buf + (size_t)tex * 16 + hh * 4 + (t & 3), 1.f);
+    }
+  }
+}
 // D: A without atomics (plain read-modify-write, racy) as a bandwidth reference
 __global__ void kD(float* buf, unsigned ntex, int iters) {
   unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,7 +98,7 @@ int main() {
     const int blocks = 2048, threads = 256, iters = 16;
     const double natom = (double)blocks * threads * iters * 4;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int kind = 0; kind < 6; ++kind) {
+    for (int kind = 0; kind < 8; ++kind) {
       float best = 1e9;
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
@@ -83,10 +108,12 @@ int main() {
         if (kind == 3) kD<<<blocks, threads>>>(buf, ntex, iters);
         if (kind == 4) kE<<<blocks, threads>>>(buf, ntex, iters);
         if (kind == 5) kF<<<blocks, threads>>>(buf, ntex, iters);
+        if (kind == 6) kG<<<blocks, threads>>>(buf, ntex, iters);
+        if (kind == 7) kH<<<blocks, threads>>>(buf, ntex, iters);
         hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
       }
-      printf("ntex %8u  kernel %c  %.3f ms  %.1f G scalar-updates/s (if all lanes live)  %.2f G wave-instr/s\n", ntex, "ABCDEF"[kind], best, natom / best / 1e6, natom / 64.0 / best / 1e6);
+      printf("ntex %8u  kernel %c  %.3f ms  %.1f G scalar-updates/s (if all lanes live)  %.2f G wave-instr/s\n", ntex, "ABCDEFGH"[kind], best, natom / best / 1e6, natom / 64.0 / best / 1e6);
     }
     CHECK(hipFree(buf));
   }
