@@ -117,12 +117,23 @@ def cpu_baseline(trainer, n_rays, S, seed=0):
         w_d = outA[11].detach()[..., None]
         loss = loss + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
         loss = loss + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
-        for ids_n, sgn in ((ids2, 1.0), (ids3, -1.0)):
+        col, row, view = O.ids2pixel(W, H, ids)
+        grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+        c2w_all = O.pose_to_mtx(poses)
+        dev = d.device
+        disp_A = {}
+        for sgn, sf, fl, mk in ((1, sf_f, d.flow_f, d.flow_mask_f), (-1, sf_b, d.flow_b, d.flow_mask_b)):
+            flow_t, mask_t = fl[ids.to(dev)].cpu(), mk[ids.to(dev)].cpu()
+            pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]
+            ind_flow, ind_disp = O.induce_flow(H, W, focal, pose_n, outA[11], oA[3] + sf, grid, rays.detach(), "ndc")
+            loss = loss + 0.02 * ((ind_flow - flow_t).abs() * mask_t).sum() / (mask_t.sum() + 1e-8) / 2.0
+            disp_A[sgn] = (ind_disp, mask_t, pose_n)
+        for ids_n, sgn in ((ids2, 1), (ids3, -1)):
             rays_n = O.generate_rays(ids_n, poses, focal, H, W, ndc=True, near=1.0)
             _, oN, outN, xyzN = rp(rays_n, (ts + sgn * dt).clamp(-1, 1), False, True, True)
-            induced = (outN[11][..., None] * xyzN).sum(1)
-            target = (outA[11].detach()[..., None] * (xyzA + (sf_f if sgn > 0 else sf_b)).detach()).sum(1)
-            loss = loss + 0.02 * (induced - target).abs().mean()
+            ind_disp, mask_t, pose_n = disp_A[sgn]
+            _, ind_disp_n = O.induce_flow(H, W, focal, pose_n, outN[11], oN[3], grid, rays_n, "ndc")
+            loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
         _, _, outE, _ = rp(rays, ts, True, False, False)
         m = (1.0 - fg)[:, None]
         loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
@@ -208,7 +219,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: Nvidia Balloon1, configs/Nvidia.txt, "
                                f"{args.rays_per_gpu} rays/iter/GPU, 1xMI355X per rank, static+dynamic "
                                "TensorVMSplit; one step = 4 dynamic + 5 static forward passes, scene-flow "
-                               "MLP, compositor, full backward, Adam",
+                               "MLP, induced flow/disparity x4, compositor, full backward, Adam",
                    "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
                    "global_batch": cfg["batch_size"], "weights": args.weights,
                    "parallelism": f"ray-sharded dp{world}", "final_loss": loss_val},

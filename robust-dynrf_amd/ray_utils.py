@@ -44,3 +44,13 @@ def generate_rays(ray_idx, poses9, focal, H, W, ndc=True, near=1.0):
 
 def ids2pixel(W, H, ids):
     return ids % W, (ids // W) % H, ids // (W * H)
+
+
+def pose_to_mtx(pose9):
+    """camera.py:8-15: 6-D rotation (two 3-vectors, Gram-Schmidt) + translation -> c2w [.,3,4] with
+    columns (b1, b2, b1 x b2, t).  A [T,9] per-frame table, not per-ray work: plain torch."""
+    a1, a2, t = pose9[..., 0:3], pose9[..., 3:6], pose9[..., 6:9]
+    b1 = a1 / a1.norm(dim=-1, keepdim=True)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = b2 / b2.norm(dim=-1, keepdim=True)
+    return torch.stack([b1, b2, torch.linalg.cross(b1, b2), t], dim=-1)

@@ -30,8 +30,8 @@ import math
 import torch
 
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
-from .ray_utils import generate_rays
-from .renderer import raw2outputs, sampleXYZ
+from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
+from .renderer import induce_flow, raw2outputs, sampleXYZ
 
 
 def balloon1_config(stage="stage0"):
@@ -123,6 +123,11 @@ class SyntheticBalloon:
         self.rgb = torch.rand(self.total, 3, generator=g).to(device)
         self.disp = torch.rand(self.total, generator=g).to(device)
         self.fgmask = (torch.rand(self.total, generator=g) < 0.2).float().to(device)
+        # optical-flow supervision (train.py:1380-1413): targets in pixels + validity masks
+        self.flow_f = (2.0 * torch.randn(self.total, 2, generator=g)).to(device)
+        self.flow_b = (2.0 * torch.randn(self.total, 2, generator=g)).to(device)
+        self.flow_mask_f = (torch.rand(self.total, 1, generator=g) < 0.8).float().to(device)
+        self.flow_mask_b = (torch.rand(self.total, 1, generator=g) < 0.8).float().to(device)
         self.perm = torch.randperm(self.total, generator=g).to(device)
         self.device = device
 
@@ -215,14 +220,28 @@ class Trainer:
         w_d = outA[11].detach()[..., None]
         loss = loss + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
         loss = loss + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
-        # ---- pass C / D: neighbour frames
-        for ids_n, sgn in ((ids2, 1.0), (ids3, -1.0)):
+        # ---- induced flow of the dynamic field into the neighbour frames (train.py:1373-1413)
+        H, W, T = c["H"], c["W"], c["T"]
+        col, row, view = ids2pixel(W, H, ids)
+        grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+        c2w_all = pose_to_mtx(d.poses)
+        weights_d, pts_ref = outA[11], oA[3]
+        disp_A = {}
+        for sgn, sf, flow_t, mask_t in ((1, sf_f, d.flow_f[ids], d.flow_mask_f[ids]),
+                                        (-1, sf_b, d.flow_b[ids], d.flow_mask_b[ids])):
+            pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
+            ind_flow, ind_disp = induce_flow(H, W, d.focal, pose_n, weights_d, pts_ref + sf, grid,
+                                             rays.detach(), ray_type=rt)
+            loss = loss + 0.02 * ((ind_flow - flow_t).abs() * mask_t).sum() / (mask_t.sum() + 1e-8) / 2.0
+            disp_A[sgn] = (ind_disp, mask_t, pose_n)
+        # ---- pass C / D: neighbour frames (train.py:1433-1528, 1530-1625): disparity consistency
+        for ids_n, sgn in ((ids2, 1), (ids3, -1)):
             rays_n = self.rays_for(ids_n).detach()
             ts_n = (ts + sgn * dt).clamp(-1.0, 1.0)
             _, oN, outN, xyzN = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, white=coin())
-            induced = (outN[11][..., None] * xyzN).sum(1)          # render_3d_point-style reduction
-            target = (outA[11].detach()[..., None] * (xyzA + (sf_f if sgn > 0 else sf_b)).detach()).sum(1)
-            loss = loss + 0.02 * (induced - target).abs().mean()
+            ind_disp, mask_t, pose_n = disp_A[sgn]
+            _, ind_disp_n = induce_flow(H, W, d.focal, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
+            loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
         # ---- pass E: static field with gradient
         _, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, static_grad=True, dynamic=False,
                                  white=coin())
