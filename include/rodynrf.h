@@ -197,6 +197,21 @@ int rdrf_induce_flow_bwd(int H, int W, const float* focal, const float* c2w, con
                          const float* g_flow, const float* g_disp, float* g_weights, float* g_pts,
                          float* g_rays, float* g_c2w, float* g_focal, rdrf_stream_t stream);
 
+/* ---- distortion loss (train.py:1299-1312, 1685-1716, 1840-1856 call flatten_eff_distloss of the
+ * un-vendored torch_efficient_distloss with ray_id = tile(arange(N), S), i.e. N rays x S points).
+ * Published formulation (DVGO v2 / mip-NeRF 360), m ascending along a ray:
+ *   loss_ray[n] = sum_i 2 w_i (m_i sum_{j<i} w_j - sum_{j<i} w_j m_j) + (1/3) sum_i interval w_i^2
+ * (= sum_ij w_i w_j |m_i - m_j| + ...); the caller sums loss_ray and divides by N.
+ * bwd: g_w[n][i] += g_ray[n] * (2 (m_i (P_i - Q_i) + (QM_i - PM_i)) + (2/3) interval w_i) with
+ * P/PM exclusive prefix and Q/QM exclusive suffix sums of w and w m.  m gets no gradient (the
+ * reference passes it detached / it is not trained).  interval_pt (per point, may be NULL) overrides
+ * the scalar interval.  PARITY UNPINNED against the library itself (absent here): checked against an
+ * O(S^2) evaluation of the double sum. */
+int rdrf_distloss_fwd(const float* w, const float* m, float interval, const float* interval_pt,
+                      int N, int S, float* loss_ray, rdrf_stream_t stream);
+int rdrf_distloss_bwd(const float* w, const float* m, float interval, const float* interval_pt,
+                      int N, int S, const float* g_ray, float* g_w, rdrf_stream_t stream);
+
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
  * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].
  * scratch for the per-sample tensors comes out of ws (rdrf_render_workspace_bytes). */

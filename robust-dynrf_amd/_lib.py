@@ -76,7 +76,7 @@ SYMBOLS = [
     "rdrf_generate_rays_bwd", "rdrf_sample_ndc", "rdrf_sample_contract", "rdrf_sample_bwd",
     "rdrf_static_fwd", "rdrf_static_bwd", "rdrf_dynamic_fwd", "rdrf_dynamic_bwd",
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
-    "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd",
+    "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]

@@ -762,3 +762,83 @@ extern "C" int rdrf_induce_flow_bwd(int H, int W, const float* focal, const floa
               pts, rays, N, S, ray_type, g_flow, g_disp, g_weights, g_pts, g_rays, g_c2w, g_focal);
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// distortion loss: wave per ray, 64-sample tiles, additive wave scans with carries
+// ------------------------------------------------------------------------------------------------
+RDRF_D float wave_excl_sum(float v, int lane, float& total) {
+  float inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  total = __shfl(inc, 63, 64);
+  return inc - v;
+}
+
+__global__ __launch_bounds__(64) void k_distloss(const float* __restrict__ w, const float* __restrict__ m,
+                                                 float interval, const float* __restrict__ ipt, int N,
+                                                 int S, float* __restrict__ loss_ray) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float cw = 0.f, cwm = 0.f, acc = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool act = s < S;
+    const size_t o = (size_t)n * S + (act ? s : 0);
+    const float wi = act ? w[o] : 0.f, mi = act ? m[o] : 0.f;
+    const float iv = ipt ? (act ? ipt[o] : 0.f) : interval;
+    float tw, twm;
+    const float pw = cw + wave_excl_sum(wi, lane, tw);
+    const float pwm = cwm + wave_excl_sum(wi * mi, lane, twm);
+    acc += 2.0f * wi * (mi * pw - pwm) + (1.0f / 3.0f) * iv * wi * wi;
+    cw += tw; cwm += twm;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) loss_ray[n] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_distloss_bwd(const float* __restrict__ w, const float* __restrict__ m,
+                                                     float interval, const float* __restrict__ ipt,
+                                                     int N, int S, const float* __restrict__ g_ray,
+                                                     float* __restrict__ g_w) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float tw_all = 0.f, twm_all = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float wi = w[(size_t)n * S + s];
+    tw_all += wi; twm_all += wi * m[(size_t)n * S + s];
+  }
+  tw_all = wave_sum(tw_all); twm_all = wave_sum(twm_all);
+  const float g = g_ray[n];
+  float cw = 0.f, cwm = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool act = s < S;
+    const size_t o = (size_t)n * S + (act ? s : 0);
+    const float wi = act ? w[o] : 0.f, mi = act ? m[o] : 0.f;
+    const float iv = ipt ? (act ? ipt[o] : 0.f) : interval;
+    float tw, twm;
+    const float pw = cw + wave_excl_sum(wi, lane, tw);
+    const float pwm = cwm + wave_excl_sum(wi * mi, lane, twm);
+    const float qw = tw_all - (pw + wi), qwm = twm_all - (pwm + wi * mi);
+    if (act) g_w[o] += g * (2.0f * (mi * (pw - qw) + (qwm - pwm)) + (2.0f / 3.0f) * iv * wi);
+    cw += tw; cwm += twm;
+  }
+}
+
+extern "C" int rdrf_distloss_fwd(const float* w, const float* m, float interval, const float* interval_pt,
+                                 int N, int S, float* loss_ray, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(w && m && loss_ray && N > 0 && S > 0, -1, "distloss_fwd: bad arguments");
+  RDRF_LAUNCH("distloss", k_distloss, dim3(N), dim3(64), stream, w, m, interval, interval_pt, N, S, loss_ray);
+  return 0;
+}
+extern "C" int rdrf_distloss_bwd(const float* w, const float* m, float interval, const float* interval_pt,
+                                 int N, int S, const float* g_ray, float* g_w, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(w && m && g_ray && g_w && N > 0 && S > 0, -1, "distloss_bwd: bad arguments");
+  RDRF_LAUNCH("distloss_bwd", k_distloss_bwd, dim3(N), dim3(64), stream, w, m, interval, interval_pt, N, S,
+              g_ray, g_w);
+  return 0;
+}

@@ -249,3 +249,58 @@ def render_single_3d_point(H, W, f, c2w, pt_NDC):
 def induce_flow_single(H, W, focal, pose_neighbor, pts_3d_neighbor, pts_2d):
     """renderer.py:1381-1386 (induce_flow_single)."""
     return render_single_3d_point(H, W, focal, pose_neighbor, pts_3d_neighbor)[0] - pts_2d
+
+
+# --------------------------------------------------------------------------------------------
+# distortion loss (train.py:19-23 imports it from torch_efficient_distloss; SURVEY.md 8f rank 2)
+# --------------------------------------------------------------------------------------------
+class _DistLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, m, interval):
+        L.require_device(w, m)
+        w, m = L.f32c(w), L.f32c(m)
+        N, S = w.shape
+        ipt = None
+        if torch.is_tensor(interval):
+            if interval.numel() == 1:
+                interval = float(interval)
+            else:
+                L.require_device(interval)
+                ipt, interval = L.f32c(interval).reshape(N, S), 0.0
+        loss_ray = torch.empty(N, device=w.device)
+        L.check(L.lib.rdrf_distloss_fwd(L.ptr(w), L.ptr(m), C.c_float(float(interval)), L.ptr(ipt), N, S,
+                                        L.ptr(loss_ray), L.stream_of(w)), "rdrf_distloss_fwd")
+        ctx.interval, ctx.ipt = float(interval), ipt
+        ctx.save_for_backward(w, m)
+        return loss_ray
+
+    @staticmethod
+    def backward(ctx, g_ray):
+        w, m = ctx.saved_tensors
+        N, S = w.shape
+        g_w = torch.zeros_like(w)
+        L.check(L.lib.rdrf_distloss_bwd(L.ptr(w), L.ptr(m), C.c_float(ctx.interval), L.ptr(ctx.ipt), N, S,
+                                        L.ptr(L.f32c(g_ray)), L.ptr(g_w), L.stream_of(w)), "rdrf_distloss_bwd")
+        return g_w, None, None
+
+
+def eff_distloss(w, m, interval):
+    """torch_efficient_distloss.eff_distloss: w, m [N,S] (m ascending along a ray), interval a scalar
+    or [N,S]; mean over rays of  sum_ij w_i w_j |m_i - m_j| + (1/3) sum_i interval w_i^2."""
+    return _DistLossFn.apply(w, m, interval).sum() / w.shape[0]
+
+
+def flatten_eff_distloss(w, m, interval, ray_id, n_rays=None):
+    """torch_efficient_distloss.flatten_eff_distloss as the reference calls it (train.py:1299-1312):
+    flattened [N*S] points with ray_id = tile(arange(N), S).  Only that regular layout is built;
+    `n_rays` (= ray_id.max() + 1) may be passed to avoid the device->host read."""
+    if n_rays is None:
+        n_rays = int(ray_id.max().item()) + 1
+        S = w.numel() // n_rays
+        if w.numel() != n_rays * S or not bool((ray_id.reshape(n_rays, S)
+                                                 == torch.arange(n_rays, device=ray_id.device)[:, None]).all()):
+            raise NotImplementedError("flatten_eff_distloss: only ray_id = tile(arange(N), S) is built")
+    S = w.numel() // n_rays
+    if torch.is_tensor(interval) and interval.numel() > 1:
+        interval = interval.reshape(n_rays, S)
+    return _DistLossFn.apply(w.reshape(n_rays, S), m.reshape(n_rays, S), interval).sum() / n_rays

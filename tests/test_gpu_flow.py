@@ -81,3 +81,33 @@ def test_induce_flow_oracle_bench_shape(rt):
             continue   # a sum over all rays, dominated by the ill-conditioned ones
         m = ok.reshape(-1, *([1] * (a.dim() - 1))).expand_as(a) if a.shape[0] == N else None
         assert_close(a, b.detach(), name, rtol=5e-4, mask=m)
+
+
+@pytest.mark.parametrize("N,S", [(33, 13), (16, 64), (7, 270), (4096, 115)])
+def test_distortion_loss_vs_bruteforce(N, S):
+    """flatten_eff_distloss (prefix-sum kernel) against the O(S^2) double sum of the oracle, value and
+    gradient, scalar and per-point interval, ragged tile counts (S not a multiple of 64)."""
+    import rodynrf
+    from oracle import rodynrf_oracle as O
+    g = torch.Generator().manual_seed(N * 1000 + S)
+    w = torch.rand(N, S, generator=g) / S
+    w[0] = 0.0
+    m = torch.sort(torch.rand(N, S, generator=g), dim=-1)[0]
+    for interval in (1.0 / S, torch.rand(N, S, generator=g) / S):
+        wr = w.clone().double().requires_grad_(True)
+        iv_ref = interval.double() if torch.is_tensor(interval) else interval
+        ref = O.eff_distloss(wr, m.double(), iv_ref)
+        gref, = torch.autograd.grad(ref, wr)
+        wg = w.clone().cuda().requires_grad_(True)
+        iv = interval.cuda() if torch.is_tensor(interval) else interval
+        ray_id = torch.arange(N, device="cuda")[:, None].expand(N, S).reshape(-1)
+        got = rodynrf.flatten_eff_distloss(wg.reshape(-1), m.cuda().reshape(-1),
+                                           iv.reshape(-1) if torch.is_tensor(iv) else iv, ray_id)
+        ggot, = torch.autograd.grad(got, wg)
+        assert_close(got, ref.float(), "distloss", rtol=2e-5)
+        assert_close(ggot, gref.float(), "d distloss / dw", rtol=1e-4)
+    got2 = rodynrf.eff_distloss(w.cuda(), m.cuda(), 1.0 / S)
+    assert_close(got2, O.eff_distloss(w.double(), m.double(), 1.0 / S).float(), "eff_distloss", rtol=2e-5)
+    with pytest.raises(NotImplementedError):
+        rodynrf.flatten_eff_distloss(w.cuda().reshape(-1), m.cuda().reshape(-1), 1.0 / S,
+                                     torch.zeros(N * S, dtype=torch.long, device="cuda") + (N - 1))
