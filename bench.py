@@ -140,6 +140,13 @@ def cpu_baseline(trainer, n_rays, S, seed=0):
         loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
         ps = list(sd_s.values()) + list(sd_d.values())
         torch.autograd.grad(loss, ps, allow_unused=True)
+        # TV regularisers of the five factor families (value NaN as in the reference: gradient only)
+        tvl = 0
+        for sd, fams in ((sd_d, ("density", "blending", "app")), (sd_s, ("density", "app"))):
+            for fam in fams:
+                tvl = tvl + O.tv_family([sd[f"{fam}_plane.{i}"] for i in range(3)],
+                                        [sd[f"{fam}_line.{i}"] for i in range(3)])
+        torch.autograd.grad(tvl, ps, allow_unused=True)
 
     step()  # warm-up
     t0 = time.perf_counter()
@@ -219,7 +226,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: Nvidia Balloon1, configs/Nvidia.txt, "
                                f"{args.rays_per_gpu} rays/iter/GPU, 1xMI355X per rank, static+dynamic "
                                "TensorVMSplit; one step = 4 dynamic + 5 static forward passes, scene-flow "
-                               "MLP, induced flow/disparity x4, compositor, full backward, Adam",
+                               "MLP, induced flow/disparity x4, compositor, TV regularisers, full backward, Adam",
                    "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
                    "global_batch": cfg["batch_size"], "weights": args.weights,
                    "parallelism": f"ray-sharded dp{world}", "final_loss": loss_val},

@@ -212,6 +212,25 @@ int rdrf_distloss_fwd(const float* w, const float* m, float interval, const floa
 int rdrf_distloss_bwd(const float* w, const float* m, float interval, const float* interval_pt,
                       int N, int S, const float* g_ray, float* g_w, rdrf_stream_t stream);
 
+/* ---- total-variation regulariser of the factor tensors (utils.py:157-181 TVLoss, applied to every
+ * plane / line by models/tensoRF.py:100-116, 418-444 each iteration of configs/Nvidia.txt).
+ * One launch handles up to RDRF_TV_MAX logical (1,C,H,W) views with arbitrary element strides
+ * (channel-last storage included).  sums[t] = { sum (x[h+1]-x[h])^2 , sum (x[w+1]-x[w])^2 }; the
+ * caller forms TVLoss_weight * 2 * (h_tv/count_h + w_tv/count_w) / batch exactly as the reference
+ * does (a line has count_w = 0, so the reference's VALUE is 0/0 = NaN while its gradient is finite;
+ * that is reproduced by doing this scalar arithmetic on the host side of the ABI, in torch).
+ * bwd: g_x[t] (same strides as x[t]) += g_sums[t][0] * d h_tv/dx + g_sums[t][1] * d w_tv/dx, the
+ * second term skipped when W == 1 (its coefficient is 2/0 there). g_sums is a DEVICE array. */
+#define RDRF_TV_MAX 16
+typedef struct {
+  const float* x;
+  float* g;            /* gradient buffer (bwd only) */
+  int C, H, W;
+  long long sC, sH, sW;  /* element strides of the (1,C,H,W) view */
+} RdrfTensor4;
+int rdrf_tv_fwd(const RdrfTensor4* t, int n, float* sums /* [n][2], overwritten */, rdrf_stream_t stream);
+int rdrf_tv_bwd(const RdrfTensor4* t, int n, const float* g_sums /* [n][2] */, rdrf_stream_t stream);
+
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
  * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].
  * scratch for the per-sample tensors comes out of ws (rdrf_render_workspace_bytes). */

@@ -77,9 +77,18 @@ SYMBOLS = [
     "rdrf_static_fwd", "rdrf_static_bwd", "rdrf_dynamic_fwd", "rdrf_dynamic_bwd",
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
+    "rdrf_tv_fwd", "rdrf_tv_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]
+
+
+class RdrfTensor4(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("g", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("sC", C.c_longlong), ("sH", C.c_longlong), ("sW", C.c_longlong)]
+
+
+TV_MAX = 16
 
 
 class RdrfError(RuntimeError):

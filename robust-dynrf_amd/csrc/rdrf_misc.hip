@@ -842,3 +842,103 @@ extern "C" int rdrf_distloss_bwd(const float* w, const float* m, float interval,
               g_ray, g_w);
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// TV regulariser of the VM factors: one launch over all tensors of a factor family.  Elements are
+// walked in (slow, fast, c) order with c fastest, which is memory order for the channel-last
+// storage: 17 MB of factors are read once per pass (HBM-trivial; the torch formulation is ~16 small
+// kernels per tensor per direction).
+// ------------------------------------------------------------------------------------------------
+struct TvJobs {
+  RdrfTensor4 t[RDRF_TV_MAX];
+  int n;
+};
+RDRF_D void tv_decode(const RdrfTensor4& T, long long i, int& c, int& h, int& w, long long& off) {
+  c = (int)(i % T.C);
+  const long long r = i / T.C;
+  if (T.sW <= T.sH) { w = (int)(r % T.W); h = (int)(r / T.W); }
+  else { h = (int)(r % T.H); w = (int)(r / T.H); }
+  off = c * T.sC + h * T.sH + w * T.sW;
+}
+__global__ __launch_bounds__(256) void k_tv_fwd(TvJobs J, float* __restrict__ sums) {
+  const RdrfTensor4& T = J.t[blockIdx.y];
+  const long long total = (long long)T.C * T.H * T.W;
+  float sh = 0.f, sw = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c, h, w;
+    long long off;
+    tv_decode(T, i, c, h, w, off);
+    const float v = T.x[off];
+    if (h + 1 < T.H) { const float d = T.x[off + T.sH] - v; sh += d * d; }
+    if (w + 1 < T.W) { const float d = T.x[off + T.sW] - v; sw += d * d; }
+  }
+  __shared__ float red[2][4];
+  sh = wave_sum(sh); sw = wave_sum(sw);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = sh; red[1][wave] = sw; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + blockIdx.y * 2 + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(sums + blockIdx.y * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+__global__ __launch_bounds__(256) void k_tv_bwd(TvJobs J, const float* __restrict__ g_sums) {
+  const RdrfTensor4& T = J.t[blockIdx.y];
+  const long long total = (long long)T.C * T.H * T.W;
+  const float gh = T.H > 1 ? 2.0f * g_sums[blockIdx.y * 2 + 0] : 0.f;
+  const float gw = T.W > 1 ? 2.0f * g_sums[blockIdx.y * 2 + 1] : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c, h, w;
+    long long off;
+    tv_decode(T, i, c, h, w, off);
+    const float v = T.x[off];
+    float g = 0.f;
+    if (T.H > 1) {
+      const float a = h > 0 ? v - T.x[off - T.sH] : 0.f, b = h + 1 < T.H ? T.x[off + T.sH] - v : 0.f;
+      g += gh * (a - b);
+    }
+    if (T.W > 1) {
+      const float a = w > 0 ? v - T.x[off - T.sW] : 0.f, b = w + 1 < T.W ? T.x[off + T.sW] - v : 0.f;
+      g += gw * (a - b);
+    }
+    T.g[off] += g;
+  }
+}
+static int tv_jobs(TvJobs& J, const RdrfTensor4* t, int n, bool need_g, long long& maxel) {
+  RDRF_CHECK(t && n > 0 && n <= RDRF_TV_MAX, -1, "tv: 1..RDRF_TV_MAX tensors per call");
+  J.n = n;
+  maxel = 0;
+  for (int i = 0; i < n; ++i) {
+    RDRF_CHECK(t[i].x && t[i].C > 0 && t[i].H > 0 && t[i].W > 0 && (!need_g || t[i].g), -1, "tv: bad tensor");
+    J.t[i] = t[i];
+    const long long e = (long long)t[i].C * t[i].H * t[i].W;
+    maxel = e > maxel ? e : maxel;
+  }
+  return 0;
+}
+extern "C" int rdrf_tv_fwd(const RdrfTensor4* t, int n, float* sums, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TvJobs J;
+  long long maxel;
+  int rc = tv_jobs(J, t, n, false, maxel);
+  if (rc) return rc;
+  RDRF_CHECK(sums, -1, "tv_fwd: sums is null");
+  RDRF_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * n, stream));
+  long long gx = (maxel + 256 * 8 - 1) / (256 * 8);
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  RDRF_LAUNCH("tv_fwd", k_tv_fwd, dim3((unsigned)gx, n), dim3(256), stream, J, sums);
+  return 0;
+}
+extern "C" int rdrf_tv_bwd(const RdrfTensor4* t, int n, const float* g_sums, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TvJobs J;
+  long long maxel;
+  int rc = tv_jobs(J, t, n, true, maxel);
+  if (rc) return rc;
+  RDRF_CHECK(g_sums, -1, "tv_bwd: g_sums is null");
+  long long gx = (maxel + 256 * 8 - 1) / (256 * 8);
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  RDRF_LAUNCH("tv_bwd", k_tv_bwd, dim3((unsigned)gx, n), dim3(256), stream, J, g_sums);
+  return 0;
+}

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
+from .regularizers import tv_family
 
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
@@ -540,6 +541,13 @@ class TensorVMSplit(TensorBase):
     def warp_coordinate(self, xyz_sampled, t_sampled):
         return None
 
+    # models/tensoRF.py:100-116
+    def TV_loss_density(self, reg):
+        return tv_family(self, reg, self.density_plane, self.density_line)
+
+    def TV_loss_app(self, reg):
+        return tv_family(self, reg, self.app_plane, self.app_line)
+
     def forward(self, rays_chunk, ts_chunk, timeembeddings_chunk, xyz_sampled, z_vals, ray_valid,
                 white_bg=True, is_train=False, ray_type="ndc", N_samples=-1):
         if timeembeddings_chunk is not None:
@@ -622,6 +630,16 @@ class TensorVMSplit_TimeEmbedding(TensorBase):
         blending, weight, xyz_prime, rgb, sigma, dists = _DynamicFn.apply(
             self, ray_type, rays_chunk, ts_chunk, xyz_sampled, z_vals, ray_valid, *self._param_list())
         return (None, None, blending, xyz_sampled, weight, xyz_prime, rgb, sigma, z_vals, dists)
+
+    # models/tensoRF.py:418-444
+    def TV_loss_blending(self, reg):
+        return tv_family(self, reg, self.blending_plane, self.blending_line)
+
+    def TV_loss_density(self, reg):
+        return tv_family(self, reg, self.density_plane, self.density_line)
+
+    def TV_loss_app(self, reg):
+        return tv_family(self, reg, self.app_plane, self.app_line)
 
     def get_forward_backward_scene_flow(self, unnormalized_pts, t_sampled):
         return _SceneFlowFn.apply(self, unnormalized_pts, t_sampled, *self._param_list())

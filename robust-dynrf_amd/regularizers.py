@@ -1,0 +1,117 @@
+"""Factor-space regularisers of the reference, fused.
+
+TVLoss mirrors utils.py:157-181; the fields' TV_loss_density / TV_loss_blending / TV_loss_app
+(models/tensoRF.py:100-116, 418-444) hand it all six tensors of a factor family at once, so a family
+costs one forward and one backward launch instead of ~16 small torch kernels per tensor per
+direction.  The reference's value arithmetic -- including its 0/0 = NaN for lines, whose count_w is
+zero, with finite gradients -- is kept by doing the scalar part in torch on the kernel's sums."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def _tensor4(x, g=None):
+    if x.dim() != 4 or x.shape[0] != 1:
+        raise L.RdrfError("TVLoss: expected a (1, C, H, W) tensor (utils.py:163)")
+    s = x.stride()
+    return L.RdrfTensor4(x.data_ptr(), 0 if g is None else g.data_ptr(), x.shape[1], x.shape[2], x.shape[3],
+                         s[1], s[2], s[3])
+
+
+class _TVSumsFn(torch.autograd.Function):
+    """sums[t] = (sum of squared H-differences, sum of squared W-differences) of each tensor"""
+
+    @staticmethod
+    def forward(ctx, field, *xs):
+        L.require_device(*xs)
+        if not 0 < len(xs) <= L.TV_MAX:
+            raise L.RdrfError(f"TVLoss: 1..{L.TV_MAX} tensors per call")
+        if any(x.dtype != torch.float32 for x in xs):
+            raise L.RdrfError("TVLoss: fp32 tensors only")
+        arr = (L.RdrfTensor4 * len(xs))(*[_tensor4(x) for x in xs])
+        sums = torch.empty(len(xs), 2, device=xs[0].device)
+        L.check(L.lib.rdrf_tv_fwd(arr, len(xs), L.ptr(sums), L.stream_of(xs[0])), "rdrf_tv_fwd")
+        ctx.field = field
+        ctx.save_for_backward(*xs)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        xs = ctx.saved_tensors
+        field = ctx.field
+        fused = field is not None and field.fused_grad
+        if fused:   # accumulate straight into p.grad (views of the field's flat buffer)
+            views = {p.data_ptr(): v for p, v in zip(field._param_list(), field.fused_grads())}
+            grads = [views[x.data_ptr()] for x in xs]
+        else:
+            grads = [torch.zeros_like(x) for x in xs]   # preserve_format keeps the channel-last strides
+        arr = (L.RdrfTensor4 * len(xs))(*[_tensor4(x, g) for x, g in zip(xs, grads)])
+        L.check(L.lib.rdrf_tv_bwd(arr, len(xs), L.ptr(L.f32c(g_sums)), L.stream_of(xs[0])), "rdrf_tv_bwd")
+        return (None, *([None] * len(xs) if fused else grads))
+
+
+class TVLoss(nn.Module):
+    """utils.py:157-181, same constructor / call signature."""
+
+    def __init__(self, TVLoss_weight=1):
+        super().__init__()
+        self.TVLoss_weight = TVLoss_weight
+
+    _cache = {}
+
+    def _counts(self, shapes, device):
+        """(count_h, count_w, batch) of utils.py:166-167 as device vectors, cached per shape list"""
+        key = (tuple(shapes), str(device))
+        c = TVLoss._cache.get(key)
+        if c is None:
+            ch = torch.tensor([c_ * (h - 1) * w for _, c_, h, w in shapes], dtype=torch.float32, device=device)
+            cw = torch.tensor([c_ * h * (w - 1) for _, c_, h, w in shapes], dtype=torch.float32, device=device)
+            b = torch.tensor([b_ for b_, _, _, _ in shapes], dtype=torch.float32, device=device)
+            c = TVLoss._cache[key] = (ch, cw, b)
+        return c
+
+    def _value(self, sums, shapes, ignore_axis=None):
+        """per-tensor losses (a vector) from the kernel sums with the reference's scalar arithmetic,
+        vectorised over the tensors: x / 0 is NaN / inf exactly as `tensor / 0` is in the reference"""
+        ch, cw, b = self._counts(shapes, sums.device)
+        h_tv, w_tv = sums[:, 0], sums[:, 1]
+        if ignore_axis is None:
+            return self.TVLoss_weight * 2 * (h_tv / ch + w_tv / cw) / b
+        if ignore_axis == "h":
+            return self.TVLoss_weight * 2 * (w_tv / cw) / b
+        if ignore_axis == "w":
+            return self.TVLoss_weight * 2 * (h_tv / ch) / b
+        raise ValueError(ignore_axis)
+
+    def many(self, xs, field=None):
+        """vector of per-tensor losses for up to 16 tensors with ONE forward / backward launch"""
+        sums = _TVSumsFn.apply(field, *xs)
+        return self._value(sums, [tuple(x.shape) for x in xs])
+
+    def forward(self, x, ignore_axis=None):
+        sums = _TVSumsFn.apply(None, x)
+        return self._value(sums, [tuple(x.shape)], ignore_axis)[0]
+
+
+_coef = {}
+
+
+def tv_family(field, reg, planes, lines):
+    """models/tensoRF.py:100-116 / 418-444: sum_i reg(plane_i) * 1e-2 + reg(line_i) * 1e-3, in the
+    reference's accumulation order.  A rodynrf TVLoss takes the fused path; any other callable is
+    applied tensor by tensor exactly as the reference does."""
+    planes, lines = list(planes), list(lines)
+    if isinstance(reg, TVLoss):
+        vals = reg.many(planes + lines, field)
+        key = (len(planes), len(lines), str(vals.device))
+        coef = _coef.get(key)
+        if coef is None:
+            coef = _coef[key] = torch.tensor([1e-2] * len(planes) + [1e-3] * len(lines), device=vals.device)
+        return (vals * coef).sum()
+    total = 0
+    for p, l in zip(planes, lines):
+        total = total + reg(p) * 1e-2 + reg(l) * 1e-3
+    return total

@@ -31,6 +31,7 @@ import torch
 
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
+from .regularizers import TVLoss
 from .renderer import induce_flow, raw2outputs, sampleXYZ
 
 
@@ -180,6 +181,7 @@ class Trainer:
             self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99))
         self.it = 0
         self.coin = torch.Generator().manual_seed(7)
+        self.tv = TVLoss()
         # backward passes accumulate straight into p.grad (views of one flat buffer per field)
         self.st.fused_grad = self.dy.fused_grad = True
         self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
@@ -248,8 +250,16 @@ class Trainer:
         m = (1.0 - fg)[:, None]
         loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
         loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
+        # ---- TV regularisers of every factor family (train.py:1735-1754, 1872-1885;
+        #      configs/Nvidia.txt: TV_weight_density = TV_weight_app = 1.0).  The VALUE is NaN in the
+        #      reference (line tensors have count_w = 0) while the gradients are finite, so it is
+        #      kept out of the reported loss and only its gradient is taken, by a second backward.
+        tvl = (self.dy.TV_loss_density(self.tv) + self.dy.TV_loss_blending(self.tv)
+               + self.dy.TV_loss_app(self.tv) + self.st.TV_loss_density(self.tv)
+               + self.st.TV_loss_app(self.tv))
         self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
         loss.backward()
+        tvl.backward()
         return loss
 
     def finish_step(self):

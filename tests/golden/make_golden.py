@@ -298,8 +298,46 @@ def gen_induce_flow(mods):
     print("induce_flow: ok")
 
 
+def gen_tv(mods):
+    """utils.py:157-181 TVLoss on single tensors (incl. a line: value NaN, gradient finite) and the
+    fields' TV_loss_* family sums (models/tensoRF.py:100-116, 418-444) on the weights of the
+    ndc_relu case, with gradients."""
+    TS, TD, _, _, _ = mods
+    import utils as ref_utils
+    tv = ref_utils.TVLoss()
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    for name, shape in (("plane", (1, 4, 9, 7)), ("line", (1, 16, 11, 1)), ("row", (1, 3, 1, 8))):
+        x = torch.randn(shape, generator=g, requires_grad=True)
+        out[f"t.{name}.x"] = x.detach().numpy()
+        for ax in (None, "h", "w"):
+            v = tv(x, ax) if ax else tv(x)
+            gx, = torch.autograd.grad(v, x, allow_unused=True)
+            out[f"t.{name}.v.{ax}"] = v.detach().numpy()
+            out[f"t.{name}.g.{ax}"] = (torch.zeros_like(x) if gx is None else gx).numpy()
+    case = np.load(os.path.join(HERE, "ndc_relu.npz"), allow_pickle=True)
+    grid = [int(v) for v in case["meta.grid"]]
+    st, dy = build_fields(TS, TD, torch.from_numpy(case["aabb"]), grid, "relu", "MLP_Fea", -10.0, 1)
+    st.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("s.")})
+    dy.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("d.")})
+    for tag, mod, fams in (("s", st, ("density", "app")), ("d", dy, ("density", "blending", "app"))):
+        for fam in fams:
+            total = getattr(mod, f"TV_loss_{fam}")(tv)
+            ps = list(getattr(mod, f"{fam}_plane")) + list(getattr(mod, f"{fam}_line"))
+            gs = torch.autograd.grad(total, ps)
+            out[f"f.{tag}.{fam}.total"] = total.detach().numpy()
+            for i, gg in enumerate(gs):
+                nm = f"{fam}_plane.{i}" if i < 3 else f"{fam}_line.{i - 3}"
+                out[f"f.{tag}.{fam}.g.{nm}"] = gg.numpy()
+    np.savez(os.path.join(HERE, "tv.npz"), **out)
+    print("tv: ok", float(out["f.s.density.total"]))
+
+
 if __name__ == "__main__":
     mods = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "tv":
+        gen_tv(mods)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "induce_flow":
         gen_induce_flow(mods)
         sys.exit(0)
@@ -312,3 +350,4 @@ if __name__ == "__main__":
              12, 13, 20211206, -1.0, False)
     gen_raygen(mods)
     gen_induce_flow(mods)
+    gen_tv(mods)
