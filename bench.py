@@ -111,8 +111,11 @@ def cpu_baseline(trainer, n_rays, S, seed=0):
         _, oA, outA, xyzA = rp(rays, ts, False, True, True)
         loss = 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
         loss = loss + 0.1 * (outA[12] - fg).abs().mean() + 0.04 * (outA[9] - disp_t).abs().mean()
+        w_dist = 0.01 * 1e-5
+        loss = loss + w_dist * O.eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
         _, oB, outB, _ = rp(rays, ts_of(ids2), False, True, False)
         loss = loss + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+        loss = loss + w_dist * O.eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
         sf_f, sf_b = O.scene_flow(sd_d, aabb, oA[3], ts)
         w_d = outA[11].detach()[..., None]
         loss = loss + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
@@ -134,6 +137,7 @@ def cpu_baseline(trainer, n_rays, S, seed=0):
             ind_disp, mask_t, pose_n = disp_A[sgn]
             _, ind_disp_n = O.induce_flow(H, W, focal, pose_n, outN[11], oN[3], grid, rays_n, "ndc")
             loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
+            loss = loss + w_dist * O.eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
         _, _, outE, _ = rp(rays, ts, True, False, False)
         m = (1.0 - fg)[:, None]
         loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
@@ -226,7 +230,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: Nvidia Balloon1, configs/Nvidia.txt, "
                                f"{args.rays_per_gpu} rays/iter/GPU, 1xMI355X per rank, static+dynamic "
                                "TensorVMSplit; one step = 4 dynamic + 5 static forward passes, scene-flow "
-                               "MLP, induced flow/disparity x4, compositor, TV regularisers, full backward, Adam",
+                               "MLP, induced flow/disparity x4, distortion loss x4, compositor, TV regularisers, full backward, Adam",
                    "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
                    "global_batch": cfg["batch_size"], "weights": args.weights,
                    "parallelism": f"ray-sharded dp{world}", "final_loss": loss_val},

@@ -32,7 +32,7 @@ import torch
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
-from .renderer import induce_flow, raw2outputs, sampleXYZ
+from .renderer import eff_distloss, induce_flow, raw2outputs, sampleXYZ
 
 
 def balloon1_config(stage="stage0"):
@@ -213,10 +213,15 @@ class Trainer:
         loss = loss + 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
         loss = loss + 0.1 * (outA[12] - fg).abs().mean()
         loss = loss + 0.04 * (outA[9] - disp_t).abs().mean()
+        # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716;
+        # configs/Nvidia.txt distortion_weight_dynamic = 0.01, ramped by iteration / n_iters)
+        w_dist = 0.01 * min(1.0, (it + 1) / 100000.0)
+        loss = loss + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
         # ---- pass B (second random time)
         ts_b = d.ts_of(ids2)
         _, oB, outB, _ = ray_pass(self.st, self.dy, rays, ts_b, S, rt, white=coin())
         loss = loss + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+        loss = loss + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
         w_d = outA[11].detach()[..., None]
@@ -244,6 +249,7 @@ class Trainer:
             ind_disp, mask_t, pose_n = disp_A[sgn]
             _, ind_disp_n = induce_flow(H, W, d.focal, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
             loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
+            loss = loss + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
         # ---- pass E: static field with gradient
         _, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, static_grad=True, dynamic=False,
                                  white=coin())
