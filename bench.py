@@ -196,7 +196,9 @@ def main():
 
     def one_step():
         loss = trainer.step(shard)
-        bucket.allreduce_()
+        # every rank's loss is a mean over ITS rays (and the full TV term): the mean over ranks is the
+        # gradient of the global-batch loss
+        bucket.allreduce_(average=True)
         trainer.finish_step()
         return loss
 
