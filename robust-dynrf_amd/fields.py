@@ -172,6 +172,7 @@ def _prep_inputs(rays, ts, xyz, z, valid):
 class _StaticFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, field, ray_type, rays, ts, xyz, z, valid, *params):
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None: their branch is skipped
         rays, ts, xyz, z, valid = _prep_inputs(rays, ts, xyz, z, valid)
         N, S = z.shape
         dev = z.device
@@ -224,6 +225,7 @@ class _StaticFn(torch.autograd.Function):
 class _DynamicFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, field, ray_type, rays, ts, xyz, z, valid, *params):
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None: their branch is skipped
         rays, ts, xyz, z, valid = _prep_inputs(rays, ts, xyz, z, valid)
         N, S = z.shape
         dev = z.device
@@ -276,6 +278,7 @@ class _DynamicFn(torch.autograd.Function):
 class _SceneFlowFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, field, pts, ts, *params):
+        ctx.set_materialize_grads(False)
         L.require_device(pts, ts)
         pts, ts = L.f32c(pts), L.f32c(ts)
         N, S, _ = pts.shape

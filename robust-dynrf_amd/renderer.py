@@ -11,6 +11,7 @@ from . import _lib as L
 class _SampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays, aabb_host, near, far, S, ray_type, jitter, jitter_outer):
+        ctx.set_materialize_grads(False)
         L.require_device(rays)
         rays = L.f32c(rays)
         N = rays.shape[0]
@@ -39,6 +40,8 @@ class _SampleFn(torch.autograd.Function):
     def backward(ctx, g_xyz, g_z, g_valid):
         rays, z = ctx.saved_tensors
         N, S = z.shape
+        if g_xyz is None:   # z_vals / valid carry no gradient to the rays
+            return None, None, None, None, None, None, None, None
         g_rays = torch.zeros_like(rays)
         g_xyz = L.f32c(g_xyz)
         L.check(L.lib.rdrf_sample_bwd(L.ptr(rays), L.ptr(z), N, S, L.RAY_TYPES[ctx.ray_type],
@@ -81,6 +84,7 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z_vals, rays, ray_type,
                 add_white_bg):
+        ctx.set_materialize_grads(False)
         L.require_device(rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z_vals, rays)
         ins = [L.f32c(t) for t in (rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z_vals, rays)]
         N, S = ins[1].shape
@@ -100,7 +104,12 @@ class _CompositeFn(torch.autograd.Function):
         ins = ctx.saved_tensors
         N, S = ins[1].shape
         g_out = [None if g is None else L.f32c(g) for g in g_out]
-        need = ctx.needs_input_grad[:8]
+        need = list(ctx.needs_input_grad[:8])
+        # like autograd on the reference's op graph, a branch no loss reaches gets NO gradient (not a
+        # zero one): rgb_s only feeds rgb_map_full / rgb_map_s, rgb_d only rgb_map_full / rgb_map_d.
+        # The field's backward then skips its whole appearance half (MLP, scatter, dW) for that pass.
+        need[0] = need[0] and (g_out[0] is not None or g_out[4] is not None)
+        need[2] = need[2] and (g_out[0] is not None or g_out[8] is not None)
         g_in = [torch.zeros_like(t) if n else None for t, n in zip(ins, need)]
         ga = (C.c_void_p * 13)(*[0 if g is None else g.data_ptr() for g in g_out])
         gi = (C.c_void_p * 8)(*[0 if g is None else g.data_ptr() for g in g_in])
@@ -181,6 +190,7 @@ def _focal_tensor(focal, dev):
 class _InduceFlowFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, H, W, focal, c2w, weights, pts, pts_2d, rays, ray_type):
+        ctx.set_materialize_grads(False)
         L.require_device(c2w, weights, pts, pts_2d, rays)
         c2w, weights, pts, pts_2d, rays = (L.f32c(t) for t in (c2w, weights, pts, pts_2d, rays))
         focal = L.f32c(focal)

@@ -62,7 +62,7 @@ def test_golden_gradients(case):
     assert not bad, "\n".join(bad)
 
 
-def _midsize_once(seed):
+def _midsize_once(seed, loss_kind="full"):
     import rodynrf
     from _gpu_util import COMMON, make_rays, oracle_cfg, oracle_sd
     from oracle import rodynrf_oracle as O
@@ -89,6 +89,9 @@ def _midsize_once(seed):
     sf = O.scene_flow(sd_d, aabb, r_d[3], ts)
 
     def loss(outs, sf, t):  # the three image terms of train.py:1323-1332,1827-1835 + extras
+        if loss_kind == "no_rgb":   # passes B-D of the trainer: only weights / depths / dynamicness
+            return (0.1 * outs[12].mean() + 0.05 * outs[9].mean() + (outs[11] ** 2).sum()
+                    + 0.01 * (sf[0] ** 2).mean())
         return (3 * ((outs[0] - t) ** 2).mean() + ((outs[8] - t) ** 2).mean() + ((outs[4] - t) ** 2).mean()
                 + 0.1 * outs[12].mean() + 0.05 * outs[9].mean() + 0.01 * (sf[0] ** 2).mean()
                 + 0.01 * (sf[1] ** 2).mean())
@@ -111,6 +114,10 @@ def _midsize_once(seed):
     bad, worst_l2 = [], 0.0
     for name, gr in zip(["gs." + k for k in ks] + ["gd." + k for k in kd], gref):
         if gr is None:
+            # a branch no loss reaches: autograd gives the reference no gradient, and ours must not
+            # have run either (no zero-filled tensor, i.e. the appearance backward was skipped)
+            g0 = own[name].grad
+            assert g0 is None or float(g0.abs().max()) == 0.0, f"{name}: expected no gradient (pruned branch)"
             continue
         a = own[name].grad.detach().cpu().double()
         b = gr.double()
@@ -138,6 +145,32 @@ def test_oracle_gradients_midsize():
             return
         msgs.append(f"seed {seed}: " + "; ".join(bad))
     raise AssertionError("no seed matched element-wise:\n" + "\n".join(msgs))
+
+
+def test_pruned_branches_match_autograd():
+    """A loss without any RGB term (trainer passes B-D): density / blending / warp gradients match the
+    oracle and every appearance parameter gets NO gradient -- the appearance backward, its scatter
+    and its dW jobs are skipped exactly as autograd skips them in the reference."""
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("robust-dynrf_amd._lib")
+
+    def launches(name):
+        ms, n = C.c_double(0), C.c_int(0)
+        L.lib.rdrf_prof_get(name.encode(), C.byref(ms), C.byref(n))
+        return n.value
+
+    L.lib.rdrf_prof_enable(1)
+    L.lib.rdrf_prof_reset()
+    try:
+        bad, l2 = _midsize_once(5, "no_rgb")
+        torch.cuda.synchronize()
+        assert launches("dyn_heads_bwd") == 1 and launches("scatter_dyn_density") == 1
+        for k in ("dyn_app_bwd", "scatter_dyn_app", "static_app_bwd", "scatter_static_app", "dw_static"):
+            assert launches(k) == 0, f"{k} ran although no loss reaches the appearance branch"
+    finally:
+        L.lib.rdrf_prof_enable(0)
+    assert l2 < 2e-2 and not bad, "\n".join(bad)
 
 
 def test_raygen_gradients_golden():
