@@ -290,20 +290,42 @@ def main():
         dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
         dw_b = sum(dw_bytes[k] * table[k]["launches_per_step"] for k in dw_keys)
         dw_f = sum(flops[k] * table[k]["launches_per_step"] for k in dw_keys)
-        ach_gbs = dw_b / (dw_ms * 1e-3) / 1e9
-        out["roofline"] = {
-            "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": ach_gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("k_dw"), "kernel": "k_dw",
-            "kernel_avg_us": dw_ms / dw_launch * 1e3, "launches_per_step": dw_launch,
-            "algorithmic_bytes_per_launch": dw_b / dw_launch,
+        dw_entry = {
+            "bound": "hbm", "achieved": dw_b / (dw_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": dw_b / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": pmc_traffic("k_dw"),
+            "kernel": "k_dw", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
+            "launches_per_step": dw_launch, "algorithmic_bytes_per_launch": dw_b / dw_launch,
             "mfma": {"achieved_tflops": dw_f / (dw_ms * 1e-3) / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
-                     "frac": dw_f / (dw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                     "frac": dw_f / (dw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+        # k_scatter (VM gather backward): per sample it re-gathers the taps (B), read-modify-writes the
+        # same texels of the gradient factors (2B) and reads the d(feature) row entries (4 B per
+        # component): B = 1728 B for a 72-component family, 5184 B for the 216-component appearance.
+        # These bytes are L2 / Infinity-Cache resident (9-17 MB of factors), so `achieved` may exceed
+        # what HBM sees (`traffic`); the kernel is bound by the L2 atomic request rate.
+        sc_bytes = {"scatter_dyn_density": ns * valid_frac * 2 * (3 * 1728 + 288.0),
+                    "scatter_dyn_app": ns * f_d * (3 * 5184 + 864.0),
+                    "scatter_static_app": ns * f_s * (3 * 1728 + 288.0)}
+        sc_keys = [k for k in sc_bytes if k in table]
+        sc_ms = sum(table[k]["ms_per_step"] for k in sc_keys)
+        sc_launch = sum(table[k]["launches_per_step"] for k in sc_keys)
+        sc_b = sum(sc_bytes[k] * table[k]["launches_per_step"] for k in sc_keys)
+        sc_entry = {
+            "bound": "hbm", "achieved": sc_b / (sc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": pmc_traffic("void k_scatter<4; 1; 9>"),
+            "kernel": "k_scatter", "ms_per_step": sc_ms, "kernel_avg_us": sc_ms / sc_launch * 1e3,
+            "launches_per_step": sc_launch, "algorithmic_bytes_per_launch": sc_b / sc_launch,
+            "limiter": "L2 fp32-atomic request rate (~20 G requests/s, tools/ubench/atomics.hip); bytes are "
+                       "cache-resident, traffic is the PMC figure of the density/blending launch"}
+        dom_e, oth_e = (sc_entry, dw_entry) if sc_ms >= dw_ms else (dw_entry, sc_entry)
+        out["roofline"] = dict(dom_e)
+        out["roofline"].update({
+            "second_kernel": oth_e,
             "step_algorithmic_tflop": step_flops / 1e12,
             "step_frac_of_peak": step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in table.items()},
             "sum_kernel_ms_per_step": tot_ms,
             "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s},
-        }
+        })
         # SURVEY.md section 8(d) canonical constants: per sample B_fwd(f) = 4032 + 6912 f bytes,
         # F_fwd(f) = 66004 + 145362 f FLOP (f = app-mask fraction averaged over both fields); one
         # training ray-pass = S * (4 B_fwd, 3 F_fwd); training ray = 5 ray-passes (Nvidia.txt).

@@ -400,6 +400,90 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
 }
 
+// XZ / YZ quads of the ray-tile scatter, column-split: BOTH half-waves work on the same quad g of the
+// same 32 samples; half h owns the bilinear column ix + h (its lower and upper row taps) and the line
+// tap h.  The run structure is identical in the two halves, so in every atomic instruction the lanes
+// of half 0 carry texel (iy, ix) and the same lanes of half 1 carry texel (iy, ix + 1): with x-fastest
+// plane storage these are 16 bytes apart and the L2 coalescer (which merges same-line lanes across
+// the whole wave, tools/ubench/atomics.hip kernels G/H) makes ONE request of them -- half the atomic
+// requests of the XZ / YZ planes, which were ~1/3 of the density scatter's time.
+// Coordinate gradients are computed by both halves and halved (x*0.5 + x*0.5 is exact).
+template <int C0Q, int C1Q>
+RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, float x0, float x1, float x2,
+                             f32x4 dq, bool live, int s, float& dx0, float& dx1, float& dx2,
+                             const LdsLines ll) {
+  QuadSel<C0Q, C1Q> sl = quad_sel<C0Q, C1Q>(g);
+  const int pi = sl.pi;   // 1 or 2 (wave-uniform)
+  const float cx = pi == 2 ? x1 : x0;
+  const float cy = x2;
+  const float cl = pi == 1 ? x1 : x0;
+  const float* P = pi == 1 ? vm.plane[1] : vm.plane[2];
+  const float* Lp = pi == 1 ? vm.line[1] : vm.line[2];
+  float* GP = pi == 1 ? gvm.plane[1] : gvm.plane[2];
+  float* GL = pi == 1 ? gvm.line[1] : gvm.line[2];
+  const int H = pi == 1 ? vm.H[1] : vm.H[2], W = pi == 1 ? vm.W[1] : vm.W[2], L = pi == 1 ? vm.L[1] : vm.L[2];
+  const int sH = pi == 1 ? vm.sH[1] : vm.sH[2], sW = pi == 1 ? vm.sW[1] : vm.sW[2];
+  const int lv = sl.level, st = 1 << lv;
+  const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
+  Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
+  const int C = sl.C, qo = 4 * sl.q;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
+  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
+  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
+  f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo), v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+  f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo), v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
+  f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo), a1 = ld4(Lp + (size_t)l1c * C + qo);
+  if (!(live && ty.ok0 && tx.ok0)) v00 = zero;
+  if (!(live && ty.ok0 && tx.ok1)) v01 = zero;
+  if (!(live && ty.ok1 && tx.ok0)) v10 = zero;
+  if (!(live && ty.ok1 && tx.ok1)) v11 = zero;
+  if (!(live && tl.ok0)) a0 = zero;
+  if (!(live && tl.ok1)) a1 = zero;
+  const f32x4 pv = v00 * (tx.w0 * ty.w0) + v01 * (tx.w1 * ty.w0) + v10 * (tx.w0 * ty.w1) +
+                   v11 * (tx.w1 * ty.w1);
+  const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
+  const f32x4 dp = live ? dq * lvv : zero;
+  const f32x4 dl = live ? dq * pv : zero;
+  // this half's column
+  const float wxc = h ? tx.w1 : tx.w0;
+  const bool okc = h ? tx.ok1 : tx.ok0;
+  const int ixc = tx.i0 + h;
+  const bool g0 = ty.ok0 && okc, g1 = ty.ok1 && okc;
+  const size_t o0 = (size_t)((ty.i0 << lv) * sH + (ixc << lv) * sW) + qo;
+  const size_t o1 = (size_t)(((ty.i0 + 1) << lv) * sH + (ixc << lv) * sW) + qo;
+  const int pkey = ((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff);   // same key in both halves
+  const Run pr = run_of(pkey, s);
+  f32x4 r0 = run_scan4((live && g0) ? dp * (wxc * ty.w0) : zero, pr.start, s);
+  const f32x4 r1 = run_scan4((live && g1) ? dp * (wxc * ty.w1) : zero, pr.start, s);
+  // cross-run merge along the row axis (see gather_quad_bwd)
+  const int pl = pr.start > 0 ? pr.start - 1 : 0;
+  const int pk = __shfl(pkey, pl, 32);
+  const bool chain_prev = pr.start > 0 && pk == pkey - (1 << 16);
+  const float ux = __shfl(r1.x, pl, 32), uy = __shfl(r1.y, pl, 32), uz = __shfl(r1.z, pl, 32),
+              uw = __shfl(r1.w, pl, 32);
+  if (chain_prev) { r0.x += ux; r0.y += uy; r0.z += uz; r0.w += uw; }
+  const int nk = dppi<0x130>(pkey);
+  const bool up_ok = !(s < 31 && nk == pkey + (1 << 16));
+  atomic_add4(GP, o0, r0, pr.tail && g0 && nz4(r0));
+  atomic_add4(GP, o1, r1, pr.tail && up_ok && g1 && nz4(r1));
+  // line tap h
+  {
+    const Run lr = run_of(tl.i0 + 4, s);
+    const bool okl = h ? tl.ok1 : tl.ok0;
+    const f32x4 r = run_scan4((live && okl) ? dl * (h ? tl.w1 : tl.w0) : zero, lr.start, s);
+    const bool doit = lr.tail && okl && nz4(r);
+    const int li = tl.i0 + h;
+    if (ll.base) lds_add4(ll.base + (pi == 1 ? ll.off[1] : ll.off[2]), (li << lv) * lds_stride(C) + qo, r, doit);
+    else atomic_add4(GL, (size_t)(li << lv) * C + qo, r, doit);
+  }
+  const float gcx = 0.25f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
+  const float gcy = 0.25f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
+  const float gcl = 0.25f * (float)(Ls - 1) * dot4(dl, a1 - a0);
+  if (pi == 1) { dx0 += gcx; dx2 += gcy; dx1 += gcl; }
+  else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
+}
+
 // d(X0)/d(xn): X0 = [xn, t | (sin q, cos q) pairs], q_j = xn[j/10] * 2^(j%10); returns this lane
 // half's partial (combine with __shfl_xor 32)
 RDRF_D void x0_bwd(const float (&X0)[32], const float (&dX0)[32], int h, float& d0, float& d1,
@@ -794,12 +878,32 @@ __global__ __launch_bounds__(256, 3) void k_scatter(ScatterArgs a) {
 #ifndef RDRF_SC_UNROLL
 #define RDRF_SC_UNROLL 1
 #endif
+      // ZSPLIT (density / blending families, bound by the L2 atomic request rate): per level C0Q/2
+      // iterations with one XY quad per half-wave, then 2*C1Q iterations with one XZ / YZ quad per
+      // WAVE, column-split across the halves (gather_zquad_bwd: half the plane requests, 1/3 more
+      // iterations).  The appearance family is VALU-issue bound and keeps one quad per half-wave.
+      constexpr bool ZSPLIT = C0Q <= 4;
+      constexpr int QPL = C0Q + 2 * C1Q, IPL = C0Q / 2 + 2 * C1Q, NLV = (2 * NQ) / QPL;
+      static_assert(C0Q % 2 == 0 && NLV * QPL == 2 * NQ, "quad layout");
+      if constexpr (ZSPLIT) {
 #pragma unroll RDRF_SC_UNROLL
-      for (int o = 0; o < NQ; ++o) {
-        const float* rq = rb + (size_t)(8 * o + 4 * h) * 32 + s;
-        const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
-        gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], 2 * o + h, x0, x1, x2, dq, live, s, dw0, dw1,
-                                     dw2, ll);
+        for (int it = 0; it < NLV * IPL; ++it) {
+          const int lv = it / IPL, r = it - lv * IPL;
+          const bool xy = r < C0Q / 2;
+          const int g = lv * QPL + (xy ? 2 * r + h : C0Q + (r - C0Q / 2));
+          const float* rq = rb + (size_t)(4 * g) * 32 + s;
+          const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
+          if (xy) gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], g, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+          else gather_zquad_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], g, h, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+        }
+      } else {
+#pragma unroll RDRF_SC_UNROLL
+        for (int o = 0; o < NQ; ++o) {
+          const float* rq = rb + (size_t)(8 * o + 4 * h) * 32 + s;
+          const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
+          gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], 2 * o + h, x0, x1, x2, dq, live, s, dw0, dw1,
+                                       dw2, ll);
+        }
       }
     }
     dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);

@@ -71,6 +71,12 @@ class MLPRender_Fea_late_view(_Head):
         nn.init.constant_(self.mlp_view[-1].bias, 0)
 
 
+# storage order of the XZ / YZ planes: False = [z][x|y][C] (x fastest: the two bilinear columns of a
+# tap are 16-32 bytes apart and the scatter's column-split atomics merge into one L2 request each);
+# True = [x|y][z][C].  The kernels take explicit strides, either works.
+Z_FAST = False
+
+
 def channel_last_(t, h_fast=False):
     """Re-stride a (1,C,H,W) tensor with the component axis contiguous (values preserved):
     [H][W][C] by default, [W][H][C] when `h_fast` (used for the XZ / YZ planes, whose H axis is z:
@@ -391,7 +397,7 @@ class TensorBase(nn.Module):
             m0, m1 = MAT_MODE[i]
             p = scale * torch.randn((1, n_component[i], gs[m1], gs[m0]))
             l = scale * torch.randn((1, n_component[i], gs[vec_id], 1))
-            plane_coef.append(nn.Parameter(channel_last_(p.to(device), h_fast=i > 0)))
+            plane_coef.append(nn.Parameter(channel_last_(p.to(device), h_fast=Z_FAST and i > 0)))
             line_coef.append(nn.Parameter(channel_last_(l.to(device))))
         return nn.ParameterList(plane_coef), nn.ParameterList(line_coef)
 
@@ -403,7 +409,7 @@ class TensorBase(nn.Module):
                     and state_dict[key].shape != p.shape:
                 mod, attr = name.split(".")
                 new = channel_last_(state_dict[key].to(p.device).float(),
-                                    h_fast="_plane" in mod and int(attr) > 0)
+                                    h_fast=Z_FAST and "_plane" in mod and int(attr) > 0)
                 getattr(self, mod)[int(attr)] = nn.Parameter(new)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
@@ -462,7 +468,7 @@ class TensorBase(nn.Module):
                               mode="bilinear", align_corners=True)
             l = F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1), mode="bilinear",
                               align_corners=True)
-            plane_coef[i] = nn.Parameter(channel_last_(p, h_fast=i > 0))
+            plane_coef[i] = nn.Parameter(channel_last_(p, h_fast=Z_FAST and i > 0))
             line_coef[i] = nn.Parameter(channel_last_(l))
         return plane_coef, line_coef
 
