@@ -21,8 +21,9 @@
  *   - VM factors are CHANNEL-LAST: the reference's (1,C,H,W) plane tensors with the component
  *     axis contiguous and explicit h/w strides (RdrfVM); line i is [L_i][C_i].  plane 0/1/2 =
  *     XY/XZ/YZ, line 0/1/2 = Z/Y/X (matMode/vecMode, models/tensorBase.py:326-327).  The host
- *     mirror stores plane 0 as [y][x][C] and planes 1,2 as [x|y][z][C] (z fastest: consecutive
- *     samples of a forward-facing ray then touch adjacent texels).
+ *     mirror stores every plane as [H][W][C] (plane 0 [y][x][C], planes 1,2 [z][x|y][C]): the two
+ *     bilinear columns of a tap are then adjacent in memory, which the scatter exploits (one L2
+ *     atomic request for both); any other h/w strides are accepted.
  *   - gradients are ACCUMULATED (+=) into the caller's (zero-initialised) buffers.
  */
 #ifndef RODYNRF_H
