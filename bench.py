@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--render-chunk", type=int, default=8192)
     args = ap.parse_args()
 
     P = importlib.import_module("robust-dynrf_amd.parallel")
@@ -349,7 +350,7 @@ def main():
         ids = torch.arange(H * W, device=dev)
         rays_f = trainer.rays_for(ids + 3 * H * W)
         ts_f = trainer.data.ts_of(ids + 3 * H * W)
-        chunk = 8192
+        chunk = args.render_chunk
 
         def frame():
             for c0 in range(0, H * W, chunk):

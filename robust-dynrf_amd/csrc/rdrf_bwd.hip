@@ -352,31 +352,63 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     f32x4 r01 = run_scan4(k01 ? dp * (tx.w1 * ty.w0) : zero, pr.start, s);
     const f32x4 r10 = run_scan4(k10 ? dp * (tx.w0 * ty.w1) : zero, pr.start, s);
     const f32x4 r11 = run_scan4(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s);
-    // cross-run merge along the row axis: a run at row iy writes its UPPER taps to row iy+1, which
-    // is where the next run (row iy+1, same column) writes its LOWER taps.  The lower sums absorb
-    // the previous run's upper sums and the previous run skips that write: two atomic requests
-    // per chained run instead of four (the ray-marching axis advances ~one texel per sample).
-    bool up_ok = true;
-    if (pi != 0) {
+    // cross-run merge: consecutive runs of a ray almost always differ by ONE texel in x or in y and
+    // then share two of their four bilinear taps (same memory locations).  The later run absorbs the
+    // earlier run's sums for the shared taps and the earlier run skips those two atomics: ~2 requests
+    // per run instead of 4.  Directions (this run relative to the previous one), tap bits 00=1 01=2
+    // 10=4 11=8 (first digit = row):   +y: prev.10->00, prev.11->01     -y: prev.00->10, prev.01->11
+    //                                  +x: prev.01->00, prev.11->10     -x: prev.00->01, prev.10->11
+    // All lanes act on the RAW scanned sums simultaneously, so a tap that a run has itself received
+    // must not be forwarded again (multi-hop): the taps moved across a boundary are
+    // skip(direction out) & ~receive(direction in of the earlier run).
+    auto recv_mask = [](int d) { return d == 65536 ? 3 : (d == -65536 ? 12 : (d == 1 ? 5 : (d == -1 ? 10 : 0))); };
+    auto skip_mask = [](int d) { return d == 65536 ? 12 : (d == -65536 ? 3 : (d == 1 ? 10 : (d == -1 ? 5 : 0))); };
+    int skip_out = 0;
+    {
       const int pl = pr.start > 0 ? pr.start - 1 : 0;           // tail lane of the previous run
       const int pk = __shfl(pkey, pl, 32);
-      const bool chain_prev = pr.start > 0 && pk == pkey - (1 << 16);
-      const float ux = __shfl(r10.x, pl, 32), uy = __shfl(r10.y, pl, 32), uz = __shfl(r10.z, pl, 32),
-                  uw = __shfl(r10.w, pl, 32);
-      const float vx_ = __shfl(r11.x, pl, 32), vy_ = __shfl(r11.y, pl, 32), vz_ = __shfl(r11.z, pl, 32),
-                  vw_ = __shfl(r11.w, pl, 32);
-      if (chain_prev) {
-        r00.x += ux; r00.y += uy; r00.z += uz; r00.w += uw;
-        r01.x += vx_; r01.y += vy_; r01.z += vz_; r01.w += vw_;
+      const int din = pr.start > 0 ? pkey - pk : 0;             // direction INTO this run
+      const int pdin = __shfl(din, pl, 32);                     // direction into the previous run
+      const int min_ = skip_mask(din) & ~recv_mask(pdin);       // prev-run taps moved into this run
+      const int nk = dppi<0x130>(pkey);                         // wave_shl:1 -> key of lane s+1
+      const int dout = s < 31 ? nk - pkey : 0;
+      skip_out = skip_mask(dout) & ~recv_mask(din);             // own taps the next run takes over
+      if (pi == 0) {
+        f32x4 p00, p01, p10, p11;
+        p00.x = __shfl(r00.x, pl, 32); p00.y = __shfl(r00.y, pl, 32); p00.z = __shfl(r00.z, pl, 32); p00.w = __shfl(r00.w, pl, 32);
+        p01.x = __shfl(r01.x, pl, 32); p01.y = __shfl(r01.y, pl, 32); p01.z = __shfl(r01.z, pl, 32); p01.w = __shfl(r01.w, pl, 32);
+        p10.x = __shfl(r10.x, pl, 32); p10.y = __shfl(r10.y, pl, 32); p10.z = __shfl(r10.z, pl, 32); p10.w = __shfl(r10.w, pl, 32);
+        p11.x = __shfl(r11.x, pl, 32); p11.y = __shfl(r11.y, pl, 32); p11.z = __shfl(r11.z, pl, 32); p11.w = __shfl(r11.w, pl, 32);
+        f32x4 a00 = zero, a01 = zero, a10 = zero, a11 = zero;
+        if (din == 65536) { if (min_ & 4) a00 = p10; if (min_ & 8) a01 = p11; }
+        else if (din == -65536) { if (min_ & 1) a10 = p00; if (min_ & 2) a11 = p01; }
+        else if (din == 1) { if (min_ & 2) a00 = p01; if (min_ & 8) a10 = p11; }
+        else if (din == -1) { if (min_ & 1) a01 = p00; if (min_ & 4) a11 = p10; }
+        r00 = r00 + a00; r01 = r01 + a01;
+        f32x4 t10 = r10 + a10, t11 = r11 + a11;
+        // (r10 / r11 are const above: rebuild the outputs)
+        atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00) && !(skip_out & 1));
+        atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01) && !(skip_out & 2));
+        atomic_add4(GP, o10, t10, pr.tail && g10 && nz4(t10) && !(skip_out & 4));
+        atomic_add4(GP, o11, t11, pr.tail && g11 && nz4(t11) && !(skip_out & 8));
+      } else {
+        // XZ / YZ (the non-split path of the appearance / static scatter): +y chains only
+        const float ux = __shfl(r10.x, pl, 32), uy = __shfl(r10.y, pl, 32), uz = __shfl(r10.z, pl, 32),
+                    uw = __shfl(r10.w, pl, 32);
+        const float vx_ = __shfl(r11.x, pl, 32), vy_ = __shfl(r11.y, pl, 32), vz_ = __shfl(r11.z, pl, 32),
+                    vw_ = __shfl(r11.w, pl, 32);
+        if (din == 65536) {
+          r00.x += ux; r00.y += uy; r00.z += uz; r00.w += uw;
+          r01.x += vx_; r01.y += vy_; r01.z += vz_; r01.w += vw_;
+        }
+        const bool up_ok = dout != 65536;
+        atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00));
+        atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01));
+        atomic_add4(GP, o10, r10, pr.tail && up_ok && g10 && nz4(r10));
+        atomic_add4(GP, o11, r11, pr.tail && up_ok && g11 && nz4(r11));
       }
-      const int nk = dppi<0x130>(pkey);  // wave_shl:1 -> key of lane s+1
-      up_ok = !(s < 31 && nk == pkey + (1 << 16));
     }
     f32x4 r;
-    atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00));
-    atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01));
-    atomic_add4(GP, o10, r10, pr.tail && up_ok && g10 && nz4(r10));
-    atomic_add4(GP, o11, r11, pr.tail && up_ok && g11 && nz4(r11));
     const Run lr = run_of(tl.i0 + 4, s);
     float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
     const int lst = lds_stride(C);
