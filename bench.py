@@ -270,7 +270,7 @@ def main():
                   "dyn_density", "dyn_app", "composite", "scene_flow", "composite_bwd", "dyn_app_bwd",
                   "scatter_dyn_app", "dyn_heads_bwd", "scatter_dyn_density", "dyn_warp_bwd",
                   "time_branch_bwd", "dw_dyn", "static_app_bwd", "scatter_static_app",
-                  "static_density_bwd", "dw_static", "scene_flow_bwd", "dw_sf"]:
+                  "static_density_bwd", "scatter_static_density", "dw_static", "scene_flow_bwd", "dw_sf"]:
             msk, n = prof_get(L, k)
             if n:
                 table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}

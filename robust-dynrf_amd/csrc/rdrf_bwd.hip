@@ -757,7 +757,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
 // static field, density phase backward: wave per ray, lane per sample.  The suffix sum is formed
 // directly by walking the ray LAST tile first (transmittance carries of each tile start come from a
 // forward pre-pass); total - prefix would cancel catastrophically when p -> 1e-10.
-__global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w, StaticG gw) {
+__global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w, float* __restrict__ gf_rows) {
   __shared__ float carr[32];
   const int lane = threadIdx.x;
   const int n = blockIdx.x;
@@ -822,22 +822,10 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
       g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
     }
     const float gf = vld ? g_sigma * act_grad(f, a.act, a.density_shift) : 0.f;
-    {
-      const bool live = vld && gf != 0.f;
-      const float x0 = norm_c(a.xyz[(size_t)idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
-      const float x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
-      const float x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
-      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-      const f32x4 dq = {gf, gf, gf, gf};
-#pragma unroll
-      for (int g = 0; g < 6; ++g)
-        gather_quad_bwd<4, 1, 1>(w.density, gw.density, g, x0, x1, x2, dq, live, lane & 31, d0, d1, d2);
-      if (live && a.g_xyz) {
-        atomicAdd(a.g_xyz + (size_t)idx * 3 + 0, d0 * a.box.inv[0]);
-        atomicAdd(a.g_xyz + (size_t)idx * 3 + 1, d1 * a.box.inv[1]);
-        atomicAdd(a.g_xyz + (size_t)idx * 3 + 2, d2 * a.box.inv[2]);
-      }
-    }
+    // d(loss)/d(density feature) per sample; the VM gather backward (scatter + coordinate gradients)
+    // runs in k_scatter with LDS line accumulators (bcast mode: the feature is the plain sum of the
+    // 24 products, so every component has this same gradient)
+    if (act) gf_rows[(size_t)n * (((a.S + 31) >> 5) << 5) + j] = gf;
   }
   if (a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
     g_nrm = wave_sum(g_nrm);
@@ -867,6 +855,8 @@ struct ScatterArgs {
   float* dxw;          // [idx][3] coordinate gradients (nullable)
   int dxw_accumulate;
   float* g_xyz;        // static field: g_xyz += dw * inv (nullable)
+  int bcast;           // 1: every component's gradient is row 0 of the tile (static density: the
+                       //    feature is the plain sum of the 24 products)
 };
 
 template <int C0Q, int C1Q, int NQ>
@@ -923,16 +913,18 @@ __global__ __launch_bounds__(256, 3) void k_scatter(ScatterArgs a) {
           const int lv = it / IPL, r = it - lv * IPL;
           const bool xy = r < C0Q / 2;
           const int g = lv * QPL + (xy ? 2 * r + h : C0Q + (r - C0Q / 2));
-          const float* rq = rb + (size_t)(4 * g) * 32 + s;
-          const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
+          const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(4 * g) * 32) + s;
+          const int rs = a.bcast ? 0 : 32;
+          const f32x4 dq = {rq[0], rq[rs], rq[2 * rs], rq[3 * rs]};
           if (xy) gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], g, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
           else gather_zquad_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], g, h, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
         }
       } else {
 #pragma unroll RDRF_SC_UNROLL
         for (int o = 0; o < NQ; ++o) {
-          const float* rq = rb + (size_t)(8 * o + 4 * h) * 32 + s;
-          const f32x4 dq = {rq[0], rq[32], rq[64], rq[96]};
+          const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(8 * o + 4 * h) * 32) + s;
+          const int rs = a.bcast ? 0 : 32;
+          const f32x4 dq = {rq[0], rq[rs], rq[2 * rs], rq[3 * rs]};
           gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], 2 * o + h, x0, x1, x2, dq, live, s, dw0, dw1,
                                        dw2, ll);
         }
@@ -1563,6 +1555,7 @@ extern "C" size_t rdrf_workspace_bytes(int N, int S) {
 
 struct BwdWs {
   float* pk;
+  float* gf;       // static field: d(density feature) per sample, [N][ceil(S/32)*32]
   float* grows1;
   float* grows3;
   float* dxw;
@@ -1578,6 +1571,7 @@ static int carve_bwd(BwdWs& b, void* ws, size_t ws_bytes, int N, int S, int dyna
   b.dxw = dynamic ? c.take<float>(ns * 3) : nullptr;
   b.dxn = dynamic ? c.take<float>(ns * 3) : nullptr;
   b.dtout = dynamic ? c.take<float>((size_t)N * 32) : nullptr;
+  b.gf = dynamic ? nullptr : c.take<float>(t1 * 32);
   RDRF_CHECK(c.ok(), -3, "backward workspace too small: need %zu have %zu", c.off, ws_bytes);
   return 0;
 }
@@ -1660,8 +1654,18 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     rc = dw_launch(D, stream, "dw_static");
     if (rc) return rc;
   }
-  if (g_sigma != nullptr || g_weight != nullptr || (g_rays != nullptr && g_dists != nullptr))
-    RDRF_LAUNCH("static_density_bwd", k_static_density_bwd, dim3(N), dim3(64), stream, a, w, gw);
+  if (g_sigma != nullptr || g_weight != nullptr || (g_rays != nullptr && g_dists != nullptr)) {
+    RDRF_LAUNCH("static_density_bwd", k_static_density_bwd, dim3(N), dim3(64), stream, a, w, b.gf);
+    if (g_sigma != nullptr || g_weight != nullptr) {
+      ScatterArgs sa;
+      fill_scatter_common(sa, a);
+      sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.nsets = 1;
+      sa.rows = b.gf; sa.stride = 1; sa.row0[0] = 0; sa.bcast = 1;
+      sa.g_xyz = g_xyz;
+      const long t1 = (long)N * ((S + 31) / 32);
+      RDRF_LAUNCH("scatter_static_density", (k_scatter<4, 1, 3>), scatter_grid(t1), dim3(256), stream, sa);
+    }
+  }
   return 0;
 }
 
