@@ -187,6 +187,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = importlib.import_module("robust-dynrf_amd._lib")
@@ -375,6 +376,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # ranks > 0 wait here while rank 0 finishes its roofline / render legs
         dist.destroy_process_group()
 
 
