@@ -13,10 +13,10 @@ from . import _lib
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding, TensorBase
 from .renderer import (sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays, render_rays,
                        induce_flow, induce_flow_single, render_3d_point, render_single_3d_point,
-                       eff_distloss, flatten_eff_distloss)
+                       eff_distloss, flatten_eff_distloss, render_frame, psnr)
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
 
-__all__ = ["TVLoss", "pose_to_mtx", "eff_distloss", "flatten_eff_distloss", "induce_flow", "induce_flow_single", "render_3d_point", "render_single_3d_point",
+__all__ = ["render_frame", "psnr", "TVLoss", "pose_to_mtx", "eff_distloss", "flatten_eff_distloss", "induce_flow", "induce_flow_single", "render_3d_point", "render_single_3d_point",
            "TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
            "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "generate_rays", "ids2pixel"]

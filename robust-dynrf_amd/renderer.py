@@ -177,6 +177,34 @@ def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc")
     return rgb, depth
 
 
+@torch.no_grad()
+def render_frame(tensorf_static, tensorf, poses9, focal, frame, H, W, N_samples=-1, ray_type="ndc",
+                 chunk=None, t=None):
+    """Whole-frame no-grad render (the per-image body of renderer.py:661-966 `evaluation`): rays of
+    every pixel of `frame` are generated on the device and pushed through rdrf_render_fwd in chunks
+    (default: the whole frame in one launch sequence).  `t` overrides the frame's own time in [-1,1].
+    Returns (rgb [H,W,3] clamped to [0,1], depth [H,W])."""
+    from .ray_utils import generate_rays
+    dev = poses9.device
+    T = poses9.shape[0]
+    ids = torch.arange(H * W, device=dev) + int(frame) * H * W
+    rays = generate_rays(ids, poses9, focal, H, W, ndc=ray_type == "ndc", near=1.0)
+    tv = (2.0 * frame / max(T - 1, 1) - 1.0) if t is None else float(t)
+    ts = torch.full((H * W,), tv, device=dev)
+    chunk = H * W if not chunk else int(chunk)
+    rgb = torch.empty(H * W, 3, device=dev)
+    depth = torch.empty(H * W, device=dev)
+    for c0 in range(0, H * W, chunk):
+        r, d = render_rays(tensorf_static, tensorf, rays[c0:c0 + chunk], ts[c0:c0 + chunk], N_samples, ray_type)
+        rgb[c0:c0 + chunk], depth[c0:c0 + chunk] = r, d
+    return rgb.clamp_(0.0, 1.0).view(H, W, 3), depth.view(H, W)
+
+
+def psnr(img, ref):
+    """-10 log10(mse) on the device (renderer.py:905-906 computes it per image on the host)."""
+    return -10.0 * torch.log10(((img - ref) ** 2).mean())
+
+
 # --------------------------------------------------------------------------------------------
 # induced optical flow / disparity (renderer.py:1266-1392) -- SURVEY.md 8f rank 1
 # --------------------------------------------------------------------------------------------

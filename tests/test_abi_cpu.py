@@ -65,3 +65,33 @@ def test_no_cpu_fallback():
         rodynrf.raw2outputs(torch.zeros(4, 3, 3), torch.zeros(4, 3), torch.zeros(4, 3, 3),
                             torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 3),
                             rays)
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """TensorBase.save / the reload recipe of train.py:433-447 (`kwargs = ckpt["kwargs"]`, pop the two
+    pose entries, `Model(**kwargs, device=...)`, `.load(ckpt)`): same file layout as
+    models/tensorBase.py:438-485, parameters bit-identical after the round trip, channel-last kept."""
+    import rodynrf
+    from _util import load_case
+    g, sd_s, _, sd_d, _ = load_case("ndc_relu")
+    grid = [int(v) for v in g["meta.grid"]]
+    kw = dict(density_n_comp=[16, 4, 4], appearance_n_comp=[48, 12, 12], app_dim=27,
+              near_far=[0.0, 1.0], alphaMask_thres=1e-4, density_shift=-10, distance_scale=25,
+              pos_pe=6, view_pe=0, featureC=128, step_ratio=2.0, fea2denseAct="relu")
+    aabb = torch.from_numpy(g["aabb"])
+    for cls, head, fea_pe, sd in ((rodynrf.TensorVMSplit, "MLP_Fea", 2, sd_s),
+                                  (rodynrf.TensorVMSplit_TimeEmbedding, "MLP_Fea_late_view", 0, sd_d)):
+        m = cls(aabb, grid, 12, "cpu", shadingMode=head, fea_pe=fea_pe, **kw)
+        m.load_state_dict(sd)
+        path = str(tmp_path / f"{cls.__name__}.th")
+        m.save(torch.eye(3, 4)[None].repeat(12, 1, 1), torch.tensor(1.0), path)
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        assert set(ckpt.keys()) == {"kwargs", "state_dict"}
+        kwargs = ckpt["kwargs"]
+        assert kwargs.pop("se3_poses").shape == (12, 3, 4) and float(kwargs.pop("focal_ratio_refine")) == 1.0
+        kwargs.update({"device": "cpu"})
+        m2 = cls(**kwargs)
+        m2.load(ckpt)
+        for (k, a), (k2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+            assert k == k2 and torch.equal(a, b), k
+        assert m2.density_plane[1].stride(1) == 1 and m2.nSamples == m.nSamples

@@ -158,3 +158,35 @@ def test_fused_render_matches_unfused():
     rgb, depth = rodynrf.render_rays(st, dy, rays, ts, N_samples=S, ray_type="ndc")
     assert_close(rgb, g["ce.rgb_map_full"], "render rgb")
     assert_close(depth, g["ce.depth_map_full"], "render depth")
+
+
+def test_render_frame_matches_oracle_pipeline():
+    """whole-frame driver: device ray generation -> fused render, one launch sequence vs chunks of
+    100 rays vs the oracle's generate_rays -> sampleXYZ -> fields -> raw2outputs on the CPU."""
+    import rodynrf
+    from _gpu_util import fields_from_case, oracle_cfg, oracle_sd
+    from oracle import rodynrf_oracle as O
+    g, st, dy, _ = fields_from_case("ndc_relu")
+    T, H, W, frame = 5, 9, 16, 3
+    gen = torch.Generator().manual_seed(2)
+    poses = torch.zeros(T, 9)
+    poses[:, 0] = 1
+    poses[:, 4] = 1
+    poses = poses + 0.02 * torch.randn(T, 9, generator=gen)
+    focal = max(H, W) / 2.0 * 1.7320508
+    S = 21
+    a, da = rodynrf.render_frame(st, dy, poses.cuda(), focal, frame, H, W, N_samples=S)
+    b, db = rodynrf.render_frame(st, dy, poses.cuda(), focal, frame, H, W, N_samples=S, chunk=100)
+    assert a.shape == (H, W, 3) and da.shape == (H, W)
+    assert torch.equal(a, b) and torch.equal(da, db)
+    ids = torch.arange(H * W) + frame * H * W
+    rays = O.generate_rays(ids, poses, focal, H, W, ndc=True, near=1.0)
+    ts = torch.full((H * W,), 2.0 * frame / (T - 1) - 1.0)
+    aabb = st.aabb.cpu()
+    xyz, z, valid = O.sampleXYZ(rays, aabb, [float(v) for v in st.near_far], S, "ndc", None)
+    r_s = O.field_forward(oracle_sd(st), oracle_cfg(st), rays, ts, xyz, z, valid, "ndc", dynamic=False)
+    r_d = O.field_forward(oracle_sd(dy), oracle_cfg(dy), rays, ts, xyz, z, valid, "ndc", dynamic=True)
+    outs = O.raw2outputs(r_s[6], r_s[7], r_d[6], r_d[7], r_d[9], r_d[2], r_d[8], rays, False, "ndc")
+    assert_close(a.view(-1, 3), outs[0].clamp(0, 1), "frame rgb", rtol=2e-4)
+    assert_close(da.view(-1), outs[1], "frame depth", rtol=2e-4)
+    assert float(rodynrf.psnr(a, a + 0.1)) == pytest.approx(20.0, abs=1e-3)
