@@ -175,6 +175,13 @@ class Trainer:
             sparsify_(self.st, self.dy, cfg, device)
         self.data = SyntheticBalloon(cfg, device)
         groups = self.st.get_optparam_groups(lr_init, lr_basis) + self.dy.get_optparam_groups(lr_init, lr_basis)
+        # the reference keeps 6 + 18 groups but only two learning rates (and scales every group by the
+        # same lr_factor each iteration, train.py:2608-2612): one group per lr is the same optimiser
+        # with 4 fused multi-tensor launches per step instead of 48
+        merged = {}
+        for g_ in groups:
+            merged.setdefault(g_["lr"], []).extend(list(g_["params"]))
+        groups = [{"params": ps, "lr": lr} for lr, ps in merged.items()]
         try:
             self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)
         except Exception:
