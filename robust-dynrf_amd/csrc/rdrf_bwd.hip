@@ -1349,8 +1349,11 @@ __global__ __launch_bounds__(256, 2) void k_dw(DwJobs jobs) {
   const int local = item - jobs.item0[ji];
   const int ngrp = (J.nblk + 3) >> 2;
   const int bo = local / ngrp, grp = local - bo * ngrp;
-  const int b0 = grp * 4;
-  const int nb = (J.nblk - b0) < 4 ? (J.nblk - b0) : 4;
+  // input blocks are split EVENLY over the groups (6 -> 3 + 3, not 4 + 2): the waves of a workgroup
+  // sit on different SIMDs, so unequal items leave the SIMDs of the light ones idle
+  const int per = (J.nblk + ngrp - 1) / ngrp;
+  const int b0 = grp * per;
+  const int nb = (J.nblk - b0) < per ? (J.nblk - b0) : per;
   const int ntiles = J.count ? ((*J.count + 31) >> 5) : J.ntiles;
   f32x16 acc[4];
 #pragma unroll
