@@ -432,6 +432,135 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
 }
 
+// XY quads, four at a time: the wave works on 16 samples (sub-tile j of the 32-sample tile) and the
+// four quads 4*grp .. 4*grp+3 of the XY plane at one level: lane = (q = lane>>4, s16 = lane&15).
+// Run structure and tail positions are identical in the four 16-lane rows (same samples), so in each
+// atomic instruction the four rows carry the four quads of the SAME texel: 64 contiguous bytes
+// (16 components), which the L2 coalescer turns into one request -- the (quad | quad) half-wave
+// pairing of gather_quad_bwd needed two.  A 16-lane run-scan is four row_shr steps.
+// xs/live: coordinates and liveness of THIS lane's sample (sub-tile j); q_is_owner: this lane also
+// owns that sample in the (half, sample) mapping of the caller's dx accumulators.
+RDRF_D Run run_of16(int key, int s16) {
+  const int prev = dppi<0x111>(key);  // row_shr:1 (lane 0 of a row reads 0)
+  const bool head = (s16 == 0) || (prev != key);
+  const unsigned long long b = __ballot(head);
+  const unsigned m = (unsigned)(b >> (16 * ((threadIdx.x & 63) >> 4))) & 0xffffu;
+  Run r;
+  r.start = 31 - __clz((int)(m & (0xffffu >> (15 - s16))));
+  r.tail = (s16 == 15) || ((m >> (s16 + 1)) & 1u);
+  return r;
+}
+RDRF_D f32x4 run_scan4_16(f32x4 v, int start, int s16) {
+#define RDRF_SCAN_STEP(D)                                                                   \
+  {                                                                                         \
+    const float ox = dppf<0x110 + D>(v.x), oy = dppf<0x110 + D>(v.y);                       \
+    const float oz = dppf<0x110 + D>(v.z), ow = dppf<0x110 + D>(v.w);                       \
+    const bool take = s16 >= D && s16 - D >= start;                                         \
+    const float tx_ = v.x + ox, ty_ = v.y + oy, tz_ = v.z + oz, tw_ = v.w + ow;             \
+    v.x = take ? tx_ : v.x; v.y = take ? ty_ : v.y; v.z = take ? tz_ : v.z; v.w = take ? tw_ : v.w; \
+  }
+  RDRF_SCAN_STEP(1)
+  RDRF_SCAN_STEP(2)
+  RDRF_SCAN_STEP(4)
+  RDRF_SCAN_STEP(8)
+#undef RDRF_SCAN_STEP
+  return v;
+}
+RDRF_D f32x4 shfl4_row(f32x4 v, int src_lane) {
+  f32x4 r;
+  r.x = __shfl(v.x, src_lane, 64); r.y = __shfl(v.y, src_lane, 64);
+  r.z = __shfl(v.z, src_lane, 64); r.w = __shfl(v.w, src_lane, 64);
+  return r;
+}
+template <int C0Q, int C1Q>
+RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, float x0, float x1, float x2,
+                           f32x4 dq, bool live, bool q_is_owner, float& dx0, float& dx1, float& dx2,
+                           const LdsLines ll) {
+  const int lane = threadIdx.x & 63, s16 = lane & 15, rowbase = lane & ~15;
+  const float* P = vm.plane[0];
+  const float* Lp = vm.line[0];
+  float* GP = gvm.plane[0];
+  float* GL = gvm.line[0];
+  const int H = vm.H[0], W = vm.W[0], L = vm.L[0], sH = vm.sH[0], sW = vm.sW[0];
+  const int st = 1 << lv;
+  const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
+  Tap1 tx = tap1d(x0, Ws), ty = tap1d(x1, Hs), tl = tap1d(x2, Ls);
+  constexpr int C = 4 * C0Q;
+  const int qo = 4 * q4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const size_t o00 = (size_t)((ty.i0 << lv) * sH + (tx.i0 << lv) * sW) + qo;
+  const size_t o01 = (size_t)((ty.i0 << lv) * sH + ((tx.i0 + 1) << lv) * sW) + qo;
+  const size_t o10 = (size_t)(((ty.i0 + 1) << lv) * sH + (tx.i0 << lv) * sW) + qo;
+  const size_t o11 = (size_t)(((ty.i0 + 1) << lv) * sH + ((tx.i0 + 1) << lv) * sW) + qo;
+  const bool g00 = ty.ok0 && tx.ok0, g01 = ty.ok0 && tx.ok1, g10 = ty.ok1 && tx.ok0, g11 = ty.ok1 && tx.ok1;
+  const bool k00 = live && g00, k01 = live && g01, k10 = live && g10, k11 = live && g11;
+  const bool m0 = live && tl.ok0, m1 = live && tl.ok1;
+  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
+  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
+  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
+  f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo), v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+  f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo), v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
+  f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo), a1 = ld4(Lp + (size_t)l1c * C + qo);
+  if (!k00) v00 = zero;
+  if (!k01) v01 = zero;
+  if (!k10) v10 = zero;
+  if (!k11) v11 = zero;
+  if (!m0) a0 = zero;
+  if (!m1) a1 = zero;
+  const f32x4 pv = v00 * (tx.w0 * ty.w0) + v01 * (tx.w1 * ty.w0) + v10 * (tx.w0 * ty.w1) +
+                   v11 * (tx.w1 * ty.w1);
+  const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
+  const f32x4 dp = live ? dq * lvv : zero;
+  const f32x4 dl = live ? dq * pv : zero;
+  const int pkey = ((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff);
+  const Run pr = run_of16(pkey, s16);
+  f32x4 r00 = run_scan4_16(k00 ? dp * (tx.w0 * ty.w0) : zero, pr.start, s16);
+  f32x4 r01 = run_scan4_16(k01 ? dp * (tx.w1 * ty.w0) : zero, pr.start, s16);
+  f32x4 r10 = run_scan4_16(k10 ? dp * (tx.w0 * ty.w1) : zero, pr.start, s16);
+  f32x4 r11 = run_scan4_16(k11 ? dp * (tx.w1 * ty.w1) : zero, pr.start, s16);
+  {  // cross-run merge of shared taps, all four directions (see gather_quad_bwd)
+    auto recv_mask = [](int d) { return d == 65536 ? 3 : (d == -65536 ? 12 : (d == 1 ? 5 : (d == -1 ? 10 : 0))); };
+    auto skip_mask = [](int d) { return d == 65536 ? 12 : (d == -65536 ? 3 : (d == 1 ? 10 : (d == -1 ? 5 : 0))); };
+    const int pl = rowbase | (pr.start > 0 ? pr.start - 1 : 0);
+    const int pk = __shfl(pkey, pl, 64);
+    const int din = pr.start > 0 ? pkey - pk : 0;
+    const int pdin = __shfl(din, pl, 64);
+    const int min_ = skip_mask(din) & ~recv_mask(pdin);
+    const int nk = dppi<0x101>(pkey);                        // row_shl:1 -> key of lane s16+1
+    const int dout = s16 < 15 ? nk - pkey : 0;
+    const int skip_out = skip_mask(dout) & ~recv_mask(din);
+    const f32x4 p00 = shfl4_row(r00, pl), p01 = shfl4_row(r01, pl), p10 = shfl4_row(r10, pl), p11 = shfl4_row(r11, pl);
+    f32x4 a00 = zero, a01 = zero, a10 = zero, a11 = zero;
+    if (din == 65536) { if (min_ & 4) a00 = p10; if (min_ & 8) a01 = p11; }
+    else if (din == -65536) { if (min_ & 1) a10 = p00; if (min_ & 2) a11 = p01; }
+    else if (din == 1) { if (min_ & 2) a00 = p01; if (min_ & 8) a10 = p11; }
+    else if (din == -1) { if (min_ & 1) a01 = p00; if (min_ & 4) a11 = p10; }
+    r00 = r00 + a00; r01 = r01 + a01; r10 = r10 + a10; r11 = r11 + a11;
+    atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00) && !(skip_out & 1));
+    atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01) && !(skip_out & 2));
+    atomic_add4(GP, o10, r10, pr.tail && g10 && nz4(r10) && !(skip_out & 4));
+    atomic_add4(GP, o11, r11, pr.tail && g11 && nz4(r11) && !(skip_out & 8));
+  }
+  {
+    const Run lr = run_of16(tl.i0 + 4, s16);
+    float* LL = ll.base ? ll.base + ll.off[0] : nullptr;
+    const int lst = lds_stride(C);
+    f32x4 r = run_scan4_16(m0 ? dl * tl.w0 : zero, lr.start, s16);
+    bool okl = lr.tail && tl.ok0 && nz4(r);
+    if (LL) lds_add4(LL, (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)(tl.i0 << lv) * C + qo, r, okl);
+    r = run_scan4_16(m1 ? dl * tl.w1 : zero, lr.start, s16);
+    okl = lr.tail && tl.ok1 && nz4(r);
+    if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)((tl.i0 + 1) << lv) * C + qo, r, okl);
+  }
+  float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
+  float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
+  float gcl = 0.5f * (float)(Ls - 1) * dot4(dl, a1 - a0);
+  // sum over the four quads (rows) of this sample, then hand it to the lane that owns the sample
+  gcx += __shfl_xor(gcx, 16, 64); gcy += __shfl_xor(gcy, 16, 64); gcl += __shfl_xor(gcl, 16, 64);
+  gcx += __shfl_xor(gcx, 32, 64); gcy += __shfl_xor(gcy, 32, 64); gcl += __shfl_xor(gcl, 32, 64);
+  if (q_is_owner) { dx0 += gcx; dx1 += gcy; dx2 += gcl; }
+}
+
 // XZ / YZ quads of the ray-tile scatter, column-split: BOTH half-waves work on the same quad g of the
 // same 32 samples; half h owns the bilinear column ix + h (its lower and upper row taps) and the line
 // tap h.  The run structure is identical in the two halves, so in every atomic instruction the lanes
@@ -893,6 +1022,12 @@ __global__ __launch_bounds__(256, 3) void k_scatter(ScatterArgs a) {
       x1 = norm_c(a.xyz[(size_t)idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
       x2 = norm_c(a.xyz[(size_t)idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
     }
+    // coordinates / liveness of the samples this lane handles in the (quad, 16-sample) mapping of
+    // the XY iterations: sample 16 j + (lane & 15), j = 0, 1 (lanes 0..31 hold samples 0..31)
+    const float xa0 = __shfl(x0, lane & 15, 64), xa1 = __shfl(x1, lane & 15, 64), xa2 = __shfl(x2, lane & 15, 64);
+    const float xb0 = __shfl(x0, 16 + (lane & 15), 64), xb1 = __shfl(x1, 16 + (lane & 15), 64),
+                xb2 = __shfl(x2, 16 + (lane & 15), 64);
+    const bool livea = __shfl((int)live, lane & 15, 64) != 0, liveb = __shfl((int)live, 16 + (lane & 15), 64) != 0;
     float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
     for (int set = 0; set < a.nsets; ++set) {
       const float* rb = a.rows + ((size_t)t * a.stride + a.row0[set]) * 32;
@@ -900,33 +1035,45 @@ __global__ __launch_bounds__(256, 3) void k_scatter(ScatterArgs a) {
 #ifndef RDRF_SC_UNROLL
 #define RDRF_SC_UNROLL 1
 #endif
-      // ZSPLIT (density / blending families, bound by the L2 atomic request rate): per level C0Q/2
-      // iterations with one XY quad per half-wave, then 2*C1Q iterations with one XZ / YZ quad per
-      // WAVE, column-split across the halves (gather_zquad_bwd: half the plane requests, 1/3 more
-      // iterations).  The appearance family is VALU-issue bound and keeps one quad per half-wave.
+      // Per level: the XY plane's C0Q quads go four at a time over 16-sample sub-tiles
+      // (gather_xy4_bwd: a texel's four quads in one instruction = one 64-byte request); then the
+      // XZ / YZ quads, either column-split over the half-waves (ZSPLIT: density / blending, one
+      // quad per wave iteration, two bilinear columns = one request) or one quad per half-wave.
       constexpr bool ZSPLIT = C0Q <= 4;
-      constexpr int QPL = C0Q + 2 * C1Q, IPL = C0Q / 2 + 2 * C1Q, NLV = (2 * NQ) / QPL;
-      static_assert(C0Q % 2 == 0 && NLV * QPL == 2 * NQ, "quad layout");
-      if constexpr (ZSPLIT) {
-#pragma unroll RDRF_SC_UNROLL
-        for (int it = 0; it < NLV * IPL; ++it) {
-          const int lv = it / IPL, r = it - lv * IPL;
-          const bool xy = r < C0Q / 2;
-          const int g = lv * QPL + (xy ? 2 * r + h : C0Q + (r - C0Q / 2));
-          const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(4 * g) * 32) + s;
+      constexpr int QPL = C0Q + 2 * C1Q, NLV = (2 * NQ) / QPL;
+      static_assert(C0Q % 4 == 0 && NLV * QPL == 2 * NQ, "quad layout");
+      const int q = lane >> 4, s16 = lane & 15;
+#pragma unroll 1
+      for (int lv = 0; lv < NLV; ++lv) {
+#pragma unroll 1
+        for (int it = 0; it < C0Q / 2; ++it) {
+          const int grp = it >> 1, j = it & 1;
+          const int g = lv * QPL + 4 * grp + q;
+          const int sidx = 16 * j + s16;
+          const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(4 * g) * 32) + sidx;
           const int rs = a.bcast ? 0 : 32;
           const f32x4 dq = {rq[0], rq[rs], rq[2 * rs], rq[3 * rs]};
-          if (xy) gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], g, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
-          else gather_zquad_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], g, h, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+          gather_xy4_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], lv, 4 * grp + q, j ? xb0 : xa0, j ? xb1 : xa1,
+                                   j ? xb2 : xa2, dq, j ? liveb : livea, lane < 32 && q == j, dw0, dw1, dw2, ll);
         }
-      } else {
-#pragma unroll RDRF_SC_UNROLL
-        for (int o = 0; o < NQ; ++o) {
-          const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(8 * o + 4 * h) * 32) + s;
-          const int rs = a.bcast ? 0 : 32;
-          const f32x4 dq = {rq[0], rq[rs], rq[2 * rs], rq[3 * rs]};
-          gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], 2 * o + h, x0, x1, x2, dq, live, s, dw0, dw1,
-                                       dw2, ll);
+        if constexpr (ZSPLIT) {
+#pragma unroll 1
+          for (int zq = 0; zq < 2 * C1Q; ++zq) {
+            const int g = lv * QPL + C0Q + zq;
+            const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(4 * g) * 32) + s;
+            const int rs = a.bcast ? 0 : 32;
+            const f32x4 dq = {rq[0], rq[rs], rq[2 * rs], rq[3 * rs]};
+            gather_zquad_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], g, h, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+          }
+        } else {
+#pragma unroll 1
+          for (int zp = 0; zp < C1Q; ++zp) {
+            const int g = lv * QPL + C0Q + 2 * zp + h;
+            const float* rq = rb + (a.bcast ? (size_t)0 : (size_t)(4 * g) * 32) + s;
+            const int rs = a.bcast ? 0 : 32;
+            const f32x4 dq = {rq[0], rq[rs], rq[2 * rs], rq[3 * rs]};
+            gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], g, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+          }
         }
       }
     }
