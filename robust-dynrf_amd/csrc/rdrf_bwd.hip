@@ -374,16 +374,19 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
       const int dout = s < 31 ? nk - pkey : 0;
       skip_out = skip_mask(dout) & ~recv_mask(din);             // own taps the next run takes over
       if (pi == 0) {
-        f32x4 p00, p01, p10, p11;
-        p00.x = __shfl(r00.x, pl, 32); p00.y = __shfl(r00.y, pl, 32); p00.z = __shfl(r00.z, pl, 32); p00.w = __shfl(r00.w, pl, 32);
-        p01.x = __shfl(r01.x, pl, 32); p01.y = __shfl(r01.y, pl, 32); p01.z = __shfl(r01.z, pl, 32); p01.w = __shfl(r01.w, pl, 32);
-        p10.x = __shfl(r10.x, pl, 32); p10.y = __shfl(r10.y, pl, 32); p10.z = __shfl(r10.z, pl, 32); p10.w = __shfl(r10.w, pl, 32);
-        p11.x = __shfl(r11.x, pl, 32); p11.y = __shfl(r11.y, pl, 32); p11.z = __shfl(r11.z, pl, 32); p11.w = __shfl(r11.w, pl, 32);
+        (void)min_;
+        const f32x4 hA = dout == 65536 ? ((skip_out & 4) ? r10 : zero) : (dout == -65536 ? ((skip_out & 1) ? r00 : zero)
+                       : (dout == 1 ? ((skip_out & 2) ? r01 : zero) : ((skip_out & 1) ? r00 : zero)));
+        const f32x4 hB = dout == 65536 ? ((skip_out & 8) ? r11 : zero) : (dout == -65536 ? ((skip_out & 2) ? r01 : zero)
+                       : (dout == 1 ? ((skip_out & 8) ? r11 : zero) : ((skip_out & 4) ? r10 : zero)));
+        f32x4 pA, pB;
+        pA.x = __shfl(hA.x, pl, 32); pA.y = __shfl(hA.y, pl, 32); pA.z = __shfl(hA.z, pl, 32); pA.w = __shfl(hA.w, pl, 32);
+        pB.x = __shfl(hB.x, pl, 32); pB.y = __shfl(hB.y, pl, 32); pB.z = __shfl(hB.z, pl, 32); pB.w = __shfl(hB.w, pl, 32);
         f32x4 a00 = zero, a01 = zero, a10 = zero, a11 = zero;
-        if (din == 65536) { if (min_ & 4) a00 = p10; if (min_ & 8) a01 = p11; }
-        else if (din == -65536) { if (min_ & 1) a10 = p00; if (min_ & 2) a11 = p01; }
-        else if (din == 1) { if (min_ & 2) a00 = p01; if (min_ & 8) a10 = p11; }
-        else if (din == -1) { if (min_ & 1) a01 = p00; if (min_ & 4) a11 = p10; }
+        if (din == 65536) { a00 = pA; a01 = pB; }
+        else if (din == -65536) { a10 = pA; a11 = pB; }
+        else if (din == 1) { a00 = pA; a10 = pB; }
+        else if (din == -1) { a01 = pA; a11 = pB; }
         r00 = r00 + a00; r01 = r01 + a01;
         f32x4 t10 = r10 + a10, t11 = r11 + a11;
         // (r10 / r11 are const above: rebuild the outputs)
@@ -529,13 +532,18 @@ RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, 
     const int nk = dppi<0x101>(pkey);                        // row_shl:1 -> key of lane s16+1
     const int dout = s16 < 15 ? nk - pkey : 0;
     const int skip_out = skip_mask(dout) & ~recv_mask(din);
-    const f32x4 p00 = shfl4_row(r00, pl), p01 = shfl4_row(r01, pl), p10 = shfl4_row(r10, pl), p11 = shfl4_row(r11, pl);
-    f32x4 a00 = zero, a01 = zero, a10 = zero, a11 = zero;
-    if (din == 65536) { if (min_ & 4) a00 = p10; if (min_ & 8) a01 = p11; }
-    else if (din == -65536) { if (min_ & 1) a10 = p00; if (min_ & 2) a11 = p01; }
-    else if (din == 1) { if (min_ & 2) a00 = p01; if (min_ & 8) a10 = p11; }
-    else if (din == -1) { if (min_ & 1) a01 = p00; if (min_ & 4) a11 = p10; }
-    r00 = r00 + a00; r01 = r01 + a01; r10 = r10 + a10; r11 = r11 + a11;
+    // the EARLIER run prepares the two taps it hands over (its direction out = the later run's
+    // direction in), so the later run pulls two quads instead of four
+    (void)min_;
+    const f32x4 hA = dout == 65536 ? ((skip_out & 4) ? r10 : zero) : (dout == -65536 ? ((skip_out & 1) ? r00 : zero)
+                   : (dout == 1 ? ((skip_out & 2) ? r01 : zero) : ((skip_out & 1) ? r00 : zero)));
+    const f32x4 hB = dout == 65536 ? ((skip_out & 8) ? r11 : zero) : (dout == -65536 ? ((skip_out & 2) ? r01 : zero)
+                   : (dout == 1 ? ((skip_out & 8) ? r11 : zero) : ((skip_out & 4) ? r10 : zero)));
+    const f32x4 pA = shfl4_row(hA, pl), pB = shfl4_row(hB, pl);
+    if (din == 65536) { r00 = r00 + pA; r01 = r01 + pB; }
+    else if (din == -65536) { r10 = r10 + pA; r11 = r11 + pB; }
+    else if (din == 1) { r00 = r00 + pA; r10 = r10 + pB; }
+    else if (din == -1) { r01 = r01 + pA; r11 = r11 + pB; }
     atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00) && !(skip_out & 1));
     atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01) && !(skip_out & 2));
     atomic_add4(GP, o10, r10, pr.tail && g10 && nz4(r10) && !(skip_out & 4));
