@@ -91,11 +91,18 @@ RDRF_D void save_rows(float* __restrict__ tile_base, int row0, const float (&v)[
   return;
 #endif
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) tile_base[(size_t)(row0 + elem_of(kk, h)) * 32 + s] = v[kk];
+  for (int kk = 0; kk < KK; ++kk) {
+    // streaming (non-temporal) store: the rows are written once and read back a whole pass later,
+    // long after L2 eviction; keeping them out of L2 leaves it to the factor gathers (-15 % on the
+    // forward kernels)
+    __builtin_nontemporal_store(v[kk], tile_base + (size_t)(row0 + elem_of(kk, h)) * 32 + s);
+  }
 }
 template <int KK>
 RDRF_D void load_rows(const float* __restrict__ tile_base, int row0, float (&v)[KK], int s, int h) {
 #pragma unroll
+  // (non-temporal LOADS were measured too: the dW kernel, whose waves share rows through L2, got
+  // 10 % slower, the backward-data kernels 2 % faster -- not adopted)
   for (int kk = 0; kk < KK; ++kk) v[kk] = tile_base[(size_t)(row0 + elem_of(kk, h)) * 32 + s];
 }
 
