@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--stage", default="stage0", choices=["stage0", "final"])
+    ap.add_argument("--stage", default="stage0", choices=["stage0", "final", "huge"])
     ap.add_argument("--weights", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--rays-per-gpu", type=int, default=4096)
     ap.add_argument("--cpu-rays", type=int, default=512)

@@ -43,6 +43,8 @@ def balloon1_config(stage="stage0"):
         cfg.update(grid=[141, 157, 94], n_samples=115)
     elif stage == "final":
         cfg.update(grid=[331, 368, 220], n_samples=270)
+    elif stage == "huge":   # BASELINE.json configs[4]: N_voxel_final = 640^3
+        cfg.update(grid=[706, 786, 471], n_samples=578)
     else:
         raise ValueError(stage)
     cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * math.sqrt(3.0)
