@@ -1759,6 +1759,17 @@ static int lines_floats_host(const RdrfVM& vm) {
 template <typename K>
 static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles, hipStream_t stream) {
   const long bytes = 4L * (lines_floats_host(sa.vm[0]) + (sa.nsets > 1 ? lines_floats_host(sa.vm[1]) : 0));
+  if (sa.nsets == 2 && bytes > SC_LINES_MAX_BYTES && 4L * lines_floats_host(sa.vm[0]) <= SC_LINES_MAX_BYTES &&
+      4L * lines_floats_host(sa.vm[1]) <= SC_LINES_MAX_BYTES) {
+    // the two factor sets do not fit the LDS together but each does alone: one launch per set
+    ScatterArgs s0 = sa, s1 = sa;
+    s0.nsets = 1;
+    s1.nsets = 1;
+    s1.vm[0] = sa.vm[1]; s1.gvm[0] = sa.gvm[1]; s1.row0[0] = sa.row0[1];
+    s1.dxw_accumulate = 1;
+    int rc = launch_scatter(name, kern, s0, ntiles, stream);
+    return rc ? rc : launch_scatter(name, kern, s1, ntiles, stream);
+  }
   sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
