@@ -1,0 +1,53 @@
+"""End-to-end trainer harness (robust-dynrf_amd/step.py): a short run of the Nvidia.txt-shaped step on
+a small synthetic scene stays finite and reduces the loss -- catches sign / accumulation mistakes in
+the fused-gradient, pruning and optimiser wiring that per-kernel parity tests cannot see."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_short_training_run_reduces_loss():
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    cfg = S_.balloon1_config("stage0")
+    cfg.update(grid=[36, 40, 24], n_samples=48, batch_size=512, H=27, W=48, T=6)
+    cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * 3.0 ** 0.5
+    tr = S_.Trainer(cfg, torch.device("cuda", 0))
+    losses = []
+    for _ in range(40):
+        loss = tr.step()
+        tr.finish_step()
+        losses.append(float(loss.detach()))
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    for m in (tr.st, tr.dy):
+        for n, p in m.named_parameters():
+            assert torch.isfinite(p).all(), n
+    first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
+    assert last < 0.9 * first, (first, last)
+
+
+def test_trainer_sharded_step_matches_unsharded_gradients():
+    """rank-sharded steps (shard = (r, 2)) add up to the unsharded gradient of the per-ray losses:
+    the data-parallel exchange is a plain sum / mean of per-rank flat buffers."""
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    cfg = S_.balloon1_config("stage0")
+    cfg.update(grid=[24, 26, 16], n_samples=40, batch_size=256, H=27, W=48, T=6)
+    cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * 3.0 ** 0.5
+    dev = torch.device("cuda", 0)
+
+    def grads(shard):
+        tr = S_.Trainer(cfg, dev)
+        tr.step(shard)
+        return [f.clone() for f in tr.grad_flats]
+
+    full = grads(None)
+    parts = [grads((r, 2)) for r in range(2)]
+    for k in range(2):
+        mean = 0.5 * (parts[0][k] + parts[1][k])
+        # every loss term is a mean over the rank's rays (equal shard sizes) or a rank-independent
+        # regulariser, so the mean over ranks is the full-batch gradient up to the mask-normalised
+        # terms (flow / disparity masks), which are per-shard statistics: compare loosely
+        rel = float((mean - full[k]).norm() / full[k].norm())
+        assert rel < 0.15, rel
