@@ -51,3 +51,24 @@ def test_trainer_sharded_step_matches_unsharded_gradients():
         # terms (flow / disparity masks), which are per-shard statistics: compare loosely
         rel = float((mean - full[k]).norm() / full[k].norm())
         assert rel < 0.15, rel
+
+
+def test_bench_two_ranks_functional():
+    """bench.py through torch.distributed.run with 2 ranks.  The box has one GPU, so both ranks share
+    cuda:0 and use gloo (RDRF_DIST_BACKEND) instead of RCCL: everything but the transport of the N>1
+    path (sharding, in-place flat-buffer all-reduce, max-over-ranks timing, rank-0 JSON) runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RDRF_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays-per-gpu", "512", "--no-render"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 1024 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["parallelism"] == "ray-sharded dp2"
