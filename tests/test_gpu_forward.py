@@ -190,3 +190,41 @@ def test_render_frame_matches_oracle_pipeline():
     assert_close(a.view(-1, 3), outs[0].clamp(0, 1), "frame rgb", rtol=2e-4)
     assert_close(da.view(-1), outs[1], "frame depth", rtol=2e-4)
     assert float(rodynrf.psnr(a, a + 0.1)) == pytest.approx(20.0, abs=1e-3)
+
+
+def test_upsample_volume_grid_then_forward():
+    """upsample_volume_grid (models/tensoRF.py:223-232, 838-850; bilinear, align_corners): the new
+    factors keep the channel-last storage, stepSize / nSamples follow, and both fields still match
+    the oracle on the upsampled weights; the fused flat gradient buffer is rebuilt for the new shapes."""
+    import rodynrf
+    from _gpu_util import fields_from_case, make_rays, oracle_cfg, oracle_sd
+    from oracle import rodynrf_oracle as O
+    g, st, dy, _ = fields_from_case("ndc_relu")
+    ref_planes = [p.detach().cpu().contiguous() for p in dy.density_plane]
+    new = [25, 27, 16]
+    n_before = dy.nSamples
+    st.upsample_volume_grid(new)
+    dy.upsample_volume_grid(new)
+    assert list(dy.gridSize.tolist()) == new and dy.nSamples != n_before
+    for i, p in enumerate(dy.density_plane):
+        assert p.stride(1) == 1 and p.is_cuda
+        want = torch.nn.functional.interpolate(ref_planes[i], size=p.shape[2:], mode="bilinear", align_corners=True)
+        assert_close(p, want, f"upsampled density_plane.{i}", rtol=1e-6)
+    N, S = 40, 33
+    rays, ts = make_rays(N, 3)
+    aabb = st.aabb.cpu()
+    xyz, z, valid = O.sampleXYZ(rays, aabb, [float(v) for v in st.near_far], S, "ndc", None)
+    r_s = O.field_forward(oracle_sd(st), oracle_cfg(st), rays, ts, xyz, z, valid, "ndc", dynamic=False)
+    r_d = O.field_forward(oracle_sd(dy), oracle_cfg(dy), rays, ts, xyz, z, valid, "ndc", dynamic=True)
+    dev = "cuda"
+    args = (rays.to(dev), ts.to(dev), None, xyz.to(dev), z.to(dev), valid.to(dev))
+    o_s = st(*args, ray_type="ndc")
+    o_d = dy(*args, ray_type="ndc")
+    for k in (4, 6, 7):
+        assert_close(o_s[k], r_s[k], f"static out {k}")
+        assert_close(o_d[k], r_d[k], f"dynamic out {k}")
+    assert_close(o_d[2], r_d[2], "blending")
+    dy.fused_grad = True
+    dy.zero_grad_fused()
+    (o_d[6].sum() + o_d[7].sum()).backward()
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in dy._param_list())
