@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
-from .regularizers import tv_family
+from .regularizers import dense_l1, tv_family, vector_diffs
 
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
@@ -550,6 +550,16 @@ class TensorVMSplit(TensorBase):
     def warp_coordinate(self, xyz_sampled, t_sampled):
         return None
 
+    # models/tensoRF.py:63-98
+    def vectorDiffs(self, vector_comps):
+        return vector_diffs(vector_comps)
+
+    def vector_comp_diffs(self):
+        return vector_diffs(self.density_line) + vector_diffs(self.app_line)
+
+    def density_L1(self):
+        return dense_l1(self, self.density_plane, self.density_line)
+
     # models/tensoRF.py:100-116
     def TV_loss_density(self, reg):
         return tv_family(self, reg, self.density_plane, self.density_line)
@@ -639,6 +649,13 @@ class TensorVMSplit_TimeEmbedding(TensorBase):
         blending, weight, xyz_prime, rgb, sigma, dists = _DynamicFn.apply(
             self, ray_type, rays_chunk, ts_chunk, xyz_sampled, z_vals, ray_valid, *self._param_list())
         return (None, None, blending, xyz_sampled, weight, xyz_prime, rgb, sigma, z_vals, dists)
+
+    # models/tensoRF.py:378-416 (the reference's dynamic class has no vector_comp_diffs)
+    def density_L1(self):
+        return dense_l1(self, self.density_plane, self.density_line)
+
+    def blending_L1(self):
+        return dense_l1(self, self.blending_plane, self.blending_line)
 
     # models/tensoRF.py:418-444
     def TV_loss_blending(self, reg):

@@ -115,3 +115,28 @@ def tv_family(field, reg, planes, lines):
     for p, l in zip(planes, lines):
         total = total + reg(p) * 1e-2 + reg(l) * 1e-3
     return total
+
+
+# --------------------------------------------------------------------------------------------
+# regularisers that configs/Nvidia.txt leaves at weight 0 (DAVIS.txt uses density_L1): plain torch on
+# the device tensors, the same dense formulation as the reference -- not a hot path, no kernel.
+# --------------------------------------------------------------------------------------------
+def vector_diffs(lines):
+    """models/tensoRF.py:63-75: mean |off-diagonal| of the component Gram matrix of every line"""
+    total = 0
+    for v in lines:
+        n_comp, n_size = v.shape[1:-1]
+        m = v.reshape(n_comp, n_size)
+        dotp = m @ m.transpose(-1, -2)
+        off = dotp.reshape(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
+        total = total + off.abs().mean()
+    return total
+
+
+def dense_l1(field, planes, lines):
+    """models/tensoRF.py:80-98 / 378-416: mean |feature2density(sum_c plane x line)| over the grid"""
+    p0, p1, p2 = (p[0] for p in planes)            # (C, H, W) logical views
+    l0, l1, l2 = (l[0, :, :, 0] for l in lines)    # (C, L)
+    f = (torch.einsum("cyx,cz->xyz", p0, l0) + torch.einsum("czx,cy->xyz", p1, l1)
+         + torch.einsum("czy,cx->xyz", p2, l2))
+    return field.feature2density(f).abs().mean()

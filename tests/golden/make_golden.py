@@ -329,8 +329,22 @@ def gen_tv(mods):
             for i, gg in enumerate(gs):
                 nm = f"{fam}_plane.{i}" if i < 3 else f"{fam}_line.{i - 3}"
                 out[f"f.{tag}.{fam}.g.{nm}"] = gg.numpy()
+    # factor-space regularisers with default weight 0 in Nvidia.txt, used by DAVIS.txt:
+    # density_L1 / blending_L1 (models/tensoRF.py:80-98, 378-416), vector_comp_diffs (:63-78)
+    for tag, mod, names in (("s", st, ("density_L1", "vector_comp_diffs")),
+                            ("d", dy, ("density_L1", "blending_L1"))):   # the dynamic class has no vector_comp_diffs
+        for nm in names:
+            val = getattr(mod, nm)()
+            fam = "blending" if nm == "blending_L1" else "density"
+            ps = list(getattr(mod, f"{fam}_plane")) + list(getattr(mod, f"{fam}_line"))
+            if nm == "vector_comp_diffs":
+                ps = list(mod.density_line) + list(mod.app_line)
+            gs = torch.autograd.grad(val, ps, allow_unused=True)
+            out[f"r.{tag}.{nm}.value"] = val.detach().numpy()
+            for i, gg in enumerate(gs):
+                out[f"r.{tag}.{nm}.g{i}"] = (torch.zeros_like(ps[i]) if gg is None else gg).numpy()
     np.savez(os.path.join(HERE, "tv.npz"), **out)
-    print("tv: ok", float(out["f.s.density.total"]))
+    print("tv: ok", float(out["f.s.density.total"]), float(out["r.d.density_L1.value"]))
 
 
 if __name__ == "__main__":

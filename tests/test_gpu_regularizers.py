@@ -70,3 +70,25 @@ def test_tv_family_foreign_callable_matches():
     gb = torch.autograd.grad(b, list(st.app_plane))
     for x, y in zip(ga, gb):
         assert_close(x, y, "tv app plane grad", rtol=2e-5)
+
+
+def test_l1_and_ortho_regularisers_golden():
+    """density_L1 / blending_L1 / vector_comp_diffs (models/tensoRF.py:63-98, 378-416) on the weights
+    of the ndc_relu case against the reference's values and gradients."""
+    from _gpu_util import fields_from_case
+    _, st, dy, _ = fields_from_case("ndc_relu")
+    for tag, mod, names in (("s", st, ("density_L1", "vector_comp_diffs")),
+                            ("d", dy, ("density_L1", "blending_L1"))):
+        for nm in names:
+            val = getattr(mod, nm)()
+            assert_close(val, G[f"r.{tag}.{nm}.value"], f"{tag}.{nm}", rtol=2e-5)
+            fam = "blending" if nm == "blending_L1" else "density"
+            ps = list(getattr(mod, f"{fam}_plane")) + list(getattr(mod, f"{fam}_line"))
+            if nm == "vector_comp_diffs":
+                ps = list(mod.density_line) + list(mod.app_line)
+            gs = torch.autograd.grad(val, ps, allow_unused=True)
+            for i, gg in enumerate(gs):
+                ref = G[f"r.{tag}.{nm}.g{i}"]
+                gg = torch.zeros_like(ps[i]) if gg is None else gg
+                assert_close(gg, ref, f"{tag}.{nm}.g{i}", rtol=5e-5)
+    assert not hasattr(dy, "vector_comp_diffs")
