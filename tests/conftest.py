@@ -11,3 +11,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The C-ABI library is a build product (git-ignored): build it in-tree when a fresh checkout runs
+    the tests before __graft_entry__.build() (hipcc cross-compiles gfx950 without a GPU).  A failing
+    build is left for the tests to report -- importing the package raises loudly without the .so."""
+    so = os.path.join(ROOT, "robust-dynrf_amd", "librodynrf.so")
+    if os.environ.get("RDRF_LIB") or os.path.exists(so):
+        return
+    import shutil
+    import subprocess
+    if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "robust-dynrf_amd", "csrc"), "-j8"],
+                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
