@@ -93,6 +93,8 @@ struct BwdArgs {
   // outputs
   float* g_xyz;
   float* g_rays;   // [N][6] (+=): through dists (ray norm) and the static head's view directions
+  float* g_z;      // [N][S] (+=): through dists = (z[j+1] - z[j]) |d| scale (nullable; no reference loss
+                   // reaches it, kept for autograd completeness: models/tensorBase.py:726-731)
 };
 
 struct StaticG {
@@ -954,9 +956,14 @@ __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w,
     }
     float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
     g_sigma += g_alpha * ds * (1.0f - alpha);
-    if (a.g_rays && act) {  // dists = dz * |d| * scale: d(loss)/d|d|
+    if ((a.g_rays || a.g_z) && act) {  // dists = dz * |d| * scale: d(loss)/d|d| and d(loss)/dz
       const float g_ds = (a.g_dists ? a.g_dists[idx] : 0.f) + g_alpha * sigma * (1.0f - alpha);
-      g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+      if (a.g_rays) g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+      if (a.g_z && j + 1 < a.S) {
+        const float gz = g_ds * nrm * a.distance_scale;
+        atomicAdd(a.g_z + idx, -gz);
+        atomicAdd(a.g_z + idx + 1, gz);
+      }
     }
     const float gf = vld ? g_sigma * act_grad(f, a.act, a.density_shift) : 0.f;
     // d(loss)/d(density feature) per sample; the VM gather backward (scatter + coordinate gradients)
@@ -1189,9 +1196,14 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
         }
         float g_sigma = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
         g_sigma += g_alpha * ds * (1.0f - alpha);
-        if (a.g_rays && act && h == 0) {
+        if ((a.g_rays || a.g_z) && act && h == 0) {
           const float g_ds = (a.g_dists ? a.g_dists[idx] : 0.f) + g_alpha * sigma * (1.0f - alpha);
-          g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+          if (a.g_rays) g_nrm += g_ds * ((j + 1 < a.S) ? (zn - zj) : 0.0f) * a.distance_scale;
+          if (a.g_z && j + 1 < a.S) {
+            const float gz = g_ds * nrm * a.distance_scale;
+            atomicAdd(a.g_z + idx, -gz);
+            atomicAdd(a.g_z + idx + 1, gz);
+          }
         }
         const float g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
         const float bl = sigmoidf_(fb);
@@ -1795,11 +1807,10 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 2048, -1, "static_bwd: bad arguments (S <= 2048)");
   // z_vals never depends on a trainable quantity in the reference (linspace + jitter)
-  RDRF_CHECK(g_z == nullptr, -38, "static_bwd: gradient wrt z_vals (g_z) is not built");
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_xyz = g_xyz;
-  a.g_rays = g_rays; a.g_dists = g_dists;
+  a.g_rays = g_rays; a.g_dists = g_dists; a.g_z = g_z;
   RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 0, N, S), -3, "static_bwd: saved buffer too small");
   BwdWs b;
   int rc = carve_bwd(b, ws, ws_bytes, N, S, 0);
@@ -1853,7 +1864,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     rc = dw_launch(D, stream, "dw_static");
     if (rc) return rc;
   }
-  if (g_sigma != nullptr || g_weight != nullptr || (g_rays != nullptr && g_dists != nullptr)) {
+  if (g_sigma != nullptr || g_weight != nullptr || ((g_rays != nullptr || g_z != nullptr) && g_dists != nullptr)) {
     RDRF_LAUNCH("static_density_bwd", k_static_density_bwd, dim3(N), dim3(64), stream, a, w, b.gf);
     if (g_sigma != nullptr || g_weight != nullptr) {
       ScatterArgs sa;
@@ -1878,11 +1889,10 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 1024, -1, "dynamic_bwd: bad arguments (S <= 1024)");
-  RDRF_CHECK(g_z == nullptr, -38, "dynamic_bwd: gradient wrt z_vals (g_z) is not built");
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_blending = g_blending;
-  a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz; a.g_rays = g_rays; a.g_dists = g_dists;
+  a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz; a.g_rays = g_rays; a.g_dists = g_dists; a.g_z = g_z;
   RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 1, N, S), -3, "dynamic_bwd: saved buffer too small");
   BwdWs b;
   int rc = carve_bwd(b, ws, ws_bytes, N, S, 1);

@@ -290,3 +290,50 @@ def test_fused_grad_accumulation_matches_autograd():
     for m in (st, dy):
         m.zero_grad_fused()
         assert all(float(p.grad.abs().max()) == 0.0 for p in m._param_list())
+
+
+@pytest.mark.parametrize("rt", ["ndc", "contract"])
+def test_z_vals_gradient_matches_oracle(rt):
+    """d(loss)/d(z_vals): z enters the fields through dists = (z[j+1]-z[j]) |d| scale (-> alpha, weight,
+    the returned dists) and the compositor through the depth maps; no reference loss uses it, but
+    autograd must reach it.  Compared with the oracle's autograd."""
+    import rodynrf
+    from _gpu_util import COMMON, make_rays, oracle_cfg, oracle_sd
+    from oracle import rodynrf_oracle as O
+    torch.manual_seed(11)
+    contract = rt == "contract"
+    N, S, grid = 40, 45, [24, 26, 16]
+    aabb = torch.tensor([[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]] if contract else [[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]])
+    nf = [0.05, 256.0] if contract else [0.0, 1.0]
+    kw = dict(COMMON, near_far=nf, density_shift=-1.0 if contract else -10.0,
+              fea2denseAct="softplus" if contract else "relu")
+    st = rodynrf.TensorVMSplit(aabb, grid, 12, "cuda", shadingMode="MLP_Fea", fea_pe=2, **kw)
+    dy = rodynrf.TensorVMSplit_TimeEmbedding(aabb, grid, 12, "cuda", shadingMode="MLP_Fea_late_view",
+                                             fea_pe=0, **kw)
+    rays, ts = make_rays(N, 21, rt)
+    xyz, z0, valid = O.sampleXYZ(rays, aabb, nf, S, rt, None, None)
+    gl = torch.Generator().manual_seed(3)
+    w_dep, w_w = torch.rand(N, generator=gl), torch.rand(N, S, generator=gl)
+
+    def loss_of(mod_s, mod_d, comp, z, dev):
+        r, t, x, v = rays.to(dev), ts.to(dev), xyz.to(dev), valid.to(dev)
+        o_s, o_d = mod_s(r, t, x, z, v), mod_d(r, t, x, z, v)
+        outs = comp(o_s[6], o_s[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], r)
+        return ((outs[1] * w_dep.to(dev)).sum() + (outs[11] * w_w.to(dev)).sum() + (o_d[9] * w_w.to(dev)).sum()
+                + (o_s[4] * w_w.to(dev)).sum() + (outs[0] ** 2).sum())
+
+    zr = z0.clone().requires_grad_(True)
+    sd_s, sd_d = oracle_sd(st), oracle_sd(dy)
+    Lr = loss_of(lambda r, t, x, z, v: O.field_forward(sd_s, oracle_cfg(st), r, t, x, z, v, rt, dynamic=False),
+                 lambda r, t, x, z, v: O.field_forward(sd_d, oracle_cfg(dy), r, t, x, z, v, rt, dynamic=True),
+                 lambda *a: O.raw2outputs(*a, False, rt), zr, "cpu")
+    gref, = torch.autograd.grad(Lr, zr)
+    zg = z0.clone().cuda().requires_grad_(True)
+    Lg = loss_of(lambda r, t, x, z, v: st(r, t, None, x, z, v, ray_type=rt),
+                 lambda r, t, x, z, v: dy(r, t, None, x, z, v, ray_type=rt),
+                 lambda *a: rodynrf.raw2outputs(*a, is_train=False, ray_type=rt), zg, "cuda")
+    at = 256.0 * 2.0 ** -18 if contract else 0.0
+    assert_close(Lg, Lr, "loss", rtol=2e-4, atol=at)
+    gg, = torch.autograd.grad(Lg, zg)
+    assert float(gref.abs().max()) > 0
+    assert_close(gg, gref, "d loss / d z_vals", rtol=3e-4)
