@@ -191,7 +191,6 @@ class Trainer:
         self.it = 0
         self.coin = torch.Generator().manual_seed(7)
         self.tv = TVLoss()
-        self._coef_cache = {}
         # backward passes accumulate straight into p.grad (views of one flat buffer per field)
         self.st.fused_grad = self.dy.fused_grad = True
         self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
@@ -217,26 +216,26 @@ class Trainer:
         rays = self.rays_for(ids)
         dt = 2.0 / (c["T"] - 1)
         coin = lambda: bool(torch.rand(1, generator=self.coin).item() < 0.5)
-        terms = []   # (coefficient, scalar loss term): summed with ONE stack + dot at the end
-        mse, l1 = torch.nn.functional.mse_loss, torch.nn.functional.l1_loss
+        loss = 0.0
         # ---- pass A
         _, oA, outA, xyzA = ray_pass(self.st, self.dy, rays, ts, S, rt, white=coin())
-        terms += [(3.0, mse(outA[0], rgb_t)), (1.0, mse(outA[8], rgb_t)), (0.1, l1(outA[12], fg)),
-                  (0.04, l1(outA[9], disp_t))]
+        loss = loss + 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
+        loss = loss + 0.1 * (outA[12] - fg).abs().mean()
+        loss = loss + 0.04 * (outA[9] - disp_t).abs().mean()
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716;
         # configs/Nvidia.txt distortion_weight_dynamic = 0.01, ramped by iteration / n_iters)
         w_dist = 0.01 * min(1.0, (it + 1) / 100000.0)
-        terms.append((w_dist, eff_distloss(outA[11], oA[8].detach(), 1.0 / S)))
+        loss = loss + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
         # ---- pass B (second random time)
         ts_b = d.ts_of(ids2)
         _, oB, outB, _ = ray_pass(self.st, self.dy, rays, ts_b, S, rt, white=coin())
-        terms += [(0.01, outB[12].mean()), (0.01, l1(outB[9], outB[5].detach())),
-                  (w_dist, eff_distloss(outB[11], oB[8].detach(), 1.0 / S))]
+        loss = loss + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+        loss = loss + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
         w_d = outA[11].detach()[..., None]
-        terms += [(0.01, (sf_f.abs() * w_d).mean()), (0.01, (sf_b.abs() * w_d).mean()),
-                  (0.01, ((sf_f + sf_b) ** 2 * w_d).mean())]
+        loss = loss + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
+        loss = loss + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
         # ---- induced flow of the dynamic field into the neighbour frames (train.py:1373-1413)
         H, W, T = c["H"], c["W"], c["T"]
         col, row, view = ids2pixel(W, H, ids)
@@ -249,29 +248,23 @@ class Trainer:
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
             ind_flow, ind_disp = induce_flow(H, W, d.focal, pose_n, weights_d, pts_ref + sf, grid,
                                              rays.detach(), ray_type=rt)
-            inv_m = 1.0 / (mask_t.sum() + 1e-8)
-            terms.append((0.01, ((ind_flow - flow_t).abs() * mask_t).sum() * inv_m))   # 0.02 / 2 channels
-            disp_A[sgn] = (ind_disp, mask_t, pose_n, inv_m)
+            loss = loss + 0.02 * ((ind_flow - flow_t).abs() * mask_t).sum() / (mask_t.sum() + 1e-8) / 2.0
+            disp_A[sgn] = (ind_disp, mask_t, pose_n)
         # ---- pass C / D: neighbour frames (train.py:1433-1528, 1530-1625): disparity consistency
         for ids_n, sgn in ((ids2, 1), (ids3, -1)):
             rays_n = self.rays_for(ids_n).detach()
             ts_n = (ts + sgn * dt).clamp(-1.0, 1.0)
             _, oN, outN, xyzN = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, white=coin())
-            ind_disp, mask_t, pose_n, inv_m = disp_A[sgn]
+            ind_disp, mask_t, pose_n = disp_A[sgn]
             _, ind_disp_n = induce_flow(H, W, d.focal, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
-            terms += [(0.04, ((ind_disp - ind_disp_n).abs() * mask_t).sum() * inv_m),
-                      (w_dist, eff_distloss(outN[11], oN[8].detach(), 1.0 / S))]
+            loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
+            loss = loss + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
         # ---- pass E: static field with gradient
         _, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, static_grad=True, dynamic=False,
                                  white=coin())
         m = (1.0 - fg)[:, None]
-        terms += [(1.0 / 3.0, (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8)),
-                  (0.04, ((outE[5] - disp_t).abs() * m[:, 0]).mean())]
-        coefs = self._coef_cache.get(tuple(c_ for c_, _ in terms))
-        if coefs is None:
-            coefs = self._coef_cache[tuple(c_ for c_, _ in terms)] = torch.tensor(
-                [c_ for c_, _ in terms], device=rays.device)
-        loss = torch.dot(torch.stack([t_ for _, t_ in terms]), coefs)
+        loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
+        loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
         # ---- TV regularisers of every factor family (train.py:1735-1754, 1872-1885;
         #      configs/Nvidia.txt: TV_weight_density = TV_weight_app = 1.0).  The VALUE is NaN in the
         #      reference (line tensors have count_w = 0) while the gradients are finite, so it is
