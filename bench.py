@@ -345,8 +345,11 @@ def main():
             "f_app": f_avg, "flop_per_training_ray": F_ray, "gather_bytes_per_training_ray": B_ray,
             "achieved": t_star / t_meas, "frac_flop": F_ray / (PEAK_F32_MFMA_TFLOPS * 1e12 * t_meas),
             "frac_bytes": B_ray / (8e12 * t_meas),
-            "note": "SURVEY 8(d) constants with 5 ray-passes per training ray; gather bytes are "
-                    "L2/MALL-resident algorithmic bytes, not HBM traffic"}
+            "note": "SURVEY 8(d) constants with 5 ray-passes per training ray (the harness runs 5 static "
+                    "and 4 dynamic forwards: pass E's dynamic evaluation is dead work, SURVEY 3.1 "
+                    "liveness table, and branches without a loss are not differentiated, so this "
+                    "figure counts more work than is executed; step_frac_of_peak counts only what "
+                    "runs); gather bytes are L2/MALL-resident algorithmic bytes, not HBM traffic"}
     if rank == 0 and not args.no_render:
         # secondary metric of BASELINE.json: render Mpix/s -- whole 240x135 frames through the
         # no-grad chunk loop of renderer.py:740-812 (one C-ABI call per chunk of 8192 rays)

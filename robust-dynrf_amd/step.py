@@ -22,8 +22,12 @@ The dataset (RGB, RAFT flow, DPT disparity, masks) is synthetic here: targets ar
 of the right shape resident in HBM; the flow-displaced neighbour pixels of passes C/D are a second /
 third random ray-id batch.  The loss keeps the terms that determine which hot-path outputs carry
 gradient (image terms, dynamicness mask, disparity on depth maps, scene-flow magnitude and
-consistency-style terms on weights/points); the distortion loss and TV/L1 regularisers are the
-"next" rows of SURVEY.md 8f and are not part of this harness.
+consistency terms), the induced flow / disparity-consistency terms through ``induce_flow``
+(train.py:1373-1413, 1511-1528), the distortion loss of the dynamic weights in passes A-D
+(distortion_weight_dynamic = 0.01) and the TV regularisers of all five factor families
+(TV_weight_density = TV_weight_app = 1.0) -- i.e. every hot-path consumer of configs/Nvidia.txt.
+Branches no loss reaches are not differentiated, as in the reference's autograd: passes B-D carry no
+RGB term, so the appearance backward (MLP, scatter, dW) runs for pass A and the static pass E only.
 """
 import math
 
