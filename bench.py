@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--render-chunk", type=int, default=8192)
+    ap.add_argument("--exploit-liveness", action="store_true",
+                    help="skip pass E's dynamic-field forward, dead work the reference computes "
+                         "(SURVEY 3.1 liveness table); by default it is executed like the reference does")
     args = ap.parse_args()
 
     P = importlib.import_module("robust-dynrf_amd.parallel")
@@ -195,7 +198,7 @@ def main():
 
     cfg = S_.balloon1_config(args.stage)
     cfg["batch_size"] = args.rays_per_gpu * world   # weak scaling: fixed rays per GPU
-    trainer = S_.Trainer(cfg, dev, weights=args.weights)
+    trainer = S_.Trainer(cfg, dev, weights=args.weights, dead_work=not args.exploit_liveness)
     params = [p for g in trainer.opt.param_groups for p in g["params"]]
     bucket = P.GradBucket(params, flats=lambda: trainer.grad_flats)
     shard = (rank, world)
@@ -237,13 +240,36 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: Nvidia Balloon1, configs/Nvidia.txt, "
                                f"{args.rays_per_gpu} rays/iter/GPU, 1xMI355X per rank, static+dynamic "
-                               "TensorVMSplit; one step = 4 dynamic + 5 static forward passes, scene-flow "
+                               "TensorVMSplit; one step = 5 dynamic + 5 static forward passes, scene-flow "
                                "MLP, induced flow/disparity x4, distortion loss x4, compositor, TV regularisers, full backward, Adam",
                    "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
                    "global_batch": cfg["batch_size"], "weights": args.weights,
-                   "parallelism": f"ray-sharded dp{world}", "final_loss": loss_val},
+                   "parallelism": f"ray-sharded dp{world}", "final_loss": loss_val,
+                   "pass_E_dynamic_forward": "skipped (dead work, SURVEY 3.1)" if args.exploit_liveness
+                   else "executed (dead work the reference also computes)"},
     }
 
+    if not args.exploit_liveness:
+        # secondary figure: the same step without pass E's dead dynamic forward (identical results)
+        trainer.dead_work = False
+        one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt2 = (time.perf_counter() - t0) / max(3, args.steps // 2)
+        if world > 1:
+            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+        out["liveness_exploited"] = {"value": cfg["batch_size"] / dt2, "unit": "rays/s", "ms_per_step": dt2 * 1e3,
+                                     "note": "pass E's dynamic forward skipped (SURVEY 3.1: nothing consumes it)"}
+        trainer.dead_work = True
     if rank == 0 and not args.no_roofline:
         # measured sample fractions (enter the algorithmic FLOP counts)
         with torch.no_grad():

@@ -202,6 +202,13 @@ class _StaticFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_sigma, g_weight, g_dists):
         rays, ts, xyz, z, valid, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if g_rgb is None and g_sigma is None and g_weight is None and not (need[2] or need[5]):
+            # only `dists` is consumed downstream: it depends on z_vals and |d| alone, no parameter
+            # (and here neither rays nor z_vals want a gradient) -- nothing to differentiate, exactly
+            # as in the reference where dists has no parameter ancestry
+            ctx.saved = None
+            return (None,) * (7 + len(params))
         N, S = z.shape
         dev = z.device
         fused = ctx.field.fused_grad
@@ -254,6 +261,12 @@ class _DynamicFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_blending, g_weight, g_xyz_prime, g_rgb, g_sigma, g_dists):
         rays, ts, xyz, z, valid, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if all(g is None for g in (g_blending, g_weight, g_xyz_prime, g_rgb, g_sigma)) and not (need[2] or need[5]):
+            # only `dists` is consumed (pass E of the trainer feeds the dynamic field's dists to the
+            # compositor): no parameter ancestry, nothing to differentiate
+            ctx.saved = None
+            return (None,) * (7 + len(params))
         N, S = z.shape
         dev = z.device
         fused = ctx.field.fused_grad

@@ -108,8 +108,15 @@ class _CompositeFn(torch.autograd.Function):
         # like autograd on the reference's op graph, a branch no loss reaches gets NO gradient (not a
         # zero one): rgb_s only feeds rgb_map_full / rgb_map_s, rgb_d only rgb_map_full / rgb_map_d.
         # The field's backward then skips its whole appearance half (MLP, scatter, dW) for that pass.
-        need[0] = need[0] and (g_out[0] is not None or g_out[4] is not None)
-        need[2] = need[2] and (g_out[0] is not None or g_out[8] is not None)
+        have = lambda idx: any(g_out[i] is not None for i in idx)
+        need[0] = need[0] and have((0, 4))
+        need[2] = need[2] and have((0, 8))
+        # sigma_s feeds the full and the static maps, sigma_d / blending the full and the dynamic maps
+        # (renderer.py:190-262): e.g. pass E of the trainer consumes only rgb_map_s / depth_map_s, so
+        # the dynamic field gets no gradient at all from it
+        need[1] = need[1] and have((0, 1, 2, 3, 4, 5, 6, 7, 12))
+        need[3] = need[3] and have((0, 1, 2, 3, 8, 9, 10, 11, 12))
+        need[5] = need[5] and have((0, 1, 2, 3, 8, 9, 10, 11, 12))
         g_in = [torch.zeros_like(t) if n else None for t, n in zip(ins, need)]
         ga = (C.c_void_p * 13)(*[0 if g is None else g.data_ptr() for g in g_out])
         gi = (C.c_void_p * 8)(*[0 if g is None else g.data_ptr() for g in g_in])

@@ -173,7 +173,10 @@ def ray_pass(st, dy, rays, ts, n_samples, ray_type, is_train=True, static_grad=F
 
 
 class Trainer:
-    def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3):
+    def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False):
+        """dead_work: also run pass E's dynamic-field forward, which the reference computes although
+        nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical."""
+        self.dead_work = dead_work
         self.cfg = cfg
         self.device = device
         self.st, self.dy = build_fields(cfg, device)
@@ -264,8 +267,8 @@ class Trainer:
             loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
             loss = loss + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
         # ---- pass E: static field with gradient
-        _, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, static_grad=True, dynamic=False,
-                                 white=coin())
+        _, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, static_grad=True,
+                                 dynamic=self.dead_work, white=coin())
         m = (1.0 - fg)[:, None]
         loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
         loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
