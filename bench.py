@@ -65,7 +65,7 @@ def prof_get(L, name):
     return ms.value, n.value
 
 
-def cpu_baseline(trainer, n_rays, S, seed=0):
+def cpu_baseline(trainer, n_rays, S, seed=0, dead_work=True):
     """The oracle (oracle/rodynrf_oracle.py, torch-CPU restatement of the reference) running the
     SAME step structure on `n_rays` rays on the host cores: kind "port"."""
     from oracle import rodynrf_oracle as O
@@ -138,7 +138,7 @@ def cpu_baseline(trainer, n_rays, S, seed=0):
             _, ind_disp_n = O.induce_flow(H, W, focal, pose_n, outN[11], oN[3], grid, rays_n, "ndc")
             loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
             loss = loss + w_dist * O.eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
-        _, _, outE, _ = rp(rays, ts, True, False, False)
+        _, _, outE, _ = rp(rays, ts, True, dead_work, False)   # pass E: dynamic forward is dead work
         m = (1.0 - fg)[:, None]
         loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
         loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
@@ -401,7 +401,8 @@ def main():
         out["render"] = {"value": H * W / dtf / 1e6, "unit": "Mpix/s", "frame": [H, W],
                          "chunk": chunk, "samples_per_ray": cfg["n_samples"], "ms_per_frame": dtf * 1e3}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, cfg["n_samples"])
+        out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, cfg["n_samples"],
+                                           dead_work=not args.exploit_liveness)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
