@@ -81,6 +81,18 @@ __global__ void kH(float* buf, unsigned ntex, int iters) {
     }
   }
 }
+// I: like B, but every XCD (workgroups are dealt round-robin: XCD = blockIdx.x % 8) updates its own
+// eighth of the buffer.  I >> B  => cross-XCD sharing of lines (L2 coherence) limits the atomic rate.
+__global__ void kI(float* buf, unsigned ntex, int iters) {
+  unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned part = ntex / 8, base = (blockIdx.x & 7) * part;
+  for (int i = 0; i < iters; ++i) {
+    for (int k = 0; k < 4; ++k) {
+      unsigned tex = base + hash(((t >> 2) * 4 + k) * 977u + i) % part;
+      atomicAdd(buf + (size_t)tex * 4 + (t & 3), 1.f);
+    }
+  }
+}
 // D: A without atomics (plain read-modify-write, racy) as a bandwidth reference
 __global__ void kD(float* buf, unsigned ntex, int iters) {
   unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +110,7 @@ int main() {
     const int blocks = 2048, threads = 256, iters = 16;
     const double natom = (double)blocks * threads * iters * 4;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int kind = 0; kind < 8; ++kind) {
+    for (int kind = 0; kind < 9; ++kind) {
       float best = 1e9;
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
@@ -110,10 +122,11 @@ int main() {
         if (kind == 5) kF<<<blocks, threads>>>(buf, ntex, iters);
         if (kind == 6) kG<<<blocks, threads>>>(buf, ntex, iters);
         if (kind == 7) kH<<<blocks, threads>>>(buf, ntex, iters);
+        if (kind == 8) kI<<<blocks, threads>>>(buf, ntex, iters);
         hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
       }
-      printf("ntex %8u  kernel %c  %.3f ms  %.1f G scalar-updates/s (if all lanes live)  %.2f G wave-instr/s\n", ntex, "ABCDEFGH"[kind], best, natom / best / 1e6, natom / 64.0 / best / 1e6);
+      printf("ntex %8u  kernel %c  %.3f ms  %.1f G scalar-updates/s (if all lanes live)  %.2f G wave-instr/s\n", ntex, "ABCDEFGHI"[kind], best, natom / best / 1e6, natom / 64.0 / best / 1e6);
     }
     CHECK(hipFree(buf));
   }
