@@ -228,3 +228,45 @@ def test_upsample_volume_grid_then_forward():
     dy.zero_grad_fused()
     (o_d[6].sum() + o_d[7].sum()).backward()
     assert all(p.grad is not None and p.grad.shape == p.shape for p in dy._param_list())
+
+
+def test_c_abi_error_paths():
+    """The C entry points never crash on bad arguments: they return a negative code and leave a
+    message for rdrf_last_error() (which the ctypes binding turns into RdrfError)."""
+    import ctypes as C
+    import importlib
+    import rodynrf
+    from _gpu_util import fields_from_case
+    L = importlib.import_module("robust-dynrf_amd._lib")
+    F = importlib.import_module("robust-dynrf_amd.fields")
+    g, st, dy, _ = fields_from_case("ndc_relu")
+    dev = "cuda"
+    rays = torch.from_numpy(g["rays"]).to(dev)
+    ts = torch.from_numpy(g["ts"]).to(dev)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    z = torch.from_numpy(g["z"]).to(dev)
+    valid = torch.from_numpy(g["valid"]).to(dev).view(torch.uint8)
+    N, S = z.shape
+    out = [torch.empty(N, S, 3, device=dev)] + [torch.empty(N, S, device=dev) for _ in range(3)]
+    P = F._static_struct(st._param_list())
+    cfg = F._cfg_struct(st, "ndc")
+    tiny = torch.empty(64, dtype=torch.uint8, device=dev)           # workspace far too small
+    rc = L.lib.rdrf_static_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz), L.ptr(z),
+                               L.ptr(valid), N, S, *[L.ptr(o) for o in out], None, C.c_size_t(0),
+                               L.ptr(tiny), C.c_size_t(tiny.numel()), L.stream_of(z))
+    assert rc < 0 and b"workspace" in L.lib.rdrf_last_error()
+    rc = L.lib.rdrf_static_fwd(C.byref(P), C.byref(cfg), None, L.ptr(ts), L.ptr(xyz), L.ptr(z),
+                               L.ptr(valid), N, S, *[L.ptr(o) for o in out], None, C.c_size_t(0),
+                               L.ptr(tiny), C.c_size_t(tiny.numel()), L.stream_of(z))
+    assert rc < 0 and len(L.lib.rdrf_last_error()) > 0                # null rays
+    with pytest.raises(L.RdrfError):
+        rodynrf.induce_flow(9, 16, 10.0, torch.zeros(N, 3, 4, device=dev), torch.zeros(N, S, device=dev),
+                            torch.zeros(N, S, 3, device=dev), torch.zeros(N, 2, device=dev), rays, ray_type="other")
+    with pytest.raises(L.RdrfError):                                  # CPU tensors: no fallback
+        st(rays.cpu(), ts.cpu(), None, xyz.cpu(), z.cpu(), valid.cpu(), ray_type="ndc")
+    with pytest.raises(NotImplementedError):                          # unsupported component counts
+        rodynrf.TensorVMSplit(st.aabb, [8, 8, 8], 12, dev, density_n_comp=[8, 8, 8], appearance_n_comp=[48, 12, 12],
+                              app_dim=27, featureC=128, view_pe=0, shadingMode="MLP_Fea", fea_pe=2)
+    # the good path still works afterwards (no sticky error state)
+    o = st(rays, ts, None, xyz, z, valid, ray_type="ndc")
+    assert torch.isfinite(o[6]).all()
