@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
-    ap.add_argument("--render-chunk", type=int, default=8192)
+    ap.add_argument("--render-chunk", type=int, default=32768, help="rays per render call (default: a whole 240x135 frame)")
     ap.add_argument("--exploit-liveness", action="store_true",
                     help="skip pass E's dynamic-field forward, dead work the reference computes "
                          "(SURVEY 3.1 liveness table); by default it is executed like the reference does")
@@ -378,7 +378,7 @@ def main():
                     "runs); gather bytes are L2/MALL-resident algorithmic bytes, not HBM traffic"}
     if rank == 0 and not args.no_render:
         # secondary metric of BASELINE.json: render Mpix/s -- whole 240x135 frames through the
-        # no-grad chunk loop of renderer.py:740-812 (one C-ABI call per chunk of 8192 rays)
+        # no-grad chunk loop of renderer.py:740-812 (one C-ABI call per chunk; default: the whole frame)
         R = importlib.import_module("robust-dynrf_amd.renderer")
         H, W = cfg["H"], cfg["W"]
         ids = torch.arange(H * W, device=dev)
