@@ -156,6 +156,41 @@ int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const 
                      float* g_rays, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
                      rdrf_stream_t stream);
 
+/* ---- compute_densityfeature / compute_appfeature / compute_blendingfeature / warp_coordinate -----
+ * The per-point building blocks TensorBase.forward calls (models/tensoRF.py:118-196 static;
+ * :521-541 warp_coordinate, :543-629 compute_blendingfeature, :646-732 compute_densityfeature,
+ * :734-811 compute_appfeature dynamic), on a batch of M independent points.  They run the SAME
+ * kernels as rdrf_*_fwd/bwd in a point geometry (32 points per wave tile, time per point).
+ *   xn[M][3]     NORMALISED coordinates ([-1,1] inside the aabb; outside is zero padded, as grid_sample)
+ *   density[M]   raw density feature (static: sum of the 24 VM products; dynamic: density_layer2 output)
+ *   blending[M]  raw blending feature (before the sigmoid)
+ *   app[M][27]   basis_mat output
+ * Any output pointer may be NULL (not computed).  saved: NULL for inference, else a buffer of
+ * rdrf_features_saved_bytes(dynamic, M) bytes that the matching *_bwd call needs.
+ * dynamic: x is xn when x_is_normalized != 0 (compute_*), else UN-normalised coordinates
+ * (warp_coordinate); t[M] is the time of every point; xyz_prime[M][3] = un-normalised warped point.
+ * bwd: g_* gradients wrt the outputs (NULL = zero); parameter gradients accumulate (+=) into G;
+ * g_x[M][3] (+=, may be NULL) is the gradient wrt the coordinates as they were passed in. */
+size_t rdrf_features_saved_bytes(int dynamic, int M);
+size_t rdrf_features_workspace_bytes(int M);
+size_t rdrf_features_bwd_workspace_bytes(int M);
+int rdrf_static_features_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* xn, int M,
+                             float* density, float* app, void* saved, size_t saved_bytes, void* ws,
+                             size_t ws_bytes, rdrf_stream_t stream);
+int rdrf_static_features_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* xn, int M,
+                             const float* g_density, const float* g_app, const RdrfStaticParams* G,
+                             float* g_xn, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                             rdrf_stream_t stream);
+int rdrf_dynamic_features_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* x,
+                              const float* t, int M, int x_is_normalized, float* density, float* blending,
+                              float* app, float* xyz_prime, void* saved, size_t saved_bytes, void* ws,
+                              size_t ws_bytes, rdrf_stream_t stream);
+int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* x,
+                              const float* t, int M, int x_is_normalized, const float* g_density,
+                              const float* g_blending, const float* g_app, const float* g_xyz_prime,
+                              const RdrfDynamicParams* G, float* g_x, void* saved, size_t saved_bytes,
+                              void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
 /* ---- get_forward_backward_scene_flow (models/tensoRF.py:446-462) -----------------------------
  * pts[N][S][3] un-normalised, ts[N] -> sf_f[N][S][3], sf_b[N][S][3]. */
 int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* pts,

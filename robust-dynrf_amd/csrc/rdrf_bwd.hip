@@ -95,6 +95,10 @@ struct BwdArgs {
   float* g_rays;   // [N][6] (+=): through dists (ray norm) and the static head's view directions
   float* g_z;      // [N][S] (+=): through dists = (z[j+1] - z[j]) |d| scale (nullable; no reference loss
                    // reaches it, kept for autograd completeness: models/tensorBase.py:726-731)
+  // feature mode (template parameter FEAT; see FieldArgs): M points, g_sigma / g_blending carry the
+  // gradients of the RAW density / blending features, g_feat [M][27] of the appearance features
+  int M, in_norm;
+  const float* g_feat;
 };
 
 struct StaticG {
@@ -692,21 +696,44 @@ RDRF_D void acc_zero(f32x16 (&acc)[NB]) {
 // ------------------------------------------------------------------------------------------------
 // appearance phase backward-data (dynamic: MLP_Fea_late_view; static: MLP_Fea | TimeEmbedding)
 // ------------------------------------------------------------------------------------------------
+// FEAT: the features ARE the basis output: d(features) arrive in g_feat, only the basis backward runs
+template <bool FEAT>
+RDRF_D void feat_dF(float (&dF)[16], const float* g_feat, int idx, bool act, int h) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int e = elem_of(kk, h);
+    dF[kk] = (act && e < 27) ? g_feat[(size_t)idx * 27 + e] : 0.f;
+  }
+}
+
+template <bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::K3_SIZE];
   lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_SIZE);
   const float* basisT = lds + pkb::K3_BASIST;
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int count = a.sp.hdr->count;
+  const int count = FEAT ? a.M : a.sp.hdr->count;
   const int ntiles = (count + 31) >> 5;
   for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
     const int li = tile * 32 + s;
     const bool act = li < count;
-    const int idx = act ? a.sp.list[li] : 0;
+    const int idx = act ? (FEAT ? li : a.sp.list[li]) : 0;
     const int n = idx / a.S;
     const float* svb = a.sp.act3 + (size_t)tile * sv::K3_ROWS * 32;
     float* gb = a.grows3 + (size_t)tile * sv::K3G_ROWS * 32;
+    if constexpr (FEAT) {
+      float dF[16];
+      feat_dF<true>(dF, a.g_feat, idx, act, h);
+      save_rows<16>(gb, sv::K3G_DF, dF, s, h);
+      f32x16 acc[7];
+      acc_zero<7>(acc);
+      mfma_seg<7, 16>(acc, dF, basisT, lane);
+      float dA[112];
+      acc_copy<7>(dA, acc);
+      save_rows<112>(gb, sv::K3G_DA, dA, s, h);
+      continue;
+    }
     float vx, vy, vz;
     ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
     // ---- output layer: v = Wv [H2, vd] + b ; rgb = sigmoid(v)
@@ -779,21 +806,33 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
   }
 }
 
-template <int HEAD>
+template <int HEAD, bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, StaticW w, StaticG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::S3_SIZE];
   lds_fill(lds, a.pk + pkb::REG_S3, pkb::S3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int count = a.sp.hdr->count;
+  const int count = FEAT ? a.M : a.sp.hdr->count;
   const int ntiles = (count + 31) >> 5;
   for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
     const int li = tile * 32 + s;
     const bool act = li < count;
-    const int idx = act ? a.sp.list[li] : 0;
+    const int idx = act ? (FEAT ? li : a.sp.list[li]) : 0;
     const int n = idx / a.S;
     const float* svb = a.sp.act3 + (size_t)tile * sv::S3_ROWS * 32;
     float* gb = a.grows3 + (size_t)tile * sv::K3G_ROWS * 32;
+    if constexpr (FEAT) {
+      float dF[16];
+      feat_dF<true>(dF, a.g_feat, idx, act, h);
+      save_rows<16>(gb, sv::K3G_DF, dF, s, h);
+      f32x16 acc[3];
+      acc_zero<3>(acc);
+      mfma_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, lane);
+      float dG[48];
+      acc_copy<3>(dG, acc);
+      save_rows<48>(gb, sv::K3G_DA, dG, s, h);
+      continue;
+    }
     float vx, vy, vz;
     ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
     float H2[64];
@@ -1127,7 +1166,7 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
 //   PHASE 1 (warp) : coordinate gradients (appearance + density + blending scatter) ->
 //                    warp MLP backward, positional-encoding backward, g_xyz, d(tout)
 // ------------------------------------------------------------------------------------------------
-template <int PHASE>
+template <int PHASE, bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[PHASE == 0 ? pkb::K1H_SIZE : pkb::K1W_SIZE];
   __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
@@ -1136,9 +1175,10 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = (a.S + 31) >> 5;
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
-    float vx, vy, vz;
-    const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-    if (PHASE == 0 && a.g_weight) {  // pre-pass: transmittance at each tile start
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    float nrm = 1.0f;
+    if constexpr (!FEAT) nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    if (!FEAT && PHASE == 0 && a.g_weight) {  // pre-pass: transmittance at each tile start
       float carry = 1.0f;
       for (int j0 = 0; j0 < a.S; j0 += 32) {
         if (lane == 0) carr[wave][j0 >> 5] = carry;
@@ -1162,13 +1202,18 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
     for (int tli = tpr - 1; tli >= 0; --tli) {  // LAST tile first: direct suffix sums
       const int j0 = tli << 5;
       const int j = j0 + s;
-      const bool act = j < a.S;
+      const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
       const int idx = n * a.S + (act ? j : 0);
-      const bool vld = act && a.valid[idx] != 0;
+      const bool vld = act && (FEAT || a.valid[idx] != 0);
       const size_t tl = (size_t)n * tpr + tli;
       const float* svb = a.sp.act1 + tl * sv::K1_ROWS * 32;
       float* gb = a.grows1 + tl * sv::K1G_ROWS * 32;
       if (PHASE == 0) {
+        float g_fd, g_fb;
+        if constexpr (FEAT) {  // the gradients of the raw head outputs arrive directly
+          g_fd = (act && a.g_sigma) ? a.g_sigma[idx] : 0.f;
+          g_fb = (act && a.g_blending) ? a.g_blending[idx] : 0.f;
+        } else {
         const float fd = a.sp.raw[(size_t)idx * 2], fb = a.sp.raw[(size_t)idx * 2 + 1];
         const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.f;
         const float zj = act ? a.z[idx] : 0.f;
@@ -1205,9 +1250,10 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
             atomicAdd(a.g_z + idx + 1, gz);
           }
         }
-        const float g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
+        g_fd = vld ? g_sigma * act_grad(fd, a.act, a.density_shift) : 0.f;
         const float bl = sigmoidf_(fb);
-        const float g_fb = (vld && a.g_blending) ? a.g_blending[idx] * bl * (1.0f - bl) : 0.f;
+        g_fb = (vld && a.g_blending) ? a.g_blending[idx] * bl * (1.0f - bl) : 0.f;
+        }
         f32x16 accX[2];  // d(X0) of the density and blending heads
         acc_zero<2>(accX);
 #pragma unroll
@@ -1303,13 +1349,26 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
           dn0 += e0 + dw0; dn1 += e1 + dw1; dn2 += e2 + dw2;
         }
         if (act && h == 0 && a.g_xyz) {
-          a.g_xyz[(size_t)idx * 3 + 0] += dn0 * a.box.inv[0] + gp0;
-          a.g_xyz[(size_t)idx * 3 + 1] += dn1 * a.box.inv[1] + gp1;
-          a.g_xyz[(size_t)idx * 3 + 2] += dn2 * a.box.inv[2] + gp2;
+          if (FEAT && a.in_norm) {   // compute_*: gradient wrt the NORMALISED input coordinates
+            a.g_xyz[(size_t)idx * 3 + 0] += dn0; a.g_xyz[(size_t)idx * 3 + 1] += dn1;
+            a.g_xyz[(size_t)idx * 3 + 2] += dn2;
+          } else {
+            a.g_xyz[(size_t)idx * 3 + 0] += dn0 * a.box.inv[0] + gp0;
+            a.g_xyz[(size_t)idx * 3 + 1] += dn1 * a.box.inv[1] + gp1;
+            a.g_xyz[(size_t)idx * 3 + 2] += dn2 * a.box.inv[2] + gp2;
+          }
+        }
+        if constexpr (FEAT) {  // time is per point: d(tout) of this sample, no reduction over the tile
+          if (act) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a.dtout[(size_t)idx * 32 + elem_of(i, h)] = dTacc[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dTacc[i] = 0.f;
         }
       }
     }
-    if (PHASE == 1) {  // per-ray d(tout): sum over the samples (lanes of each half)
+    if (PHASE == 1 && !FEAT) {  // per-ray d(tout): sum over the samples (lanes of each half)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float v = dTacc[i];
@@ -1318,7 +1377,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
         if (s == 0) a.dtout[(size_t)n * 32 + elem_of(i, h)] = v;
       }
     }
-    if (PHASE == 0 && a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
+    if (!FEAT && PHASE == 0 && a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
       g_nrm = wave_sum(g_nrm);
       if (lane < 3) atomicAdd(a.g_rays + (size_t)n * 6 + 3 + lane, g_nrm * (lane == 0 ? vx : (lane == 1 ? vy : vz)));
     }
@@ -1797,6 +1856,40 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   return 0;
 }
 
+// dW jobs of the dynamic field's density phase (warp MLP, density / blending heads)
+static void add_density_phase_dw(DwJobs& D, const float* grows1, const float* act1, const RdrfDynamicParams* G,
+                                 int T1) {
+  // layer3: [X0 | tout]
+  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_DZ3, 2, 64, 0, act1, sv::K1_ROWS, 93, 93, G->l3w, G->l3b, nullptr, T1);
+  dw_blk(D, sv::K1_X0, SEG_WARP3_X0, 0);
+  dw_blk(D, sv::K1_X0 + 32, SEG_WARP3_X0, 32);
+  dw_blk(D, sv::K1_T, SEG_WARP3_T, 0);
+  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_DZ4, 2, 64, 0, act1, sv::K1_ROWS, 64, 64, G->l4w, G->l4b, nullptr, T1);
+  dw_blk(D, sv::K1_H3, SEG_IDENT, 0);
+  dw_blk(D, sv::K1_H3 + 32, SEG_IDENT, 32);
+  // small layers share one dz block: rows 0..2 -> layer5, row 3 -> density_layer2, row 4 -> blending_layer2
+  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 3, 0, act1, sv::K1_ROWS, 64, 64, G->l5w, G->l5b, nullptr, T1);
+  dw_blk(D, sv::K1_H4, SEG_IDENT, 0);
+  dw_blk(D, sv::K1_H4 + 32, SEG_IDENT, 32);
+  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 3, act1, sv::K1_ROWS, 64, 64, G->dw2, G->db2, nullptr, T1);
+  dw_blk(D, sv::K1_HD, SEG_IDENT, 0);
+  dw_blk(D, sv::K1_HD + 32, SEG_IDENT, 32);
+  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, act1, sv::K1_ROWS, 64, 64, G->bw2, G->bb2, nullptr, T1);
+  dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
+  dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
+  for (int head = 0; head < 2; ++head) {
+    dw_add(D, grows1, sv::K1G_ROWS, head ? sv::K1G_DZB : sv::K1G_DZD, 2, 64, 0, act1, sv::K1_ROWS, 152, 152,
+           head ? G->bw1 : G->dw1, head ? G->bb1 : G->db1, nullptr, T1);
+    const int f0 = head ? sv::K1_FB : sv::K1_FD;
+    dw_blk(D, f0, SEG_IDENT72, 0);
+    dw_blk(D, f0 + 32, SEG_IDENT72, 32);
+    dw_blk(D, f0 + 64, SEG_IDENT72, 64);
+    dw_blk(D, sv::K1_X0, SEG_DEN1_X0, 0);
+    dw_blk(D, sv::K1_X0 + 32, SEG_DEN1_X0, 32);
+    dw_blk(D, sv::K1_X1, SEG_DEN1_X1, 0);
+  }
+}
+
 extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                                const float* ts, const float* xyz, const float* z,
                                const uint8_t* valid, int N, int S, const float* g_rgb,
@@ -1828,10 +1921,10 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   if (g_rgb != nullptr) {
     const Geo g = geo_for_units((long)t3);
     if (cfg->static_head == RDRF_HEAD_MLP_FEA)
-      RDRF_LAUNCH("static_app_bwd", k_static_app_bwd<RDRF_HEAD_MLP_FEA>, dim3(g.grid), dim3(g.block),
+      RDRF_LAUNCH("static_app_bwd", (k_static_app_bwd<RDRF_HEAD_MLP_FEA, false>), dim3(g.grid), dim3(g.block),
                   stream, a, w, gw);
     else
-      RDRF_LAUNCH("static_app_bwd", k_static_app_bwd<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING>, dim3(g.grid),
+      RDRF_LAUNCH("static_app_bwd", (k_static_app_bwd<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING, false>), dim3(g.grid),
                   dim3(g.block), stream, a, w, gw);
     {
       ScatterArgs sa;
@@ -1916,7 +2009,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   D.n = 0;
   if (g_rgb != nullptr) {
     const Geo g = geo_for_units((long)t3);
-    RDRF_LAUNCH("dyn_app_bwd", k_dyn_app_bwd, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    RDRF_LAUNCH("dyn_app_bwd", k_dyn_app_bwd<false>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
     {
       ScatterArgs sa;
       fill_scatter_common(sa, a);
@@ -1945,7 +2038,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   }
   {
     const Geo g = geo_for_units(N);
-    RDRF_LAUNCH("dyn_heads_bwd", k_dyn_density_bwd<0>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    RDRF_LAUNCH("dyn_heads_bwd", (k_dyn_density_bwd<0, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     {
       ScatterArgs sa;
       fill_scatter_common(sa, a);
@@ -1956,47 +2049,170 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
       sa.dxw = b.dxw; sa.dxw_accumulate = 1;
       { int rc_ = launch_scatter("scatter_dyn_density", k_scatter<4, 1, 9>, sa, (long)t1, stream); if (rc_) return rc_; }
     }
-    RDRF_LAUNCH("dyn_warp_bwd", k_dyn_density_bwd<1>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    RDRF_LAUNCH("dyn_warp_bwd", (k_dyn_density_bwd<1, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((N + TB_RPB - 1) / TB_RPB), dim3(128), stream, ts, w,
                 N, b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
-    const int T1 = (int)t1;
-    // layer3: [X0 | tout]
-    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_DZ3, 2, 64, 0, a.sp.act1, sv::K1_ROWS, 93, 93, G->l3w,
-           G->l3b, nullptr, T1);
-    dw_blk(D, sv::K1_X0, SEG_WARP3_X0, 0);
-    dw_blk(D, sv::K1_X0 + 32, SEG_WARP3_X0, 32);
-    dw_blk(D, sv::K1_T, SEG_WARP3_T, 0);
-    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_DZ4, 2, 64, 0, a.sp.act1, sv::K1_ROWS, 64, 64, G->l4w,
-           G->l4b, nullptr, T1);
-    dw_blk(D, sv::K1_H3, SEG_IDENT, 0);
-    dw_blk(D, sv::K1_H3 + 32, SEG_IDENT, 32);
-    // small layers share one dz block: rows 0..2 -> layer5, row 3 -> density_layer2, row 4 -> blending_layer2
-    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 3, 0, a.sp.act1, sv::K1_ROWS, 64, 64, G->l5w,
-           G->l5b, nullptr, T1);
-    dw_blk(D, sv::K1_H4, SEG_IDENT, 0);
-    dw_blk(D, sv::K1_H4 + 32, SEG_IDENT, 32);
-    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 3, a.sp.act1, sv::K1_ROWS, 64, 64, G->dw2,
-           G->db2, nullptr, T1);
-    dw_blk(D, sv::K1_HD, SEG_IDENT, 0);
-    dw_blk(D, sv::K1_HD + 32, SEG_IDENT, 32);
-    dw_add(D, b.grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, a.sp.act1, sv::K1_ROWS, 64, 64, G->bw2,
-           G->bb2, nullptr, T1);
-    dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
-    dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
-    for (int head = 0; head < 2; ++head) {
-      dw_add(D, b.grows1, sv::K1G_ROWS, head ? sv::K1G_DZB : sv::K1G_DZD, 2, 64, 0, a.sp.act1,
-             sv::K1_ROWS, 152, 152, head ? G->bw1 : G->dw1, head ? G->bb1 : G->db1, nullptr, T1);
-      const int f0 = head ? sv::K1_FB : sv::K1_FD;
-      dw_blk(D, f0, SEG_IDENT72, 0);
-      dw_blk(D, f0 + 32, SEG_IDENT72, 32);
-      dw_blk(D, f0 + 64, SEG_IDENT72, 64);
-      dw_blk(D, sv::K1_X0, SEG_DEN1_X0, 0);
-      dw_blk(D, sv::K1_X0 + 32, SEG_DEN1_X0, 32);
-      dw_blk(D, sv::K1_X1, SEG_DEN1_X1, 0);
-    }
+    add_density_phase_dw(D, b.grows1, a.sp.act1, G, (int)t1);
   }
   rc = dw_launch(D, stream, "dw_dyn");
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature mode backward (compute_* / warp_coordinate): gradients of the raw features wrt every
+// parameter they depend on and wrt the input coordinates; pseudo-ray geometry (rdrf_fwd.hip)
+// ------------------------------------------------------------------------------------------------
+struct FeatWs {
+  float *pk, *grows3, *grows1, *dxw, *dxn, *dtout, *gpad, *xpad;
+  uint8_t* valid;
+};
+static int carve_feat_bwd(FeatWs& b, void* ws, size_t ws_bytes, int M, int dynamic) {
+  WsCarver c(ws, ws_bytes);
+  const size_t t = ((size_t)M + 31) / 32, mp = t * 32;
+  b.pk = c.take<float>(PACK_AREA_FLOATS);
+  b.grows3 = c.take<float>(t * sv::K3G_ROWS * 32);
+  b.grows1 = dynamic ? c.take<float>(t * sv::K1G_ROWS * 32) : nullptr;
+  b.dxw = dynamic ? c.take<float>(mp * 3) : nullptr;
+  b.dxn = dynamic ? c.take<float>(mp * 3) : nullptr;
+  b.dtout = dynamic ? c.take<float>(mp * 32) : nullptr;
+  b.gpad = dynamic ? nullptr : c.take<float>(mp);
+  b.xpad = dynamic ? nullptr : c.take<float>(mp * 3);
+  b.valid = c.take<uint8_t>(mp);
+  RDRF_CHECK(c.ok(), -3, "features backward: workspace too small: need %zu have %zu", c.off, ws_bytes);
+  return 0;
+}
+extern "C" size_t rdrf_features_bwd_workspace_bytes(int M) {
+  const size_t t = ((size_t)M + 31) / 32, mp = t * 32;
+  return (size_t)PACK_AREA_FLOATS * 4 + t * (sv::K3G_ROWS + sv::K1G_ROWS) * 32 * 4 + mp * (6 + 32 + 4) * 4 + mp +
+         (1 << 14);
+}
+
+extern "C" int rdrf_static_features_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* xn,
+                                        int M, const float* g_density, const float* g_app,
+                                        const RdrfStaticParams* G, float* g_xn, void* saved, size_t saved_bytes,
+                                        void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && G && xn && M > 0 && (g_density || g_app), -1, "static_features_bwd: bad arguments");
+  RDRF_CHECK(g_app == nullptr || saved != nullptr, -1, "static_features_bwd: the appearance features need the "
+             "saved buffer of their forward call");
+  const int Np = (M + 31) / 32;
+  const size_t mp = (size_t)Np * 32;
+  FeatWs b;
+  int rc = carve_feat_bwd(b, ws, ws_bytes, M, 0);
+  if (rc) return rc;
+  BwdArgs a;
+  fill_bwd_common(a, cfg, nullptr, nullptr, xn, nullptr, b.valid, Np, 32);
+  a.M = M; a.in_norm = 1; a.g_feat = g_app; a.pk = b.pk; a.grows3 = b.grows3;
+  if (saved != nullptr)
+    RDRF_CHECK(carve_saved_feat(a.sp, saved, saved_bytes, 0, M), -3, "static_features_bwd: saved buffer too small");
+  RDRF_HIP(hipMemsetAsync(b.valid, 0, mp, stream));
+  RDRF_HIP(hipMemsetAsync(b.valid, 1, (size_t)M, stream));
+  RDRF_HIP(hipMemsetAsync(b.xpad, 0, mp * 3 * 4, stream));
+  RDRF_HIP(hipMemcpyAsync(b.xpad, xn, (size_t)M * 3 * 4, hipMemcpyDeviceToDevice, stream));
+  ScatterArgs sa0;
+  fill_scatter_common(sa0, a);
+  sa0.xw = b.xpad;                       // already normalised
+  sa0.box.inv[0] = sa0.box.inv[1] = sa0.box.inv[2] = 1.0f;   // g_xn is the gradient wrt the normalised input
+  sa0.g_xyz = g_xn;
+  if (g_density != nullptr) {            // the feature is the plain sum of the 24 products: broadcast rows
+    RDRF_HIP(hipMemsetAsync(b.gpad, 0, mp * 4, stream));
+    RDRF_HIP(hipMemcpyAsync(b.gpad, g_density, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+    ScatterArgs sa = sa0;
+    sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.nsets = 1;
+    sa.rows = b.gpad; sa.stride = 1; sa.row0[0] = 0; sa.bcast = 1;
+    { int rc_ = launch_scatter("feat_scatter_static_density", k_scatter<4, 1, 3>, sa, (long)Np, stream); if (rc_) return rc_; }
+  }
+  if (g_app != nullptr) {
+    StaticW w;
+    fill_static_w(w, P);
+    StaticG gw;
+    gw.density = G->density; gw.app = G->app; gw.b3 = G->b3; gw.w3 = G->w3;
+    PackJobs J;
+    static_pack_jobs_bwd(J, P, cfg->static_head);
+    rc = pack_launch(J, b.pk, stream);
+    if (rc) return rc;
+    const Geo g = geo_for_units(Np);
+    RDRF_LAUNCH("feat_static_app_bwd", (k_static_app_bwd<RDRF_HEAD_MLP_FEA, true>), dim3(g.grid), dim3(g.block),
+                stream, a, w, gw);
+    ScatterArgs sa = sa0;
+    sa.vm[0] = P->app; sa.gvm[0] = G->app; sa.nsets = 1;
+    sa.rows = b.grows3; sa.stride = sv::K3G_ROWS; sa.row0[0] = sv::K3G_DA;
+    { int rc_ = launch_scatter("feat_scatter_static_app", k_scatter<12, 3, 9>, sa, (long)Np, stream); if (rc_) return rc_; }
+    DwJobs D;
+    D.n = 0;
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DF, 1, 27, 0, a.sp.act3, sv::S3_ROWS, 72, 72, G->basis, nullptr,
+           nullptr, Np);
+    for (int i = 0; i < 3; ++i) dw_blk(D, sv::S3_G + 32 * i, SEG_IDENT, 32 * i);
+    rc = dw_launch(D, stream, "feat_dw_static");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* x,
+                                         const float* t, int M, int x_is_normalized, const float* g_density,
+                                         const float* g_blending, const float* g_app, const float* g_xyz_prime,
+                                         const RdrfDynamicParams* G, float* g_x, void* saved, size_t saved_bytes,
+                                         void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && G && x && t && saved && M > 0 && (g_density || g_blending || g_app || g_xyz_prime), -1,
+             "dynamic_features_bwd: bad arguments");
+  const int Np = (M + 31) / 32;
+  const size_t mp = (size_t)Np * 32;
+  FeatWs b;
+  int rc = carve_feat_bwd(b, ws, ws_bytes, M, 1);
+  if (rc) return rc;
+  BwdArgs a;
+  fill_bwd_common(a, cfg, nullptr, t, x, nullptr, b.valid, Np, 32);
+  a.M = M; a.in_norm = x_is_normalized ? 1 : 0;
+  a.g_sigma = g_density; a.g_blending = g_blending; a.g_feat = g_app; a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_x;
+  RDRF_CHECK(carve_saved_feat(a.sp, saved, saved_bytes, 1, M), -3, "dynamic_features_bwd: saved buffer too small");
+  a.pk = b.pk; a.grows1 = b.grows1; a.grows3 = b.grows3; a.dxw_app = b.dxw; a.dxn_app = b.dxn; a.dtout = b.dtout;
+  DynW w;
+  fill_dyn_w(w, P);
+  DynG gw;
+  gw.density = G->density; gw.blending = G->blending; gw.app = G->app;
+  gw.rbv = G->rbv; gw.rwv = G->rwv; gw.l5b = G->l5b; gw.db2 = G->db2; gw.bb2 = G->bb2;
+  PackJobs J;
+  dyn_pack_jobs_bwd(J, P);
+  rc = pack_launch(J, b.pk, stream);
+  if (rc) return rc;
+  RDRF_HIP(hipMemsetAsync(b.valid, 0, mp, stream));
+  RDRF_HIP(hipMemsetAsync(b.valid, 1, (size_t)M, stream));
+  RDRF_HIP(hipMemsetAsync(b.dxw, 0, mp * 3 * 4, stream));
+  RDRF_HIP(hipMemsetAsync(b.dxn, 0, mp * 3 * 4, stream));
+  const Geo g = geo_for_units(Np);
+  DwJobs D;
+  D.n = 0;
+  if (g_app != nullptr) {
+    RDRF_LAUNCH("feat_dyn_app_bwd", k_dyn_app_bwd<true>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    ScatterArgs sa;
+    fill_scatter_common(sa, a);
+    sa.vm[0] = P->app; sa.gvm[0] = G->app; sa.nsets = 1;
+    sa.rows = b.grows3; sa.stride = sv::K3G_ROWS; sa.row0[0] = sv::K3G_DA;
+    sa.xw = a.sp.xw;
+    sa.dxw = b.dxw; sa.dxw_accumulate = 0;
+    { int rc_ = launch_scatter("feat_scatter_dyn_app", k_scatter<12, 3, 27>, sa, (long)Np, stream); if (rc_) return rc_; }
+    dw_add(D, b.grows3, sv::K3G_ROWS, sv::K3G_DF, 1, 27, 0, a.sp.act3, sv::K3_ROWS, 216, 216, G->basis, nullptr,
+           nullptr, Np);
+    for (int i = 0; i < 7; ++i) dw_blk(D, sv::K3_A + 32 * i, SEG_IDENT, 32 * i);
+  }
+  RDRF_LAUNCH("feat_dyn_heads_bwd", (k_dyn_density_bwd<0, true>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
+  if (g_density != nullptr || g_blending != nullptr) {
+    ScatterArgs sa;
+    fill_scatter_common(sa, a);
+    sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;
+    sa.nsets = 2;
+    sa.rows = b.grows1; sa.stride = sv::K1G_ROWS; sa.row0[0] = sv::K1G_DFD; sa.row0[1] = sv::K1G_DFB;
+    sa.xw = a.sp.xw;
+    sa.dxw = b.dxw; sa.dxw_accumulate = 1;
+    { int rc_ = launch_scatter("feat_scatter_dyn_density", k_scatter<4, 1, 9>, sa, (long)Np, stream); if (rc_) return rc_; }
+  }
+  RDRF_LAUNCH("feat_dyn_warp_bwd", (k_dyn_density_bwd<1, true>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
+  RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((M + TB_RPB - 1) / TB_RPB), dim3(128), stream, t, w, M,
+              b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
+  add_density_phase_dw(D, b.grows1, a.sp.act1, G, Np);
+  return dw_launch(D, stream, "feat_dw_dyn");
 }
 
 extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg,

@@ -14,23 +14,30 @@
 // ------------------------------------------------------------------------------------------------
 // static field, density phase: one wave per ray, one lane per sample (64 per step)
 // ------------------------------------------------------------------------------------------------
+template <bool FEAT>
 __global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
   const int lane = threadIdx.x;
   const int n = blockIdx.x;
   if (n >= a.N) return;
   float vx, vy, vz;
-  const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float nrm = 1.0f;
+  if constexpr (!FEAT) nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
   float carry = 1.0f;
   for (int j0 = 0; j0 < a.S; j0 += 64) {
     const int j = j0 + lane;
-    const bool act = j < a.S;
+    const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
     const int idx = n * a.S + (act ? j : 0);
-    const bool vld = act && a.valid[idx] != 0;
+    const bool vld = act && (FEAT || a.valid[idx] != 0);
     float f = 0.0f;
     if (vld) {
-      const float x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
-      const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
-      const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+      float x0, x1, x2;
+      if (FEAT && a.in_norm) {
+        x0 = a.xyz[idx * 3 + 0]; x1 = a.xyz[idx * 3 + 1]; x2 = a.xyz[idx * 3 + 2];
+      } else {
+        x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+        x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+        x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+      }
 #pragma unroll
       for (int pi = 0; pi < 3; ++pi) {  // quads 0..3 plane 0, 4 plane 1, 5 plane 2
         float sp = 0.f;
@@ -42,31 +49,35 @@ __global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
         f += sp;
       }
     }
-    const float sigma = vld ? density_act(f, a.act, a.density_shift) : 0.0f;
     if (a.raw != nullptr && act) a.raw[idx] = f;
-    const float zj = act ? a.z[idx] : 0.f;
-    const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
-    const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
-    const float alpha = 1.0f - expf(-sigma * ds);
-    const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
-    const float incl = scan_mul64(p, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0f;
-    const float T = carry * excl;
-    const float wt = alpha * T;
-    carry *= __shfl(incl, 63, 64);
-    const bool m = act && wt > a.weight_thres;
-    if (act) {
-      a.sigma[idx] = sigma;
-      a.weight[idx] = wt;
-      a.dists[idx] = ds;
-    }
-    const unsigned long long bal = __ballot(m);
-    if (bal) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
-      base = __shfl(base, 0, 64);
-      if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+    if constexpr (FEAT) {  // compute_densityfeature: the raw feature (models/tensoRF.py:118-154)
+      if (act && a.sigma != nullptr) a.sigma[idx] = f;
+    } else {
+      const float sigma = vld ? density_act(f, a.act, a.density_shift) : 0.0f;
+      const float zj = act ? a.z[idx] : 0.f;
+      const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+      const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+      const float alpha = 1.0f - expf(-sigma * ds);
+      const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+      const float incl = scan_mul64(p, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.0f;
+      const float T = carry * excl;
+      const float wt = alpha * T;
+      carry *= __shfl(incl, 63, 64);
+      const bool m = act && wt > a.weight_thres;
+      if (act) {
+        a.sigma[idx] = sigma;
+        a.weight[idx] = wt;
+        a.dists[idx] = ds;
+      }
+      const unsigned long long bal = __ballot(m);
+      if (bal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+      }
     }
   }
 }
@@ -74,26 +85,31 @@ __global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
 // ------------------------------------------------------------------------------------------------
 // static field, appearance phase: 32-sample MFMA tiles over the compacted list
 // ------------------------------------------------------------------------------------------------
-template <int HEAD>
+template <int HEAD, bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, StaticW w) {
   __shared__ __attribute__((aligned(16))) float lds[pk::S3_SIZE];
   lds_fill(lds, a.pk + pk::REG_S3, pk::S3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int count = *a.counter;
+  const int count = FEAT ? a.M : *a.counter;
   const int ntiles = (count + 31) >> 5;
   const float* pkw = lds;
   for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
     const int li = tile * 32 + s;
     const bool act = li < count;
-    const int idx = act ? a.list[li] : 0;
+    const int idx = act ? (FEAT ? li : a.list[li]) : 0;
     const int n = idx / a.S;
     float* svb = a.act3 ? a.act3 + (size_t)tile * sv::S3_ROWS * 32 : nullptr;
-    float vx, vy, vz;
-    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-    const float x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
-    const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
-    const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if constexpr (!FEAT) ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    float x0, x1, x2;
+    if (FEAT && a.in_norm) {
+      x0 = a.xyz[idx * 3 + 0]; x1 = a.xyz[idx * 3 + 1]; x2 = a.xyz[idx * 3 + 2];
+    } else {
+      x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    }
     float G[36];
 #pragma unroll
     for (int o = 0; o < 9; ++o) {
@@ -106,6 +122,15 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, Stat
     mfma_seg<1, 36>(accF, G, pkw + pk::S3_BASIS, lane);
     float F[16];
     acc_copy<1>(F, accF);
+    if constexpr (FEAT) {  // compute_appfeature: basis_mat output (models/tensoRF.py:156-196)
+      save_rows<36>(svb, sv::S3_G, G, s, h);
+      if (act) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+          if (elem_of(kk, h) < 27) a.feat[(size_t)idx * 27 + elem_of(kk, h)] = F[kk];
+      }
+      continue;
+    }
     float P[64];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(256) void k_time_branch(const float* __restrict__ t
 // ------------------------------------------------------------------------------------------------
 // dynamic field, density/blending phase: one wave per ray, tiles of 32 samples, 2 lanes / sample
 // ------------------------------------------------------------------------------------------------
+template <bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, DynW w) {
   __shared__ __attribute__((aligned(16))) float lds[pk::K1_SIZE];
   lds_fill(lds, a.pk + pk::REG_K1, pk::K1_SIZE);
@@ -190,27 +216,40 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const float* pkw = lds;
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
-  const float t = a.ts[n];
-  float vx, vy, vz;
-  const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float t = 0.f, nrm = 1.0f;
   float T[16];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 v = ld4(a.tout + n * 32 + 8 * q + 4 * h);
-    T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
-  }
   float X1[8];
-  fill_x1(X1, t, h);
+  if constexpr (!FEAT) {   // time is per ray: tout / PE8(t) are per-ray constants
+    t = a.ts[n];
+    float vx, vy, vz;
+    nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = ld4(a.tout + n * 32 + 8 * q + 4 * h);
+      T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
+    }
+    fill_x1(X1, t, h);
+  }
   float carry = 1.0f;
   for (int j0 = 0; j0 < a.S; j0 += 32) {
     const int j = j0 + s;
-    const bool act = j < a.S;
+    const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
     const int idx = n * a.S + (act ? j : 0);
-    const bool vld = act && a.valid[idx] != 0;
+    const bool vld = act && (FEAT || a.valid[idx] != 0);
+    if constexpr (FEAT) {  // time is per point
+      t = a.ts[idx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = ld4(a.tout + (size_t)idx * 32 + 8 * q + 4 * h);
+        T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
+      }
+      fill_x1(X1, t, h);
+    }
     const float px = a.xyz[idx * 3 + 0], py = a.xyz[idx * 3 + 1], pz = a.xyz[idx * 3 + 2];
-    const float xn0 = norm_c(px, a.box.lo[0], a.box.inv[0]);
-    const float xn1 = norm_c(py, a.box.lo[1], a.box.inv[1]);
-    const float xn2 = norm_c(pz, a.box.lo[2], a.box.inv[2]);
+    const bool raw_in = FEAT && a.in_norm;   // compute_*: the caller hands normalised coordinates
+    const float xn0 = raw_in ? px : norm_c(px, a.box.lo[0], a.box.inv[0]);
+    const float xn1 = raw_in ? py : norm_c(py, a.box.lo[1], a.box.inv[1]);
+    const float xn2 = raw_in ? pz : norm_c(pz, a.box.lo[2], a.box.inv[2]);
     float X0[32];
     fill_x0(X0, xn0, xn1, xn2, t, h);
     float* svb = a.act1 ? a.act1 + ((size_t)n * ((a.S + 31) >> 5) + (j0 >> 5)) * sv::K1_ROWS * 32 : nullptr;
@@ -240,9 +279,11 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
     const float xw1 = norm_c(unnorm_c(xn1, a.box.lo[1], a.box.inv[1]) + d1, a.box.lo[1], a.box.inv[1]);
     const float xw2 = norm_c(unnorm_c(xn2, a.box.lo[2], a.box.inv[2]) + d2, a.box.lo[2], a.box.inv[2]);
     if (act && h == 0) {
-      a.xyz_prime[(size_t)idx * 3 + 0] = px + d0;
-      a.xyz_prime[(size_t)idx * 3 + 1] = py + d1;
-      a.xyz_prime[(size_t)idx * 3 + 2] = pz + d2;
+      if (!FEAT || a.xyz_prime != nullptr) {
+        a.xyz_prime[(size_t)idx * 3 + 0] = (raw_in ? unnorm_c(xn0, a.box.lo[0], a.box.inv[0]) : px) + d0;
+        a.xyz_prime[(size_t)idx * 3 + 1] = (raw_in ? unnorm_c(xn1, a.box.lo[1], a.box.inv[1]) : py) + d1;
+        a.xyz_prime[(size_t)idx * 3 + 2] = (raw_in ? unnorm_c(xn2, a.box.lo[2], a.box.inv[2]) : pz) + d2;
+      }
       a.xw[(size_t)idx * 3 + 0] = xw0;
       a.xw[(size_t)idx * 3 + 1] = xw1;
       a.xw[(size_t)idx * 3 + 2] = xw2;
@@ -287,6 +328,13 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
       save_rows<32>(svb, sv::K1_HB, Hd, s, h);
       fb = dot_small<32>(Hd, pkw + pk::K1_BLE2, h) + w.bb2[0];
     }
+    if constexpr (FEAT) {  // compute_densityfeature / compute_blendingfeature: the raw head outputs
+      if (act && h == 0) {
+        if (a.sigma != nullptr) a.sigma[idx] = fd;
+        if (a.blending != nullptr) a.blending[idx] = fb;
+        if (a.raw != nullptr) { a.raw[(size_t)idx * 2] = fd; a.raw[(size_t)idx * 2 + 1] = fb; }
+      }
+    } else {
     const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.0f;
     const float blend = vld ? sigmoidf_(fb) : 0.0f;
     const float zj = act ? a.z[idx] : 0.f;
@@ -315,6 +363,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
       base = __shfl(base, 0, 64);
       if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
     }
+    }
   }
   }  // ray loop
 }
@@ -322,26 +371,30 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
 // ------------------------------------------------------------------------------------------------
 // dynamic field, appearance phase (models/tensoRF.py:734-811 + MLPRender_Fea_late_view)
 // ------------------------------------------------------------------------------------------------
+template <bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app(FieldArgs a, DynW w) {
   __shared__ __attribute__((aligned(16))) float lds[pk::K3_SIZE];
   lds_fill(lds, a.pk + pk::REG_K3, pk::K3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int count = *a.counter;
+  const int count = FEAT ? a.M : *a.counter;
   const int ntiles = (count + 31) >> 5;
   const float* pkw = lds;
   for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
     const int li = tile * 32 + s;
     const bool act = li < count;
-    const int idx = act ? a.list[li] : 0;
+    const int idx = act ? (FEAT ? li : a.list[li]) : 0;
     const int n = idx / a.S;
-    const float t = a.ts[n];
+    const float t = FEAT ? 0.f : a.ts[n];
     float* svb = a.act3 ? a.act3 + (size_t)tile * sv::K3_ROWS * 32 : nullptr;
-    float vx, vy, vz;
-    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
-    const float xn0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
-    const float xn1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
-    const float xn2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    float xn0 = 0.f, xn1 = 0.f, xn2 = 0.f;
+    if constexpr (!FEAT) {
+      ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+      xn0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      xn1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      xn2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    }
     const float xw0 = a.xw[(size_t)idx * 3 + 0], xw1 = a.xw[(size_t)idx * 3 + 1],
                 xw2 = a.xw[(size_t)idx * 3 + 2];
     float F[16];
@@ -358,6 +411,14 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app(FieldArgs a, DynW w)
       mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
       acc_copy<1>(F, accF);
       save_rows<108>(svb, sv::K3_A, A, s, h);
+    }
+    if constexpr (FEAT) {  // compute_appfeature: basis_mat output (models/tensoRF.py:734-811)
+      if (act) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+          if (elem_of(kk, h) < 27) a.feat[(size_t)idx * 27 + elem_of(kk, h)] = F[kk];
+      }
+      continue;
     }
     float X0[32], X1[8];
     fill_x0(X0, xn0, xn1, xn2, t, h);
@@ -620,13 +681,13 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   if (rc) return rc;
   RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
   RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
-  RDRF_LAUNCH("static_density", k_static_density, dim3(N), dim3(64), stream, a, w);
+  RDRF_LAUNCH("static_density", k_static_density<false>, dim3(N), dim3(64), stream, a, w);
   const Geo g = geo_for_tiles(N, S);
   if (cfg->static_head == RDRF_HEAD_MLP_FEA)
-    RDRF_LAUNCH("static_app", k_static_app<RDRF_HEAD_MLP_FEA>, dim3(g.grid), dim3(g.block), stream,
+    RDRF_LAUNCH("static_app", (k_static_app<RDRF_HEAD_MLP_FEA, false>), dim3(g.grid), dim3(g.block), stream,
                 a, w);
   else
-    RDRF_LAUNCH("static_app", k_static_app<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING>, dim3(g.grid),
+    RDRF_LAUNCH("static_app", (k_static_app<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING, false>), dim3(g.grid),
                 dim3(g.block), stream, a, w);
   return 0;
 }
@@ -657,8 +718,95 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
   RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout);
   const Geo g1 = geo_for_units(N), g3 = geo_for_tiles(N, S);
-  RDRF_LAUNCH("dyn_density", k_dyn_density, dim3(g1.grid), dim3(g1.block), stream, a, w);
-  RDRF_LAUNCH("dyn_app", k_dyn_app, dim3(g3.grid), dim3(g3.block), stream, a, w);
+  RDRF_LAUNCH("dyn_density", k_dyn_density<false>, dim3(g1.grid), dim3(g1.block), stream, a, w);
+  RDRF_LAUNCH("dyn_app", k_dyn_app<false>, dim3(g3.grid), dim3(g3.block), stream, a, w);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature mode: compute_densityfeature / compute_appfeature / compute_blendingfeature /
+// warp_coordinate on a batch of M independent points (models/tensoRF.py:118-196, 521-811).  The same
+// kernels in pseudo-ray geometry: N = ceil(M/32) rays of 32 samples, time per point.
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t rdrf_features_saved_bytes(int dynamic, int M) { return saved_bytes_feat(dynamic, M); }
+extern "C" size_t rdrf_features_workspace_bytes(int M) {
+  const int Np = (M + 31) / 32;
+  return rdrf_workspace_bytes(Np, 32) + (size_t)Np * 32 * (32 * 4 + 27 * 4 + 8) + (1 << 14);
+}
+
+static int feat_carve_fwd(FieldArgs& a, void* ws, size_t ws_bytes, int M, void* saved, size_t saved_bytes,
+                          int dynamic) {
+  WsCarver c(ws, ws_bytes);
+  const size_t mp = ((size_t)M + 31) / 32 * 32;
+  a.pk = c.take<float>(PACK_AREA_FLOATS);
+  a.tout = c.take<float>(mp * 32);
+  a.xw = c.take<float>(mp * 3);
+  RDRF_CHECK(c.ok(), -3, "features: workspace too small: need %zu have %zu", c.off, ws_bytes);
+  if (saved != nullptr) {
+    SavedPtrs sp;
+    RDRF_CHECK(carve_saved_feat(sp, saved, saved_bytes, dynamic, M), -3,
+               "features: saved buffer too small: need %zu have %zu", saved_bytes_feat(dynamic, M), saved_bytes);
+    a.xw = sp.xw; a.tout = sp.tout; a.raw = sp.raw; a.act1 = sp.act1; a.act3 = sp.act3;
+  }
+  return 0;
+}
+
+extern "C" int rdrf_static_features_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* xn,
+                                        int M, float* density, float* app, void* saved, size_t saved_bytes,
+                                        void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && xn && M > 0 && (density || app), -1, "static_features_fwd: bad arguments");
+  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
+             "static_features_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+  const int Np = (M + 31) / 32;
+  FieldArgs a;
+  fill_common(a, cfg, nullptr, nullptr, xn, nullptr, nullptr, Np, 32);
+  a.M = M; a.in_norm = 1; a.sigma = density; a.feat = app;
+  int rc = feat_carve_fwd(a, ws, ws_bytes, M, saved, saved_bytes, 0);
+  if (rc) return rc;
+  StaticW w;
+  fill_static_w(w, P);
+  if (density != nullptr)
+    RDRF_LAUNCH("feat_static_density", k_static_density<true>, dim3(Np), dim3(64), stream, a, w);
+  if (app != nullptr) {
+    PackJobs J;
+    static_pack_jobs_fwd(J, P, cfg->static_head);
+    rc = pack_launch(J, (float*)a.pk, stream);
+    if (rc) return rc;
+    const Geo g = geo_for_units(Np);
+    RDRF_LAUNCH("feat_static_app", (k_static_app<RDRF_HEAD_MLP_FEA, true>), dim3(g.grid), dim3(g.block), stream,
+                a, w);
+  }
+  return 0;
+}
+
+extern "C" int rdrf_dynamic_features_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, const float* x,
+                                         const float* t, int M, int x_is_normalized, float* density,
+                                         float* blending, float* app, float* xyz_prime, void* saved,
+                                         size_t saved_bytes, void* ws, size_t ws_bytes,
+                                         rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(P && cfg && x && t && M > 0 && (density || blending || app || xyz_prime), -1,
+             "dynamic_features_fwd: bad arguments");
+  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
+             "dynamic_features_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+  const int Np = (M + 31) / 32;
+  FieldArgs a;
+  fill_common(a, cfg, nullptr, t, x, nullptr, nullptr, Np, 32);
+  a.M = M; a.in_norm = x_is_normalized ? 1 : 0;
+  a.sigma = density; a.blending = blending; a.feat = app; a.xyz_prime = xyz_prime;
+  int rc = feat_carve_fwd(a, ws, ws_bytes, M, saved, saved_bytes, 1);
+  if (rc) return rc;
+  DynW w;
+  fill_dyn_w(w, P);
+  PackJobs J;
+  dyn_pack_jobs_fwd(J, P);
+  rc = pack_launch(J, (float*)a.pk, stream);
+  if (rc) return rc;
+  RDRF_LAUNCH("time_branch", k_time_branch, dim3((M + 7) / 8), dim3(256), stream, t, w, M, a.tout);
+  const Geo g = geo_for_units(Np);
+  RDRF_LAUNCH("feat_dyn_density", k_dyn_density<true>, dim3(g.grid), dim3(g.block), stream, a, w);
+  if (app != nullptr) RDRF_LAUNCH("feat_dyn_app", k_dyn_app<true>, dim3(g.grid), dim3(g.block), stream, a, w);
   return 0;
 }
 

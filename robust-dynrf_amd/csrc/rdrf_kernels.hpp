@@ -27,6 +27,12 @@ struct FieldArgs {
   float* act1;
   float* act3;
   float* raw;
+  // feature mode (the compute_* / warp_coordinate entry points, template parameter FEAT of the field
+  // kernels): the batch is M independent points in pseudo-ray geometry -- N = ceil(M/32) "rays" of
+  // S = 32 "samples", idx = point id -- `ts` is indexed PER POINT and every point is live.
+  int M;         // number of points
+  int in_norm;   // 1: `xyz` holds NORMALISED coordinates (compute_*), 0: un-normalised (warp_coordinate)
+  float* feat;   // [M][27] appearance features (basis_mat output) or nullptr
 };
 
 struct StaticW {
@@ -122,6 +128,27 @@ struct SavedPtrs {
   float* act3;     // appearance-phase rows: [ceil(N*S/32)][K3_ROWS|S3_ROWS][32]
 };
 
+// feature mode (rdrf_*_features_*): M points, Mp = 32 * ceil(M/32); per-point time branch
+static inline size_t saved_bytes_feat(int dynamic, int M) {
+  size_t t = ((size_t)M + 31) / 32, mp = t * 32;
+  size_t b = sizeof(SavedHdr) + 256;
+  b += mp * 3 * 4 + 256 + mp * 32 * 4 + 256 + mp * 2 * 4 + 256;   // xw, tout, raw
+  if (dynamic) b += t * sv::K1_ROWS * 32 * 4 + 256;
+  b += t * (dynamic ? sv::K3_ROWS : sv::S3_ROWS) * 32 * 4 + 256;
+  return b;
+}
+static inline bool carve_saved_feat(SavedPtrs& p, void* saved, size_t bytes, int dynamic, int M) {
+  WsCarver c(saved, bytes);
+  size_t t = ((size_t)M + 31) / 32, mp = t * 32;
+  p.hdr = c.take<SavedHdr>(1);
+  p.list = nullptr;
+  p.xw = c.take<float>(mp * 3);
+  p.tout = c.take<float>(mp * 32);
+  p.raw = c.take<float>(mp * 2);
+  p.act1 = dynamic ? c.take<float>(t * sv::K1_ROWS * 32) : nullptr;
+  p.act3 = c.take<float>(t * (dynamic ? sv::K3_ROWS : sv::S3_ROWS) * 32);
+  return c.ok();
+}
 static inline size_t saved_bytes_field(int dynamic, int N, int S) {
   size_t ns = (size_t)N * S, t1 = (size_t)N * ((S + 31) / 32), t3 = (ns + 31) / 32;
   size_t b = sizeof(SavedHdr) + 256;

@@ -65,12 +65,17 @@ extern "C" int rdrf_generate_rays(const int64_t* ids, const float* poses9, const
 // ------------------------------------------------------------------------------------------------
 // samplers
 // ------------------------------------------------------------------------------------------------
-RDRF_D float linspace_at(float start, float end, int steps, int i) {  // ATen linspace, fp32
+// ATen's CPU linspace (aten/src/ATen/native/cpu/RangeFactoriesKernel.cpp), fp32, as the shipped torch
+// binaries compute it: step = (end - start) / (steps - 1); element i is start + step * i in the first
+// half and end - step * (steps - i - 1) in the second, and GCC contracts each multiply-add into ONE
+// fused operation (checked bit-for-bit against torch.linspace over many (start, end, steps),
+// tests/test_oracle_golden.py::test_linspace_formula).  The `valid` byte mask depends on these bits.
+RDRF_D float linspace_at(float start, float end, int steps, int i) {
 #pragma clang fp contract(off)
   if (steps <= 1) return start;
   const float step = (end - start) / (float)(steps - 1);
-  if (i < steps / 2) return start + step * (float)i;
-  return end - step * (float)(steps - i - 1);
+  if (i < steps / 2) return __builtin_fmaf(step, (float)i, start);
+  return __builtin_fmaf(-step, (float)(steps - i - 1), end);
 }
 
 __global__ void k_sample_ndc(const float* __restrict__ rays, int N, int S, float near, float far,

@@ -340,6 +340,119 @@ class _SceneFlowFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------
+# compute_* / warp_coordinate: the per-point building blocks (rdrf_*_features_fwd/bwd)
+# --------------------------------------------------------------------------------------------
+def _feat_saved(ctx, dynamic, M, dev):
+    if not any(ctx.needs_input_grad):
+        return None, 0
+    nbytes = int(L.lib.rdrf_features_saved_bytes(int(dynamic), M))
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
+class _StaticFeatFn(torch.autograd.Function):
+    """(density feature [M], appearance feature [M,27]) of the static field at normalised points"""
+
+    @staticmethod
+    def forward(ctx, field, want_density, want_app, xn, *params):
+        ctx.set_materialize_grads(False)
+        L.require_device(xn)
+        xn = L.f32c(xn)
+        M, dev = xn.shape[0], xn.device
+        dens = torch.empty(M, device=dev) if want_density else None
+        app = torch.empty(M, 27, device=dev) if want_app else None
+        ws = L.workspace(dev, L.lib.rdrf_features_workspace_bytes(M))
+        saved, sbytes = _feat_saved(ctx, 0, M, dev)
+        P = _static_struct(params)
+        cfg = _cfg_struct(field, "ndc")
+        L.check(L.lib.rdrf_static_features_fwd(C.byref(P), C.byref(cfg), L.ptr(xn), M, L.ptr(dens), L.ptr(app),
+                                               L.ptr(saved), C.c_size_t(sbytes), L.ptr(ws),
+                                               C.c_size_t(ws.numel()), L.stream_of(xn)),
+                "rdrf_static_features_fwd")
+        ctx.field, ctx.saved = field, saved
+        ctx.save_for_backward(xn, *params)
+        return dens, app
+
+    @staticmethod
+    def backward(ctx, g_dens, g_app):
+        xn, *params = ctx.saved_tensors
+        if ctx.saved is None:
+            raise L.RdrfError("compute_*: backward called twice (the saved activations were released)")
+        M, dev = xn.shape[0], xn.device
+        fused = ctx.field.fused_grad
+        grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
+        if g_dens is None and g_app is None:
+            return (None,) * (4 + len(params))
+        G, P = _static_struct(grads), _static_struct(params)
+        cfg = _cfg_struct(ctx.field, "ndc")
+        g_xn = torch.zeros_like(xn) if ctx.needs_input_grad[3] else None
+        g_dens = None if g_dens is None else L.f32c(g_dens)
+        g_app = None if g_app is None else L.f32c(g_app)
+        ws = L.workspace(dev, L.lib.rdrf_features_bwd_workspace_bytes(M))
+        L.check(L.lib.rdrf_static_features_bwd(C.byref(P), C.byref(cfg), L.ptr(xn), M, L.ptr(g_dens),
+                                               L.ptr(g_app), C.byref(G), L.ptr(g_xn), L.ptr(ctx.saved),
+                                               C.c_size_t(ctx.saved.numel()), L.ptr(ws), C.c_size_t(ws.numel()),
+                                               L.stream_of(xn)), "rdrf_static_features_bwd")
+        ctx.saved = None
+        if fused:
+            grads = [None] * len(params)
+        return (None, None, None, g_xn, *grads)
+
+
+class _DynFeatFn(torch.autograd.Function):
+    """(density [M], blending [M], app [M,27], xyz_prime [M,3]) of the dynamic field at M points with
+    per-point times; `x` normalised (compute_*) or un-normalised (warp_coordinate)"""
+
+    @staticmethod
+    def forward(ctx, field, want, x_is_normalized, x, t, *params):
+        ctx.set_materialize_grads(False)
+        L.require_device(x, t)
+        x, t = L.f32c(x), L.f32c(t)
+        M, dev = x.shape[0], x.device
+        dens = torch.empty(M, device=dev) if "density" in want else None
+        blend = torch.empty(M, device=dev) if "blending" in want else None
+        app = torch.empty(M, 27, device=dev) if "app" in want else None
+        xp = torch.empty(M, 3, device=dev) if "warp" in want else None
+        ws = L.workspace(dev, L.lib.rdrf_features_workspace_bytes(M))
+        saved, sbytes = _feat_saved(ctx, 1, M, dev)
+        P = _dynamic_struct(params)
+        cfg = _cfg_struct(field, "ndc")
+        L.check(L.lib.rdrf_dynamic_features_fwd(C.byref(P), C.byref(cfg), L.ptr(x), L.ptr(t), M,
+                                                int(x_is_normalized), L.ptr(dens), L.ptr(blend), L.ptr(app),
+                                                L.ptr(xp), L.ptr(saved), C.c_size_t(sbytes), L.ptr(ws),
+                                                C.c_size_t(ws.numel()), L.stream_of(x)),
+                "rdrf_dynamic_features_fwd")
+        ctx.field, ctx.saved, ctx.norm = field, saved, int(x_is_normalized)
+        ctx.save_for_backward(x, t, *params)
+        return dens, blend, app, xp
+
+    @staticmethod
+    def backward(ctx, g_dens, g_blend, g_app, g_xp):
+        x, t, *params = ctx.saved_tensors
+        if all(g is None for g in (g_dens, g_blend, g_app, g_xp)):
+            return (None,) * (5 + len(params))
+        if ctx.saved is None:
+            raise L.RdrfError("compute_*: backward called twice (the saved activations were released)")
+        M, dev = x.shape[0], x.device
+        fused = ctx.field.fused_grad
+        grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
+        G, P = _dynamic_struct(grads), _dynamic_struct(params)
+        cfg = _cfg_struct(ctx.field, "ndc")
+        g_x = torch.zeros_like(x) if ctx.needs_input_grad[3] else None
+        c = lambda g: None if g is None else L.f32c(g)
+        g_dens, g_blend, g_app, g_xp = c(g_dens), c(g_blend), c(g_app), c(g_xp)
+        ws = L.workspace(dev, L.lib.rdrf_features_bwd_workspace_bytes(M))
+        L.check(L.lib.rdrf_dynamic_features_bwd(C.byref(P), C.byref(cfg), L.ptr(x), L.ptr(t), M, ctx.norm,
+                                                L.ptr(g_dens), L.ptr(g_blend), L.ptr(g_app), L.ptr(g_xp),
+                                                C.byref(G), L.ptr(g_x), L.ptr(ctx.saved),
+                                                C.c_size_t(ctx.saved.numel()), L.ptr(ws), C.c_size_t(ws.numel()),
+                                                L.stream_of(x)), "rdrf_dynamic_features_bwd")
+        ctx.saved = None
+        if fused:
+            grads = [None] * len(params)
+        return (None, None, None, g_x, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------
 # TensorBase (models/tensorBase.py:281-559)
 # --------------------------------------------------------------------------------------------
 class TensorBase(nn.Module):
@@ -563,6 +676,17 @@ class TensorVMSplit(TensorBase):
     def warp_coordinate(self, xyz_sampled, t_sampled):
         return None
 
+    # ---- models/tensoRF.py:118-196: the per-point building blocks of forward() -------------------
+    def compute_densityfeature(self, xyz_sampled, t_sampled=None, time_embedding_sampled=None):
+        """xyz_sampled [M,3] NORMALISED coordinates -> sigma feature [M] (sum of the 24 VM products,
+        before feature2density).  t_sampled / time_embedding_sampled are accepted and unused, as in
+        the reference.  Differentiable wrt the density factors and the coordinates."""
+        return _StaticFeatFn.apply(self, True, False, xyz_sampled.reshape(-1, 3), *self._param_list())[0]
+
+    def compute_appfeature(self, xyz_sampled, t_sampled=None, time_embedding_sampled=None):
+        """xyz_sampled [M,3] normalised -> basis_mat(72 VM products) [M,27]"""
+        return _StaticFeatFn.apply(self, False, True, xyz_sampled.reshape(-1, 3), *self._param_list())[1]
+
     # models/tensoRF.py:63-98
     def vectorDiffs(self, vector_comps):
         return vector_diffs(vector_comps)
@@ -683,18 +807,31 @@ class TensorVMSplit_TimeEmbedding(TensorBase):
     def get_forward_backward_scene_flow(self, unnormalized_pts, t_sampled):
         return _SceneFlowFn.apply(self, unnormalized_pts, t_sampled, *self._param_list())
 
+    def _features(self, want, x, t, normalized):
+        x2 = x.reshape(-1, 3)
+        t2 = t.reshape(-1)
+        if t2.numel() != x2.shape[0]:
+            raise L.RdrfError(f"compute_*: {x2.shape[0]} points but {t2.numel()} times")
+        return _DynFeatFn.apply(self, want, normalized, x2, t2, *self._param_list())
+
     def warp_coordinate(self, unnormalized_xyz_sampled, t_sampled):
-        """(N,S,3), (N,S) -> warped un-normalised coordinates (value only; the differentiable path
-        is forward()'s xyz_prime output)."""
-        xyz = unnormalized_xyz_sampled
-        N, S, _ = xyz.shape
-        rays = torch.zeros(N, 6, device=xyz.device)
-        rays[:, 5] = 1.0
-        z = torch.zeros(N, S, device=xyz.device)
-        valid = torch.ones(N, S, dtype=torch.bool, device=xyz.device)
-        with torch.no_grad():
-            out = self.forward(rays, t_sampled[:, 0].contiguous(), None, xyz, z, valid)
-        return out[5]
+        """models/tensoRF.py:521-541: (...,3) un-normalised points, (...) times -> warped un-normalised
+        points, same shape.  Differentiable wrt the warp MLP, the coordinates (not the times)."""
+        out = self._features(("warp",), unnormalized_xyz_sampled, t_sampled, False)[3]
+        return out.reshape(unnormalized_xyz_sampled.shape)
+
+    def compute_densityfeature(self, xyz_sampled, t_sampled, time_embedding_sampled=None):
+        """models/tensoRF.py:646-732: xyz_sampled [M,3] NORMALISED, t_sampled [M] -> density_layer2 output [M]
+        (3-stride VM features at the warped point + [xn, PE10, t, PE8] -> 64 -> 1)."""
+        return self._features(("density",), xyz_sampled, t_sampled, True)[0]
+
+    def compute_blendingfeature(self, xyz_sampled, t_sampled, time_embedding_sampled=None):
+        """models/tensoRF.py:543-629 (before the sigmoid)"""
+        return self._features(("blending",), xyz_sampled, t_sampled, True)[1]
+
+    def compute_appfeature(self, xyz_sampled, t_sampled, time_embedding_sampled=None):
+        """models/tensoRF.py:734-811: basis_mat(216 3-stride VM features at the warped point) [M,27]"""
+        return self._features(("app",), xyz_sampled, t_sampled, True)[2]
 
     @torch.no_grad()
     def upsample_volume_grid(self, res_target):

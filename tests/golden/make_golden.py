@@ -347,8 +347,50 @@ def gen_tv(mods):
     print("tv: ok", float(out["f.s.density.total"]), float(out["r.d.density_L1.value"]))
 
 
+def gen_fn_grads(mods):
+    """Gradients of the per-point building blocks (compute_densityfeature / compute_appfeature /
+    compute_blendingfeature / warp_coordinate of both fields, models/tensoRF.py:118-196, 521-811) wrt
+    every parameter and wrt the coordinates, on the weights and points of the ndc_relu case, from the
+    reference's own autograd.  L = sum_k <fn_k, r_k> with fixed random r_k."""
+    TS, TD, _, _, _ = mods
+    case = np.load(os.path.join(HERE, "ndc_relu.npz"), allow_pickle=True)
+    grid = [int(v) for v in case["meta.grid"]]
+    st, dy = build_fields(TS, TD, torch.from_numpy(case["aabb"]), grid, "relu", "MLP_Fea", -10.0, 1)
+    st.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("s.")})
+    dy.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("d.")})
+    xn = torch.from_numpy(case["fn.xn"]).clone().requires_grad_(True)
+    xu = dy.unnormalize_coord(torch.from_numpy(case["fn.xn"])).clone().requires_grad_(True)
+    tf = torch.from_numpy(case["fn.t"])
+    g = torch.Generator().manual_seed(4242)
+    outs = {"s_density": st.compute_densityfeature(xn, tf, None), "s_app": st.compute_appfeature(xn, tf, None),
+            "d_density": dy.compute_densityfeature(xn, tf, None),
+            "d_blending": dy.compute_blendingfeature(xn, tf, None),
+            "d_app": dy.compute_appfeature(xn, tf, None), "d_warp": dy.warp_coordinate(xu, tf)}
+    out = {}
+    L = 0.0
+    for k, v in outs.items():
+        assert np.allclose(v.detach().numpy(), case["fn." + k], rtol=0, atol=0), k
+        r = torch.randn(v.shape, generator=g)
+        out["lw." + k] = r.numpy()
+        L = L + (v * r).sum()
+    ps, pd = list(st.parameters()), list(dy.parameters())
+    grads = torch.autograd.grad(L, ps + pd + [xn, xu], allow_unused=True)
+    for (k, _), gv in zip(st.named_parameters(), grads[: len(ps)]):
+        out["gs." + k] = (gv if gv is not None else torch.zeros(())).numpy()
+    for (k, _), gv in zip(dy.named_parameters(), grads[len(ps): len(ps) + len(pd)]):
+        out["gd." + k] = (gv if gv is not None else torch.zeros(())).numpy()
+    out["g.xn"] = grads[-2].numpy()
+    out["g.xu"] = grads[-1].numpy()
+    out["loss"] = L.detach().numpy()
+    np.savez(os.path.join(HERE, "fn_grads.npz"), **out)
+    print("fn_grads: ok", float(L))
+
+
 if __name__ == "__main__":
     mods = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "fn_grads":
+        gen_fn_grads(mods)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tv":
         gen_tv(mods)
         sys.exit(0)
@@ -365,3 +407,4 @@ if __name__ == "__main__":
     gen_raygen(mods)
     gen_induce_flow(mods)
     gen_tv(mods)
+    gen_fn_grads(mods)
