@@ -113,6 +113,18 @@ int rdrf_generate_rays_bwd(const int64_t* ids, const float* poses9, const float*
                            int T, int H, int W, int ndc, float near, const float* grad_rays,
                            float* grad_poses9, float* grad_focal, rdrf_stream_t stream);
 
+/* The flow-displaced rays of train.py:1433-1460, 1530-1557, 1968-1990, 2033-2050: uv[N][2] (may be NULL)
+ * replaces the pixel centre of the ray id by (column + 0.5 + flow_x, row + 0.5 + flow_y); the camera is
+ * frame id / (H W) + view_shift clamped to [0, T-1] (allposes_refine_f / allposes_refine_b). uv carries no
+ * gradient (the flow is data). */
+int rdrf_generate_rays_uv(const int64_t* ids, const float* uv, int view_shift, const float* poses9,
+                          const float* focal, int N, int T, int H, int W, int ndc, float near, float* rays,
+                          rdrf_stream_t stream);
+int rdrf_generate_rays_uv_bwd(const int64_t* ids, const float* uv, int view_shift, const float* poses9,
+                              const float* focal, int N, int T, int H, int W, int ndc, float near,
+                              const float* grad_rays, float* grad_poses9, float* grad_focal,
+                              rdrf_stream_t stream);
+
 /* ---- renderer.sampleXYZ (renderer.py:147-170) ------------------------------------------------
  * NDC: models/tensorBase.py:487-499. jitter[S] (uniform [0,1), shared by all rays) or NULL. */
 int rdrf_sample_ndc(const float* rays, int N, int S, float near, float far, const float* jitter,
@@ -266,6 +278,29 @@ typedef struct {
 } RdrfTensor4;
 int rdrf_tv_fwd(const RdrfTensor4* t, int n, float* sums /* [n][2], overwritten */, rdrf_stream_t stream);
 int rdrf_tv_bwd(const RdrfTensor4* t, int n, const float* g_sums /* [n][2] */, rdrf_stream_t stream);
+
+/* ---- Adam over a flat parameter range (torch.optim.Adam as train.py:924-934 builds it: betas
+ * (0.9, 0.99), eps 1e-8, no weight decay / amsgrad; the learning-rate decay of train.py:2608-2612 is the
+ * caller's: it passes the current rates).  p, g, m, v: n floats each, 16-byte aligned, n % 4 == 0.
+ * Elements [0, split) step with lr0 (the VM factors), [split, n) with lr1 (the networks).  step >= 1 is
+ * the 1-based iteration for the bias corrections; grad_scale multiplies g first (1 / world size when the
+ * data-parallel exchange summed the per-rank gradients). */
+int rdrf_adam_step(float* p, const float* g, float* m, float* v, size_t n, size_t split, float lr0,
+                   float lr1, float beta1, float beta2, float eps, int step, float grad_scale,
+                   rdrf_stream_t stream);
+
+/* ---- upsample_volume_grid (models/tensoRF.py:199-232, 814-850): bilinear, align_corners=True, of up to
+ * RDRF_TV_MAX (1,C,H,W) views with arbitrary element strides (src[i] -> dst[i], C % 4 == 0) in one launch;
+ * lines are the W == 1 case. */
+int rdrf_upsample_bilinear(const RdrfTensor4* src, const RdrfTensor4* dst, int n, rdrf_stream_t stream);
+
+/* ---- density_L1 / blending_L1 (models/tensoRF.py:80-98, 378-416): sum over the X x Y x Z grid of
+ * |feature2density(sum_c plane x line)| without materialising any volume (the reference builds a
+ * [1,24,X,Y,Z] tensor).  fwd: sum_out[0] = the sum (the caller divides by X*Y*Z).  bwd: g_mean[0] (device)
+ * = d loss / d mean; plane / line gradients accumulate (+=) into gvm. {16,4,4}-component sets only. */
+int rdrf_dense_l1_fwd(const RdrfVM* vm, int act, float density_shift, float* sum_out, rdrf_stream_t stream);
+int rdrf_dense_l1_bwd(const RdrfVM* vm, const RdrfVM* gvm, int act, float density_shift, const float* g_mean,
+                      rdrf_stream_t stream);
 
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
  * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].

@@ -1,0 +1,190 @@
+"""CPU re-enactment of ONE training iteration of the hot path -- TEST INFRASTRUCTURE ONLY.
+
+The same pass / loss recipe as robust-dynrf_amd/step.py (Trainer.losses), written against the oracle's
+functions (oracle/rodynrf_oracle.py) with torch autograd on the CPU, the per-frame depth loss as the
+reference's host loop (train.py:1636-1664), density_L1 as an einsum.  Used by
+  * tests/test_gpu_trainer.py: Trainer.step's flat gradient vs this step on identical batch / jitter / coins,
+  * bench.py's cpu_baseline leg (timed on the host cores, kind "port").
+Reference structure restated: train.py:1092-1162 (A), 1166-1246 (B), 1319 (scene flow), 1373-1413 (induced
+flow), 1433-1625 (C, D), 1756-1861 (E), 1895-2311 (optimize_poses block: P1-P4)."""
+import math
+
+import torch
+
+from . import rodynrf_oracle as O
+
+
+class FixedRng:
+    """replays a fixed list of jitter vectors / coins (the GPU trainer is given the same object type)"""
+
+    def __init__(self, seed=0):
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def coin(self):
+        return bool(torch.rand(1, generator=self.gen).item() < 0.5)
+
+    def jitter(self, S, ray_type, device="cpu"):
+        if ray_type == "ndc":
+            return torch.rand(S, generator=self.gen).to(device), None
+        return (torch.rand(S - S // 2 + 1, generator=self.gen).to(device),
+                torch.rand(S // 2 + 1, generator=self.gen).to(device))
+
+
+def masked_mean(x, m):
+    return (x * m).sum() / (m.sum() + 1e-8)
+
+
+def _cfgs(cfg, aabb):
+    base = dict(aabb=aabb, act="relu", density_shift=-10.0, distance_scale=25.0, weight_thres=1e-4, view_pe=0)
+    return dict(base, head=cfg.get("static_head", "MLP_Fea"), fea_pe=2), dict(base, head="MLP_Fea_late_view", fea_pe=0)
+
+
+def ray_pass(sd_s, cfg_s, sd_d, cfg_d, rays, ts, S, rt, near_far, rng, static_grad=False, dynamic=True):
+    jit, jit_o = rng.jitter(S, rt)
+    xyz, z, valid = O.sampleXYZ(rays, cfg_d["aabb"], near_far, S, rt, jit, jit_o)
+    if static_grad:
+        o_s = O.field_forward(sd_s, cfg_s, rays, ts, xyz, z, valid, rt, dynamic=False)
+    else:
+        with torch.no_grad():
+            o_s = O.field_forward(sd_s, cfg_s, rays, ts, xyz, z, valid, rt, dynamic=False)
+    if dynamic:
+        o_d = O.field_forward(sd_d, cfg_d, rays, ts, xyz, z, valid, rt, dynamic=True)
+        a = (o_d[6], o_d[7], o_d[9], o_d[2], o_d[8])
+    else:
+        o_d = None
+        a = (torch.zeros_like(o_s[6]), torch.zeros_like(o_s[7]), o_s[9], torch.zeros_like(o_s[7]), z)
+    white = rng.coin()
+    outs = O.raw2outputs(o_s[6], o_s[7], a[0], a[1], a[2], a[3], a[4], rays, white, rt)
+    return o_s, o_d, outs, (xyz, z, valid)
+
+
+def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False):
+    """(loss_dynamic, loss_static, tv_dynamic, tv_static) of one iteration; `poses` [T,9] and `focal`
+    (0-dim tensor or float) may require grad (optimize_poses)."""
+    S, rt, T, H, W = cfg["n_samples"], cfg["ray_type"], cfg["T"], cfg["H"], cfg["W"]
+    aabb = torch.tensor(cfg["aabb"], dtype=torch.float32)
+    cfg_s, cfg_d = _cfgs(cfg, aabb)
+    nf = cfg["near_far"]
+    ndc = rt == "ndc"
+    b = batch
+    ids, ts, rgb_t, disp_t, fg = b["ids"], b["ts"], b["rgb"], b["disp"], b["fg"]
+    opt_poses = bool(cfg.get("optimize_poses", False))
+    rays = O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0)
+    rays_d = rays.detach()
+    poses_d = poses.detach()
+    focal_d = focal.detach() if torch.is_tensor(focal) else focal
+    dt = 2.0 / (T - 1)
+    col, row, view = O.ids2pixel(W, H, ids)
+    grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+    c2w_all = O.pose_to_mtx(poses)
+    temp = 1.0 / (10 ** (it // 100000))
+    temp_static = 1.0 / (10 ** (it / 100000.0))
+    gt_depth = -disp_t if ndc else disp_t
+    to_depth = (lambda d: d) if ndc else (lambda d: 1.0 / (d + 1e-6))
+    rp = lambda rays_, ts_, **kw: ray_pass(sd_s, cfg_s, sd_d, cfg_d, rays_, ts_, S, rt, nf, rng, **kw)
+    # ---- pass A
+    _, oA, outA, _ = rp(rays_d, ts)
+    loss_d = 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
+    loss_d = loss_d + 0.1 * (outA[12] - fg).abs().mean()
+    loss_d = loss_d + cfg["monodepth_dynamic"] * temp * O.frame_depth_loss(to_depth(outA[9]), gt_depth, view, T)
+    w_dist = cfg["dist_dynamic"] * min(1.0, (it + 1) / cfg["n_iters"])
+    loss_d = loss_d + w_dist * O.eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
+    # ---- pass B
+    _, oB, outB, _ = rp(rays_d, b["ts_rand"])
+    loss_d = loss_d + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+    loss_d = loss_d + w_dist * O.eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
+    # ---- scene flow
+    sf_f, sf_b = O.scene_flow(sd_d, aabb, oA[3], ts)
+    w_d = outA[11].detach()[..., None]
+    loss_d = loss_d + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
+    loss_d = loss_d + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
+    weights_d, pts_ref = outA[11], oA[3]
+    disp_A = {}
+    for sgn, sf, flow_t, mask_t in ((1, sf_f, b["flow_f"], b["mask_f"]), (-1, sf_b, b["flow_b"], b["mask_b"])):
+        pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
+        pts_n = pts_ref + sf if ndc else torch.clamp(pts_ref + sf, min=-2.0 + 1e-6, max=2.0 - 1e-6)
+        ind_flow, ind_disp = O.induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, grid, rays_d, rt)
+        loss_d = loss_d + 0.02 * temp * masked_mean((ind_flow - flow_t).abs(), mask_t) / 2.0
+        disp_A[sgn] = (ind_disp, mask_t, pose_n, flow_t)
+    # ---- pass C / D
+    for sgn in (1, -1):
+        ind_disp, mask_t, pose_n, flow_t = disp_A[sgn]
+        rays_n = O.generate_rays(ids, poses_d, focal_d, H, W, ndc=ndc, near=1.0, uv=grid + flow_t, view_shift=sgn)
+        _, oN, outN, _ = rp(rays_n, ts + sgn * dt)
+        _, ind_disp_n = O.induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, rt)
+        loss_d = loss_d + 0.04 * temp * masked_mean((ind_disp - ind_disp_n).abs(), mask_t)
+        loss_d = loss_d + w_dist * O.eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
+    # ---- pass E
+    oE, _, outE, _ = rp(rays, ts, static_grad=True, dynamic=dead_work)
+    m = (1.0 - fg)[:, None]
+    loss_s = masked_mean((outE[4] - rgb_t) ** 2, m) / 3.0
+    if not opt_poses:
+        loss_s = loss_s + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
+    if cfg["dist_static"] > 0:
+        loss_s = loss_s + cfg["dist_static"] * (it / cfg["n_iters"]) * O.eff_distloss(outE[7], oE[8].detach(), 1.0 / S)
+    if opt_poses:   # train.py:1895-2311
+        weights_s, pts_ref_s, depth_s = outE[7], oE[3], outE[5]
+        for sgn, flow_t, mask_t in ((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"])):
+            pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]
+            mm = mask_t * m
+            ind_flow, ind_disp = O.induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, grid, rays, rt)
+            loss_s = loss_s + 0.02 * temp_static * masked_mean((ind_flow - flow_t).abs(), mm) / 2.0
+            rays_n = O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0, uv=grid + flow_t, view_shift=sgn)
+            jit, jit_o = rng.jitter(S, rt)
+            xyz, z, valid = O.sampleXYZ(rays_n, aabb, nf, S, rt, jit, jit_o)
+            o = O.field_forward(sd_s, cfg_s, rays_n, ts, xyz, z, valid, rt, dynamic=False)
+            _, ind_disp_n = O.induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, rt)
+            loss_s = loss_s + 0.04 * temp_static * masked_mean((ind_disp - ind_disp_n).abs(), mm)
+        loss_s = loss_s + cfg["monodepth_static"] * temp_static * O.frame_depth_loss(to_depth(depth_s), gt_depth, view,
+                                                                                     T, mask=fg < 0.5)
+        colf, rowf = grid[:, 0], grid[:, 1]
+        inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)
+        sm = 0.0
+        for uv_n in (torch.stack([torch.clamp(colf + 1.0, max=W - 0.5), rowf], -1),
+                     torch.stack([colf, torch.clamp(rowf + 1.0, max=H - 0.5)], -1)):
+            rays_n = O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0, uv=uv_n)
+            _, _, outN, _ = rp(rays_n, ts, static_grad=True, dynamic=dead_work)
+            sm = sm + ((inv_d - 1.0 / torch.clamp(outN[5], min=1e-6)) ** 2).mean()
+        loss_s = loss_s + 50.0 * temp * sm
+    fam = lambda sd, name: ([sd[f"{name}_plane.{i}"] for i in range(3)], [sd[f"{name}_line.{i}"] for i in range(3)])
+    if cfg["l1_weight"] > 0:
+        loss_d = loss_d + cfg["l1_weight"] * O.dense_l1(*fam(sd_d, "density"), "relu", -10.0)
+        loss_s = loss_s + cfg["l1_weight"] * O.dense_l1(*fam(sd_s, "density"), "relu", -10.0)
+    tv_d = tv_s = None
+    if cfg["tv_density"] > 0 or cfg["tv_app"] > 0:
+        tv_d = (cfg["tv_density"] * (O.tv_family(*fam(sd_d, "density")) + O.tv_family(*fam(sd_d, "blending")))
+                + cfg["tv_app"] * O.tv_family(*fam(sd_d, "app")))
+        tv_s = cfg["tv_density"] * O.tv_family(*fam(sd_s, "density")) + cfg["tv_app"] * O.tv_family(*fam(sd_s, "app"))
+    return loss_d, loss_s, tv_d, tv_s
+
+
+def step_gradients(cfg, sd_s, sd_d, batch, poses, focal_or_fov, it, rng, dead_work=False):
+    """gradients of one iteration wrt every entry of both state_dicts (+ poses / fov when optimised):
+    returns (loss, {'s.<key>': grad, 'd.<key>': grad, 'poses': ..., 'fov': ...})"""
+    opt_poses = bool(cfg.get("optimize_poses", False))
+    for sd in (sd_s, sd_d):
+        for v in sd.values():
+            v.requires_grad_(True)
+    extra = []
+    if opt_poses:
+        poses = poses.clone().requires_grad_(True)
+        fov = focal_or_fov.clone().requires_grad_(True)
+        focal = max(cfg["H"], cfg["W"]) / 2.0 / torch.tan(fov[0])
+        extra = [poses, fov]
+    else:
+        focal = float(focal_or_fov)
+    ld, ls, tvd, tvs = step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work)
+    ks, kd = list(sd_s.keys()), list(sd_d.keys())
+    ps = [sd_s[k] for k in ks] + [sd_d[k] for k in kd] + extra
+    total = ld + ls
+    g1 = torch.autograd.grad(total, ps, allow_unused=True)
+    out = {}
+    names = ["s." + k for k in ks] + ["d." + k for k in kd] + (["poses", "fov"] if opt_poses else [])
+    for n, g in zip(names, g1):
+        out[n] = g
+    if tvd is not None:
+        g2 = torch.autograd.grad(tvd + tvs, ps, allow_unused=True)
+        for n, g in zip(names, g2):
+            if g is not None:
+                out[n] = g if out[n] is None else out[n] + g
+    return total.detach(), out

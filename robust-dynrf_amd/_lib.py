@@ -64,6 +64,9 @@ def _load():
                        ("rdrf_features_bwd_workspace_bytes", [C.c_int])):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = args
+    lib.rdrf_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
+                                   C.c_void_p]
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
     lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -78,14 +81,15 @@ lib = _load()
 SYMBOLS = [
     "rdrf_abi_version", "rdrf_last_error", "rdrf_workspace_bytes", "rdrf_saved_bytes",
     "rdrf_generate_rays",
-    "rdrf_generate_rays_bwd", "rdrf_sample_ndc", "rdrf_sample_contract", "rdrf_sample_bwd",
+    "rdrf_generate_rays_bwd", "rdrf_generate_rays_uv", "rdrf_generate_rays_uv_bwd", "rdrf_sample_ndc", "rdrf_sample_contract", "rdrf_sample_bwd",
     "rdrf_static_fwd", "rdrf_static_bwd", "rdrf_dynamic_fwd", "rdrf_dynamic_bwd",
     "rdrf_features_saved_bytes", "rdrf_features_workspace_bytes", "rdrf_features_bwd_workspace_bytes",
     "rdrf_static_features_fwd", "rdrf_static_features_bwd", "rdrf_dynamic_features_fwd",
     "rdrf_dynamic_features_bwd",
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
-    "rdrf_tv_fwd", "rdrf_tv_bwd",
+    "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
+    "rdrf_dense_l1_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]

@@ -1899,6 +1899,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 2048, -1, "static_bwd: bad arguments (S <= 2048)");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "static_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   // z_vals never depends on a trainable quantity in the reference (linspace + jitter)
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
@@ -1982,6 +1983,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 1024, -1, "dynamic_bwd: bad arguments (S <= 1024)");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "dynamic_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_blending = g_blending;
@@ -2223,6 +2225,7 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
                                    rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "scene_flow_bwd: bad arguments");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "scene_flow_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   const size_t tiles = ((size_t)N * S + 31) / 32;
   RDRF_CHECK(saved_bytes >= tiles * sv::SF_ROWS * 32 * 4, -3, "scene_flow_bwd: saved buffer too small");
   WsCarver c(ws, ws_bytes);
@@ -2261,7 +2264,8 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
 
 // ------------------------------------------------------------------------------------------------
 // ray generation backward: hand-written adjoint of k_generate_rays (rdrf_misc.hip)
-__global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float* __restrict__ poses9,
+__global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float* __restrict__ uv, int view_shift,
+                                    const float* __restrict__ poses9,
                                     const float* __restrict__ focal_p, int N, int T, int H, int W,
                                     int ndc, float near, const float* __restrict__ g_rays,
                                     float* __restrict__ g_poses, float* __restrict__ g_focal) {
@@ -2270,10 +2274,11 @@ __global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float
   if (n < N) {
     const long id = ids[n];
     const int col = (int)(id % W), row = (int)((id / W) % H);
-    int view = (int)(id / ((long)W * H));
+    int view = (int)(id / ((long)W * H)) + view_shift;
     view = view < 0 ? 0 : (view >= T ? T - 1 : view);
     const float f = focal_p[0];
-    const float dir[3] = {((float)col + 0.5f - 0.5f * W) / f, -((float)row + 0.5f - 0.5f * H) / f, -1.0f};
+    const float pu = uv ? uv[2 * n] : (float)col + 0.5f, pv = uv ? uv[2 * n + 1] : (float)row + 0.5f;
+    const float dir[3] = {(pu - 0.5f * W) / f, -(pv - 0.5f * H) / f, -1.0f};
     const float* p = poses9 + view * 9;
     float b1[3] = {p[0], p[1], p[2]};
     const float n1 = sqrtf(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
@@ -2340,13 +2345,20 @@ __global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float
   if ((threadIdx.x & 63) == 0 && gf != 0.f) atomicAdd(g_focal, gf);
 }
 
+extern "C" int rdrf_generate_rays_uv_bwd(const int64_t* ids, const float* uv, int view_shift, const float* poses9,
+                                         const float* focal, int N, int T, int H, int W, int ndc, float near,
+                                         const float* grad_rays, float* grad_poses9, float* grad_focal,
+                                         rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(N > 0 && T > 0 && grad_rays && grad_poses9 && grad_focal, -1, "generate_rays_bwd: bad arguments");
+  RDRF_LAUNCH("generate_rays_bwd", k_generate_rays_bwd, dim3((N + 255) / 256), dim3(256), stream, ids, uv,
+              view_shift, poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9, grad_focal);
+  return 0;
+}
 extern "C" int rdrf_generate_rays_bwd(const int64_t* ids, const float* poses9, const float* focal,
                                       int N, int T, int H, int W, int ndc, float near,
                                       const float* grad_rays, float* grad_poses9, float* grad_focal,
                                       rdrf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  RDRF_CHECK(N > 0 && T > 0 && grad_rays && grad_poses9 && grad_focal, -1, "generate_rays_bwd: bad arguments");
-  RDRF_LAUNCH("generate_rays_bwd", k_generate_rays_bwd, dim3((N + 255) / 256), dim3(256), stream, ids,
-              poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9, grad_focal);
-  return 0;
+  return rdrf_generate_rays_uv_bwd(ids, nullptr, 0, poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9,
+                                   grad_focal, stream_);
 }

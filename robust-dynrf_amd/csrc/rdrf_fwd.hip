@@ -666,6 +666,7 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "static_fwd: bad arguments");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "static_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
              "static_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
   FieldArgs a;
@@ -700,6 +701,7 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "dynamic_fwd: bad arguments");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "dynamic_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
              "dynamic_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
   FieldArgs a;
@@ -816,6 +818,7 @@ extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCf
                                    size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "scene_flow_fwd: bad arguments");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "scene_flow_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   FieldArgs a;
   memset(&a, 0, sizeof(a));
   RDRF_CHECK(saved == nullptr || saved_bytes >= rdrf_saved_bytes(2, N, S), -3,

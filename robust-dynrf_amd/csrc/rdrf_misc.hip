@@ -9,7 +9,11 @@
 // ------------------------------------------------------------------------------------------------
 // ray generation
 // ------------------------------------------------------------------------------------------------
-__global__ void k_generate_rays(const int64_t* __restrict__ ids, const float* __restrict__ poses9,
+// uv (nullable): [N][2] pixel coordinates (column + 0.5 + flow_x, row + 0.5 + flow_y) that replace the
+// pixel centre of the ray id -- the flow-displaced rays of train.py:1433-1460, 1530-1557, 1968-1990;
+// view_shift: the camera is frame view + view_shift clamped to [0, T-1] (allposes_refine_f / _b).
+__global__ void k_generate_rays(const int64_t* __restrict__ ids, const float* __restrict__ uv, int view_shift,
+                                const float* __restrict__ poses9,
                                 const float* __restrict__ focal_p, int N, int T, int H, int W,
                                 int ndc, float near, float* __restrict__ rays) {
 #pragma clang fp contract(off)
@@ -17,10 +21,10 @@ __global__ void k_generate_rays(const int64_t* __restrict__ ids, const float* __
   if (n >= N) return;
   const long id = ids[n];
   const int col = (int)(id % W), row = (int)((id / W) % H);
-  int view = (int)(id / ((long)W * H));
+  int view = (int)(id / ((long)W * H)) + view_shift;
   view = view < 0 ? 0 : (view >= T ? T - 1 : view);
   const float focal = focal_p[0];
-  const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+  const float i = uv ? uv[2 * n] : (float)col + 0.5f, j = uv ? uv[2 * n + 1] : (float)row + 0.5f;
   const float cx = (float)((double)W / 2), cy = (float)((double)H / 2);
   const float dir0 = (i - cx) / focal, dir1 = -(j - cy) / focal, dir2 = -1.0f;
   const float* p = poses9 + view * 9;
@@ -52,14 +56,19 @@ __global__ void k_generate_rays(const int64_t* __restrict__ ids, const float* __
   r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
 }
 
+extern "C" int rdrf_generate_rays_uv(const int64_t* ids, const float* uv, int view_shift, const float* poses9,
+                                     const float* focal, int N, int T, int H, int W, int ndc, float near,
+                                     float* rays, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(ids && poses9 && focal && rays && N > 0 && T > 0 && H > 0 && W > 0, -1, "generate_rays: bad arguments");
+  RDRF_LAUNCH("generate_rays", k_generate_rays, dim3((N + 255) / 256), dim3(256), stream, ids, uv, view_shift,
+              poses9, focal, N, T, H, W, ndc, near, rays);
+  return 0;
+}
 extern "C" int rdrf_generate_rays(const int64_t* ids, const float* poses9, const float* focal,
                                   int N, int T, int H, int W, int ndc, float near, float* rays,
                                   rdrf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  RDRF_CHECK(N > 0 && T > 0 && H > 0 && W > 0, -1, "generate_rays: bad arguments");
-  RDRF_LAUNCH("generate_rays", k_generate_rays, dim3((N + 255) / 256), dim3(256), stream, ids,
-              poses9, focal, N, T, H, W, ndc, near, rays);
-  return 0;
+  return rdrf_generate_rays_uv(ids, nullptr, 0, poses9, focal, N, T, H, W, ndc, near, rays, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

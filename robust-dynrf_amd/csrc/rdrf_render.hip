@@ -16,6 +16,7 @@ extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* c
                                rdrf_stream_t stream) {
   RDRF_CHECK(PS && PD && cfg_s && cfg_d && rays && ts && rgb_map && depth_map && N > 0 && S > 0, -1,
              "render_fwd: bad arguments");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "render_fwd: N * S * 3 must stay below 2^31: render in chunks");
   RDRF_CHECK(ws_bytes >= rdrf_render_workspace_bytes(N, S), -3, "render_fwd: workspace too small");
   WsCarver c(ws, ws_bytes);
   const size_t ns = (size_t)N * S;

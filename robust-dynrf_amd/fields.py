@@ -99,6 +99,12 @@ def _vm_struct(planes, lines):
     vm = L.RdrfVM()
     for i in range(3):
         p, l = planes[i], lines[i]
+        # the kernels read components with stride 1 (16-byte quads) and lines as [L][C]: a factor that
+        # lost its channel-last storage (user-assigned parameter, .contiguous(), external resampling)
+        # would be read with the wrong layout -- fail loudly instead
+        if p.stride(1) != 1 or l.stride(1) != 1 or l.stride(2) != l.shape[1] or p.shape[1] % 4 != 0:
+            raise L.RdrfError(f"VM factor {i} is not channel-last (plane strides {tuple(p.stride())}, line strides "
+                              f"{tuple(l.stride())}): use fields.channel_last_()")
         vm.plane[i] = p.data_ptr()
         vm.line[i] = l.data_ptr()
         vm.C[i] = p.shape[1]
@@ -209,6 +215,9 @@ class _StaticFn(torch.autograd.Function):
             # as in the reference where dists has no parameter ancestry
             ctx.saved = None
             return (None,) * (7 + len(params))
+        if ctx.saved is None:
+            raise L.RdrfError("TensorVMSplit.forward: backward called twice (the saved activations are released "
+                              "after the first backward; retain_graph is not supported)")
         N, S = z.shape
         dev = z.device
         fused = ctx.field.fused_grad
@@ -267,6 +276,9 @@ class _DynamicFn(torch.autograd.Function):
             # compositor): no parameter ancestry, nothing to differentiate
             ctx.saved = None
             return (None,) * (7 + len(params))
+        if ctx.saved is None:
+            raise L.RdrfError("TensorVMSplit_TimeEmbedding.forward: backward called twice (the saved activations "
+                              "are released after the first backward; retain_graph is not supported)")
         N, S = z.shape
         dev = z.device
         fused = ctx.field.fused_grad
@@ -318,6 +330,8 @@ class _SceneFlowFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_f, g_b):
         pts, ts, *params = ctx.saved_tensors
+        if ctx.saved is None:
+            raise L.RdrfError("get_forward_backward_scene_flow: backward called twice (retain_graph is not supported)")
         N, S, _ = pts.shape
         fused = ctx.field.fused_grad
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
@@ -569,6 +583,12 @@ class TensorBase(nn.Module):
         torch.save({"kwargs": kwargs, "state_dict": self.state_dict()}, path)
 
     def load(self, ckpt):
+        """models/tensorBase.py:472-485.  The alpha-mask machinery is dead in the reference (compute_alpha calls
+        compute_densityfeature with the wrong arity) and is not built here: a checkpoint
+        that carries one is refused instead of silently dropping it."""
+        if any(k.startswith("alphaMask") for k in ckpt) or any(k.startswith("alphaMask") for k in ckpt["state_dict"]):
+            raise NotImplementedError("checkpoint carries an alphaMask: AlphaGridMask is not built (dead code in "
+                                      "the reference, SURVEY.md section 0)")
         self.load_state_dict(ckpt["state_dict"])
 
     # ---- samplers (models/tensorBase.py:487-559): device kernels, RNG stays in torch ----------
@@ -587,15 +607,26 @@ class TensorBase(nn.Module):
 
     @torch.no_grad()
     def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        """models/tensoRF.py:199-221 / 814-836: bilinear (align_corners) resampling of a factor family to
+        the new grid -- rdrf_upsample_bilinear, one launch for the six tensors, channel-last in and out."""
+        from .regularizers import _tensor4
+        srcs, dsts = [], []
         for i in range(3):
             vec_id = VEC_MODE[i]
             m0, m1 = MAT_MODE[i]
-            p = F.interpolate(plane_coef[i].data, size=(res_target[m1], res_target[m0]),
-                              mode="bilinear", align_corners=True)
-            l = F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1), mode="bilinear",
-                              align_corners=True)
-            plane_coef[i] = nn.Parameter(channel_last_(p, h_fast=Z_FAST and i > 0))
-            line_coef[i] = nn.Parameter(channel_last_(l))
+            p, l = plane_coef[i].data, line_coef[i].data
+            L.require_device(p, l)
+            newp = torch.empty((1, p.shape[1], int(res_target[m1]), int(res_target[m0])), device=p.device)
+            newl = torch.empty((1, l.shape[1], int(res_target[vec_id]), 1), device=l.device)
+            newp, newl = channel_last_(newp, h_fast=Z_FAST and i > 0), channel_last_(newl)
+            srcs += [p, l]
+            dsts += [newp, newl]
+        sa = (L.RdrfTensor4 * 6)(*[_tensor4(t) for t in srcs])
+        da = (L.RdrfTensor4 * 6)(*[_tensor4(t) for t in dsts])
+        L.check(L.lib.rdrf_upsample_bilinear(sa, da, 6, L.stream_of(srcs[0])), "rdrf_upsample_bilinear")
+        for i in range(3):
+            plane_coef[i] = nn.Parameter(dsts[2 * i])
+            line_coef[i] = nn.Parameter(dsts[2 * i + 1])
         return plane_coef, line_coef
 
     # ---- fused gradient accumulation ----------------------------------------------------
@@ -607,26 +638,59 @@ class TensorBase(nn.Module):
     # (torch.autograd.grad, retain_graph, ...) need freshly returned gradients.
     fused_grad = False
 
+    FLAT_ALIGN = 4096   # floats: the flat buffers split evenly over 1, 2, 4, 8 ... ranks in 16-byte units
+
+    def _flat_layout(self):
+        """(offsets, total, split): float offset of every parameter of _param_list() inside the flat
+        buffers (64-float aligned), the padded total, and the offset where the VM factors end and the
+        networks begin (the two learning rates of get_optparam_groups)."""
+        params = self._param_list()
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        n_vm = sum(1 for n, _ in self.named_parameters() if "_plane." in n or "_line." in n)
+        split = offs[n_vm] if n_vm < len(offs) else total
+        total = (total + self.FLAT_ALIGN - 1) // self.FLAT_ALIGN * self.FLAT_ALIGN
+        return offs, total, split
+
     def fused_grads(self):
         params = self._param_list()
         views = getattr(self, "_gviews", None)
         ok = views is not None and len(views) == len(params) and all(
             p.grad is not None and p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride()
-            for p, v in zip(params, views))
+            and p.shape == v.shape for p, v in zip(params, views))
         if not ok:
-            offs, total = [], 0
-            for p in params:
-                offs.append(total)
-                total += (p.numel() + 63) // 64 * 64
+            offs, total, _ = self._flat_layout()
             flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
             views = [torch.as_strided(flat, p.size(), p.stride(), o) for p, o in zip(params, offs)]
             with torch.no_grad():
                 for p, v in zip(params, views):
-                    if p.grad is not None:
+                    if p.grad is not None and p.grad.shape == v.shape:
                         v.copy_(p.grad)
                     p.grad = v
             self._gflat, self._gviews = flat, views
         return views
+
+    def flatten_params_(self):
+        """Make every parameter a view of ONE flat fp32 buffer (same layout as the fused gradient buffer):
+        the Adam kernel then updates a field with one launch over (p, g, m, v) flat ranges, and the
+        sharded data-parallel step reduce-scatters / all-gathers the flat buffers in place.  Values,
+        shapes, strides and state_dict() are unchanged.  Returns the flat buffer (idempotent)."""
+        params = self._param_list()
+        offs, total, _ = self._flat_layout()
+        flat = getattr(self, "_pflat", None)
+        ok = flat is not None and flat.numel() == total and all(
+            p.data_ptr() == flat.data_ptr() + 4 * o for p, o in zip(params, offs))
+        if not ok:
+            flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            with torch.no_grad():
+                for p, o in zip(params, offs):
+                    v = torch.as_strided(flat, p.size(), p.stride(), o)
+                    v.copy_(p.data)
+                    p.data = v
+            self._pflat = flat
+        return flat
 
     def zero_grad_fused(self):
         """one memset for every gradient of this field (replaces optimizer.zero_grad())"""

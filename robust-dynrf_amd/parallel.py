@@ -84,3 +84,72 @@ class GradBucket:
 
 def shard_bounds(n, rank, world):
     return rank * n // world, (rank + 1) * n // world
+
+
+class FlatExchange:
+    """The data-parallel exchange of flat gradient buffers, separated from the optimiser
+    arithmetic so that the choreography is testable on CPU tensors with gloo:
+
+      mode "allreduce": sum-all-reduce of the whole buffer, every rank updates every parameter;
+      mode "zero1":     reduce-scatter -> the rank updates the slice [rank*n, (rank+1)*n) it owns ->
+                        all-gather of the updated parameter slices (ZeRO-1: moments only for the slice).
+
+    begin(i, g) may be called as soon as buffer i is complete (async); grads(i) waits and returns
+    (gradient tensor to use, lo, n); gather(i, p) publishes the updated slice of parameter buffer p."""
+
+    def __init__(self, totals, mode="zero1", group=None):
+        if mode not in ("allreduce", "zero1"):
+            raise ValueError(mode)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.mode = mode if self.world > 1 else "allreduce"
+        self.totals = list(totals)
+        if self.mode == "zero1":
+            for t in self.totals:
+                if t % (4 * self.world) != 0:
+                    raise ValueError(f"flat buffer of {t} floats does not split into {self.world} 16-byte aligned shards")
+        self._pending, self._g, self._shards = {}, {}, {}
+
+    def slice(self, i):
+        if self.mode == "zero1":
+            n = self.totals[i] // self.world
+            return self.rank * n, n
+        return 0, self.totals[i]
+
+    def begin(self, i, g, async_op=True):
+        if i in self._g:
+            return
+        self._g[i] = g
+        if self.world == 1:
+            return
+        if self.mode == "zero1":
+            lo, n = self.slice(i)
+            sh = self._shards.get(i)
+            if sh is None or sh.numel() != n or sh.device != g.device:
+                sh = self._shards[i] = torch.empty(n, dtype=g.dtype, device=g.device)
+            w = dist.reduce_scatter_tensor(sh, g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        else:
+            w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        self._pending[i] = w if async_op else None
+
+    def grads(self, i, g=None):
+        """wait for buffer i; returns (tensor holding the summed gradient of this rank's slice, lo, n)"""
+        if i not in self._g:
+            self.begin(i, g, async_op=False)
+        w = self._pending.pop(i, None)
+        if w is not None:
+            w.wait()
+        g = self._g.pop(i)
+        lo, n = self.slice(i)
+        return (self._shards[i] if (self.mode == "zero1" and self.world > 1) else g), lo, n
+
+    def gather(self, i, p, async_op=True):
+        """zero1: all-gather the updated parameter slices into the flat parameter buffer p (in place)"""
+        if self.world == 1 or self.mode != "zero1":
+            return None
+        lo, n = self.slice(i)
+        src = p[lo: lo + n]
+        if dist.get_backend(self.group) != "nccl":   # the in-place form (input = own slice of output) is an NCCL idiom
+            src = src.clone()
+        return dist.all_gather_into_tensor(p, src, group=self.group, async_op=async_op)

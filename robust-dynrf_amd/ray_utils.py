@@ -9,37 +9,47 @@ from . import _lib as L
 
 class _RayGenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, poses9, focal, H, W, ndc, near):
+    def forward(ctx, ids, poses9, focal, H, W, ndc, near, uv, view_shift):
         L.require_device(ids, poses9, focal)
         ids = ids.contiguous().long()
         poses9 = L.f32c(poses9)
+        ctx.focal_shape = focal.shape
         focal = L.f32c(focal.reshape(1))
+        if uv is not None:
+            L.require_device(uv)
+            uv = L.f32c(uv)
+            if uv.shape != (ids.shape[0], 2):
+                raise L.RdrfError("generate_rays: uv must be [N,2] pixel coordinates")
         N, T = ids.shape[0], poses9.shape[0]
         rays = torch.empty(N, 6, device=ids.device)
-        L.check(L.lib.rdrf_generate_rays(L.ptr(ids), L.ptr(poses9), L.ptr(focal), N, T, H, W,
-                                         int(ndc), C.c_float(near), L.ptr(rays), L.stream_of(rays)),
+        L.check(L.lib.rdrf_generate_rays_uv(L.ptr(ids), L.ptr(uv), int(view_shift), L.ptr(poses9), L.ptr(focal), N, T,
+                                            H, W, int(ndc), C.c_float(near), L.ptr(rays), L.stream_of(rays)),
                 "rdrf_generate_rays")
-        ctx.meta = (H, W, int(ndc), float(near))
-        ctx.save_for_backward(ids, poses9, focal)
+        ctx.meta = (H, W, int(ndc), float(near), int(view_shift))
+        ctx.save_for_backward(ids, poses9, focal, uv)
         return rays
 
     @staticmethod
     def backward(ctx, g_rays):
-        ids, poses9, focal = ctx.saved_tensors
-        H, W, ndc, near = ctx.meta
+        ids, poses9, focal, uv = ctx.saved_tensors
+        H, W, ndc, near, shift = ctx.meta
         N, T = ids.shape[0], poses9.shape[0]
         g_rays = L.f32c(g_rays)
         gp = torch.zeros_like(poses9)
         gf = torch.zeros_like(focal)
-        L.check(L.lib.rdrf_generate_rays_bwd(L.ptr(ids), L.ptr(poses9), L.ptr(focal), N, T, H, W, ndc,
-                                             C.c_float(near), L.ptr(g_rays), L.ptr(gp), L.ptr(gf),
-                                             L.stream_of(g_rays)), "rdrf_generate_rays_bwd")
-        return None, gp, gf.reshape(()), None, None, None, None
+        L.check(L.lib.rdrf_generate_rays_uv_bwd(L.ptr(ids), L.ptr(uv), shift, L.ptr(poses9), L.ptr(focal), N, T, H, W,
+                                                ndc, C.c_float(near), L.ptr(g_rays), L.ptr(gp), L.ptr(gf),
+                                                L.stream_of(g_rays)), "rdrf_generate_rays_bwd")
+        return None, gp, gf.reshape(ctx.focal_shape), None, None, None, None, None, None
 
 
-def generate_rays(ray_idx, poses9, focal, H, W, ndc=True, near=1.0):
+def generate_rays(ray_idx, poses9, focal, H, W, ndc=True, near=1.0, uv=None, view_shift=0):
+    """rays[N,6] of the flat ray ids (train.py:1062-1077).  `uv` [N,2] replaces the pixel centres by
+    (column + 0.5 + flow_x, row + 0.5 + flow_y) and `view_shift` = +1 / -1 selects the next / previous
+    frame's camera (clamped), i.e. the flow-displaced rays of train.py:1433-1460, 1968-1990.  Differentiable
+    wrt poses9 [T,9] and focal (scalar or [1])."""
     focal = torch.as_tensor(focal, dtype=torch.float32, device=ray_idx.device)
-    return _RayGenFn.apply(ray_idx, poses9, focal, int(H), int(W), bool(ndc), float(near))
+    return _RayGenFn.apply(ray_idx, poses9, focal, int(H), int(W), bool(ndc), float(near), uv, int(view_shift))
 
 
 def ids2pixel(W, H, ids):

@@ -118,8 +118,8 @@ def tv_family(field, reg, planes, lines):
 
 
 # --------------------------------------------------------------------------------------------
-# regularisers that configs/Nvidia.txt leaves at weight 0 (DAVIS.txt uses density_L1): plain torch on
-# the device tensors, the same dense formulation as the reference -- not a hot path, no kernel.
+# regularisers that configs/Nvidia.txt leaves at weight 0 (DAVIS.txt uses density_L1).  vector_diffs is a
+# handful of (C x L)(L x C) products on the line tensors: plain torch.  dense_l1 is a kernel.
 # --------------------------------------------------------------------------------------------
 def vector_diffs(lines):
     """models/tensoRF.py:63-75: mean |off-diagonal| of the component Gram matrix of every line"""
@@ -133,10 +133,43 @@ def vector_diffs(lines):
     return total
 
 
+class _DenseL1Fn(torch.autograd.Function):
+    """mean |feature2density(sum_c plane x line)| over the grid through rdrf_dense_l1_fwd/bwd: no dense
+    volume is ever materialised (the reference builds a [1,24,X,Y,Z] tensor, models/tensoRF.py:80-98)."""
+
+    @staticmethod
+    def forward(ctx, field, *xs):
+        from .fields import _vm_struct
+        L.require_device(*xs)
+        planes, lines = xs[:3], xs[3:]
+        vm = _vm_struct(planes, lines)
+        out = torch.empty(1, device=xs[0].device)
+        L.check(L.lib.rdrf_dense_l1_fwd(C.byref(vm), L.ACTS[field.fea2denseAct], C.c_float(float(field.density_shift)),
+                                        L.ptr(out), L.stream_of(xs[0])), "rdrf_dense_l1_fwd")
+        ctx.field = field
+        ctx.save_for_backward(*xs)
+        nv = planes[0].shape[2] * planes[0].shape[3] * lines[0].shape[2]
+        return out[0] / nv
+
+    @staticmethod
+    def backward(ctx, g):
+        from .fields import _vm_struct
+        xs = ctx.saved_tensors
+        field = ctx.field
+        fused = field.fused_grad
+        if fused:
+            views = {p.data_ptr(): v for p, v in zip(field._param_list(), field.fused_grads())}
+            grads = [views[x.data_ptr()] for x in xs]
+        else:
+            grads = [torch.zeros_like(x) for x in xs]
+        vm, gvm = _vm_struct(xs[:3], xs[3:]), _vm_struct(grads[:3], grads[3:])
+        g = L.f32c(g.reshape(1))
+        L.check(L.lib.rdrf_dense_l1_bwd(C.byref(vm), C.byref(gvm), L.ACTS[field.fea2denseAct],
+                                        C.c_float(float(field.density_shift)), L.ptr(g), L.stream_of(xs[0])),
+                "rdrf_dense_l1_bwd")
+        return (None, *([None] * len(xs) if fused else grads))
+
+
 def dense_l1(field, planes, lines):
     """models/tensoRF.py:80-98 / 378-416: mean |feature2density(sum_c plane x line)| over the grid"""
-    p0, p1, p2 = (p[0] for p in planes)            # (C, H, W) logical views
-    l0, l1, l2 = (l[0, :, :, 0] for l in lines)    # (C, L)
-    f = (torch.einsum("cyx,cz->xyz", p0, l0) + torch.einsum("czx,cy->xyz", p1, l1)
-         + torch.einsum("czy,cx->xyz", p2, l2))
-    return field.feature2density(f).abs().mean()
+    return _DenseL1Fn.apply(field, *planes, *lines)

@@ -198,7 +198,10 @@ def render_frame(tensorf_static, tensorf, poses9, focal, frame, H, W, N_samples=
     rays = generate_rays(ids, poses9, focal, H, W, ndc=ray_type == "ndc", near=1.0)
     tv = (2.0 * frame / max(T - 1, 1) - 1.0) if t is None else float(t)
     ts = torch.full((H * W,), tv, device=dev)
-    chunk = H * W if not chunk else int(chunk)
+    S_ = int(N_samples) if N_samples and N_samples > 0 else tensorf.nSamples
+    if not chunk:   # whole frame in one launch sequence, bounded by the kernels' 32-bit sample indices
+        chunk = max(1, min(H * W, (2 ** 31 - 1) // (3 * S_) - 1))
+    chunk = int(chunk)
     rgb = torch.empty(H * W, 3, device=dev)
     depth = torch.empty(H * W, device=dev)
     for c0 in range(0, H * W, chunk):

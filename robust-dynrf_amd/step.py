@@ -1,69 +1,94 @@
-"""Minimal training / rendering step harness reproducing the pass structure of the reference's
-trainer for the hot path (/root/reference/train.py:1032-2325
-for ``configs/Nvidia.txt``: optimize_poses = 0).
+"""Training / rendering step harness reproducing the pass structure of the reference's trainer for the hot
+path (/root/reference/train.py:1032-2351).
 
-Per iteration, on the same ``batch_size`` rays:
+Per iteration, on the same ``batch_size`` rays (all configs):
 
     pass A  (rays, t)          static (value only) + dynamic (grad) + composite   train.py:1092-1162
     pass B  (rays, t_rand)     same                                              train.py:1166-1246
     scene-flow MLP on pass A's sample points                                     train.py:1319
-    pass C  (rays of frame t+1 through the flow-displaced pixel, t + 2/(T-1))    train.py:1433-1521
-    pass D  (frame t-1, t - 2/(T-1))                                             train.py:1530-1618
-    pass E  (rays, t)          static (grad)  + composite                        train.py:1756-1823
-    one backward through everything, one Adam step (betas 0.9/0.99)              train.py:2313-2325
+    pass C  (flow-displaced pixel in frame t+1, t + 2/(T-1))                     train.py:1433-1528
+    pass D  (frame t-1, t - 2/(T-1))                                             train.py:1530-1625
+    pass E  (rays WITH grad -> pose / focal)  static (grad) + dynamic (dead) + composite   train.py:1756-1823
 
-Liveness is exploited but results are unchanged: the static forwards of A-D
-are value-only, so they run without saving activations; in pass E only rgb_map_s / depth_map_s /
-weights_s are consumed and those do not depend on the dynamic field, so its (dead) evaluation is
-skipped and zeros are fed to the compositor in its place.  Unlike the reference loop there is no
-per-iteration host sync (``.item()``): losses stay on the device.
+and, with ``optimize_poses`` (configs/Nvidia_no_poses.txt, configs/DAVIS.txt), the static-only block
+train.py:1895-2311:
 
-The dataset (RGB, RAFT flow, DPT disparity, masks) is synthetic here: targets are random tensors
-of the right shape resident in HBM; the flow-displaced neighbour pixels of passes C/D are a second /
-third random ray-id batch.  The loss keeps the terms that determine which hot-path outputs carry
-gradient (image terms, dynamicness mask, disparity on depth maps, scene-flow magnitude and
-consistency terms), the induced flow / disparity-consistency terms through ``induce_flow``
-(train.py:1373-1413, 1511-1528), the distortion loss of the dynamic weights in passes A-D
-(distortion_weight_dynamic = 0.01) and the TV regularisers of all five factor families
-(TV_weight_density = TV_weight_app = 1.0) -- i.e. every hot-path consumer of configs/Nvidia.txt.
-Branches no loss reaches are not differentiated, as in the reference's autograd: passes B-D carry no
-RGB term, so the appearance backward (MLP, scatter, dW) runs for pass A and the static pass E only.
+    static induced flow of pass E's weights into frames t+-1 (poses / focal live)           :1895-1948
+    pass P1 / P2   static field along the flow-displaced rays of frames t+-1 (grad)         :1951-2095
+    per-frame median-normalised monocular depth loss of the static depth                    :2097-2121
+    pass P3 / P4   static (grad) + dynamic (dead) + composite on the x+1 / y+1 pixel rays   :2123-2311
+
+i.e. 5 dynamic + 5 static forwards (Nvidia.txt) or 7 dynamic + 9 static (no-poses / DAVIS), one backward,
+Adam on both fields (+ pose and focal Adam).  Every dynamic-field loss sees detached poses, focal and static
+outputs (train.py:1380-1625), every static-field loss is independent of the dynamic field, so the backward
+runs in two phases -- static first -- and the data-parallel exchange of the static gradients overlaps the
+dynamic backward (optim.FlatAdam.begin_exchange).
+
+The dataset (RGB, RAFT flow, DPT disparity, masks) is synthetic: random tensors of the right shape resident
+in HBM.  Losses keep every term that decides which hot-path outputs carry gradient; there is no
+per-iteration host sync (``.item()``): losses and the per-frame medians stay on the device.
 """
 import math
 
 import torch
+import torch.nn as nn
 
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
+from .optim import FlatAdam
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
 from .renderer import eff_distloss, induce_flow, raw2outputs, sampleXYZ
 
+NDC_AABB = [[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]]
 
-def balloon1_config(stage="stage0"):
-    """Synthetic Balloon1-shaped scene constants."""
-    cfg = dict(aabb=[[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]], near_far=[0.0, 1.0], T=12, H=135, W=240,
-               ray_type="ndc", batch_size=4096)
-    if stage == "stage0":
-        cfg.update(grid=[141, 157, 94], n_samples=115)
-    elif stage == "final":
-        cfg.update(grid=[331, 368, 220], n_samples=270)
-    elif stage == "huge":   # BASELINE.json configs[4]: N_voxel_final = 640^3
-        cfg.update(grid=[706, 786, 471], n_samples=578)
+
+def scene_config(name="nvidia", stage="stage0"):
+    """Synthetic scene constants shaped like the three shipped configs:
+    nvidia           configs/Nvidia.txt          Balloon1: NDC, GT poses, TV 1.0, grid 128^3 -> 300^3
+    nvidia_no_poses  configs/Nvidia_no_poses.txt NDC, pose + focal optimisation, grid 16^3 -> 640^3
+    davis            configs/DAVIS.txt           contracted rays, aabb +-2, T = 50, 16^3 -> 256^3, L1 + TV"""
+    if name == "nvidia":
+        cfg = dict(aabb=NDC_AABB, near_far=[0.0, 1.0], T=12, H=135, W=240, ray_type="ndc", batch_size=4096,
+                   static_head="MLP_Fea", optimize_poses=False, tv_density=1.0, tv_app=1.0, dist_static=0.0,
+                   dist_dynamic=0.01, l1_weight=0.0)
+        stages = {"stage0": ([141, 157, 94], 115), "final": ([331, 368, 220], 270), "huge": ([706, 786, 471], 578)}
+    elif name == "nvidia_no_poses":
+        cfg = dict(aabb=NDC_AABB, near_far=[0.0, 1.0], T=12, H=135, W=240, ray_type="ndc", batch_size=4096,
+                   static_head="MLP_Fea", optimize_poses=True, tv_density=0.0, tv_app=0.0, dist_static=0.01,
+                   dist_dynamic=0.01, l1_weight=0.0)
+        stages = {"stage0": ([17, 19, 11], 13), "final": ([706, 786, 471], 578), "huge": ([706, 786, 471], 578)}
+    elif name == "davis":
+        # DAVIS 480p frames (854 x 480) at downsample_train = 2; 50 frames; contracted rays to far = 256
+        cfg = dict(aabb=[[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]], near_far=[0.0, 256.0], T=50, H=240, W=427,
+                   ray_type="contract", batch_size=8192, static_head="MLP_Fea_TimeEmbedding", optimize_poses=True,
+                   tv_density=0.1, tv_app=0.01, dist_static=0.02, dist_dynamic=0.005, l1_weight=8e-5)
+        stages = {"stage0": ([16, 16, 16], 13), "final": ([256, 256, 256], 221)}
     else:
-        raise ValueError(stage)
+        raise ValueError(name)
+    if stage not in stages:
+        raise ValueError(f"{name}: stage must be one of {sorted(stages)}")
+    cfg["grid"], cfg["n_samples"] = stages[stage]
+    cfg.update(name=name, stage=stage, monodepth_static=0.04, monodepth_dynamic=0.04, n_iters=100000,
+               lr_decay_target_ratio=0.1)
     cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * math.sqrt(3.0)
     return cfg
 
 
+def balloon1_config(stage="stage0"):
+    """BASELINE.json configs[1] (kept name: the Nvidia.txt / Balloon1 shape)."""
+    return scene_config("nvidia", stage)
+
+
 def build_fields(cfg, device, seed=20211202):
-    """Both fields exactly as train.py:874-922 builds them for configs/Nvidia.txt."""
+    """Both fields exactly as train.py:874-922 builds them (static fea_pe = 2, dynamic fea_pe = 0)."""
     torch.manual_seed(seed)
     common = dict(density_n_comp=[16, 4, 4], appearance_n_comp=[48, 12, 12], app_dim=27,
                   near_far=cfg["near_far"], alphaMask_thres=1e-4, density_shift=-10,
                   distance_scale=25, pos_pe=6, view_pe=0, featureC=128, step_ratio=2.0,
                   fea2denseAct="relu")
     aabb = torch.tensor(cfg["aabb"], dtype=torch.float32)
-    st = TensorVMSplit(aabb, cfg["grid"], cfg["T"], device, shadingMode="MLP_Fea", fea_pe=2, **common)
+    st = TensorVMSplit(aabb, cfg["grid"], cfg["T"], device, shadingMode=cfg.get("static_head", "MLP_Fea"),
+                       fea_pe=2, **common)
     dy = TensorVMSplit_TimeEmbedding(aabb, cfg["grid"], cfg["T"], device,
                                      shadingMode="MLP_Fea_late_view", fea_pe=0, **common)
     return st, dy
@@ -74,7 +99,6 @@ def sparsify_(st, dy, cfg, device, target=0.10, n_probe=1024):
     shift of the dynamic density head's output bias, each found by bisection so that the measured
     app_mask fraction lands near `target` (trained-scene-like; the reference initialiser gives
     0.5-0.8).  The measured fractions are reported by bench.py and enter the roofline counts."""
-    from .ray_utils import generate_rays
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(0, cfg["T"] * cfg["H"] * cfg["W"], (n_probe,), generator=g).to(device)
     poses = torch.zeros(cfg["T"], 9, device=device)
@@ -113,8 +137,9 @@ def sparsify_(st, dy, cfg, device, target=0.10, n_probe=1024):
     return frac(st), frac(dy)
 
 
-class SyntheticBalloon:
-    """Synthetic dataset tensors, resident on the device."""
+class SyntheticScene:
+    """Synthetic dataset tensors, resident on the device (train.py:826-846, 953-990 keep the real ones
+    as flat (T*H*W, ...) tensors the same way)."""
 
     def __init__(self, cfg, device, seed=20211202):
         g = torch.Generator().manual_seed(seed)
@@ -146,151 +171,305 @@ class SyntheticBalloon:
         T, H, W = self.cfg["T"], self.cfg["H"], self.cfg["W"]
         return (ids // (H * W)).float() * (2.0 / (T - 1)) - 1.0
 
+    def make_batch(self, it, bs, shard=None):
+        """everything one iteration reads, as a dict of device tensors (train.py:1043-1060)"""
+        ids, ids2 = self.batch(it, bs, 0), self.batch(it, bs, 1)
+        if shard is not None:  # (rank, world): ray-sharded data parallelism
+            r, w = shard
+            lo, hi = r * bs // w, (r + 1) * bs // w
+            ids, ids2 = ids[lo:hi], ids2[lo:hi]
+        return dict(ids=ids, ts=self.ts_of(ids), ts_rand=self.ts_of(ids2), rgb=self.rgb[ids], disp=self.disp[ids],
+                    fg=self.fgmask[ids], flow_f=self.flow_f[ids], flow_b=self.flow_b[ids],
+                    mask_f=self.flow_mask_f[ids], mask_b=self.flow_mask_b[ids])
 
-def ray_pass(st, dy, rays, ts, n_samples, ray_type, is_train=True, static_grad=False,
-             dynamic=True, white=None):
-    """sampleXYZ -> static -> dynamic -> raw2outputs (one ray-pass)."""
-    xyz, z, valid = sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=is_train)
+
+SyntheticBalloon = SyntheticScene   # round-1 name
+
+
+class StepRng:
+    """The three random draws of an iteration that live OUTSIDE the kernels: the per-call sampling jitter
+    (models/tensorBase.py:492, 530-545), the white-background coin of raw2outputs (renderer.py:269).
+    Tests replace this object to replay fixed draws on the GPU and in the oracle."""
+
+    def __init__(self, seed=7):
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def coin(self):
+        return bool(torch.rand(1, generator=self.gen).item() < 0.5)
+
+    def jitter(self, S, ray_type, device):
+        if ray_type == "ndc":
+            return torch.rand(S, device=device), None
+        return torch.rand(S - S // 2 + 1, device=device), torch.rand(S // 2 + 1, device=device)
+
+
+def frame_median_depth_loss(pred, gt, frame, T, mask=None):
+    """train.py:797-807 compute_depth_loss summed over the frames of the batch and divided by the number of
+    rays used (train.py:1636-1664, 2097-2121): per frame k with more than one ray,
+    sum(((p - med p) / (mean|p - med p| + 1e-10) - (g - med g) / (mean|g - med g| + 1e-10))^2).
+    The reference loops over the frames on the host with a sync per frame; here the per-frame medians
+    come from one segmented sort on the device (torch.median = the lower middle element)."""
+    N = pred.shape[0]
+    dev = pred.device
+    seg = frame if mask is None else torch.where(mask, frame, torch.full_like(frame, T))
+    nseg = T + 1
+    ones = torch.ones(N, device=dev)
+    counts = torch.zeros(nseg, device=dev).scatter_add_(0, seg, ones)
+    starts = torch.cumsum(counts, 0) - counts
+    pos = (starts + torch.div((counts - 1).clamp(min=0), 2, rounding_mode="floor")).long().clamp(max=N - 1)
+
+    def normalise(x):
+        i1 = torch.argsort(x.detach())
+        i2 = torch.argsort(seg[i1], stable=True)
+        order = i1[i2]                      # sorted by (segment, value)
+        med = x[order][pos]                 # [nseg]; gradient goes to the median element, as torch.median
+        dev_ = x - med[seg]
+        s = torch.zeros(nseg, device=dev).scatter_add(0, seg, dev_.abs()) / counts.clamp(min=1)
+        return dev_ / (s[seg] + 1e-10)
+
+    use = ((counts[seg] > 1) & (seg < T)).float()
+    sq = (normalise(pred) - normalise(gt)) ** 2
+    return (sq * use).sum() / use.sum()
+
+
+def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_grad=False, dynamic=True):
+    """sampleXYZ -> static -> dynamic -> raw2outputs (one ray-pass).  The static field runs value-only unless
+    `static_grad`; with dynamic=False (dead work of passes E / P3 / P4 skipped) zeros stand in for the dynamic
+    outputs, which the static maps do not depend on."""
+    jit, jit_o = rng.jitter(n_samples, ray_type, rays.device) if is_train else (None, None)
+    xyz, z, valid = sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=is_train, jitter=jit,
+                              jitter_outer=jit_o)
     if static_grad:
         o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
-        rgb_s, sigma_s = o_s[6], o_s[7]
     else:
         with torch.no_grad():
             o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
-        rgb_s, sigma_s = o_s[6], o_s[7]
-    if dynamic:
+    rgb_s, sigma_s = o_s[6], o_s[7]
+    if dynamic:   # in passes E / P3 / P4 this evaluation is dead work the reference performs (autograd graph and all)
         o_d = dy(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
         rgb_d, sigma_d, dists, blending, zv = o_d[6], o_d[7], o_d[9], o_d[2], o_d[8]
-    else:  # dead work in pass E: the static outputs do not depend on these
+    else:
         o_d = None
         rgb_d = torch.zeros_like(rgb_s)
         sigma_d = torch.zeros_like(sigma_s)
         blending = torch.zeros_like(sigma_s)
         dists, zv = o_s[9], z
+    white = rng.coin() if is_train else False
     outs = raw2outputs(rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, zv, rays, is_train=is_train,
                        ray_type=ray_type, add_white_bg=white)
     return o_s, o_d, outs, xyz
 
 
+def masked_mean(x, m):
+    return (x * m).sum() / (m.sum() + 1e-8)
+
+
 class Trainer:
-    def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False):
-        """dead_work: also run pass E's dynamic-field forward, which the reference computes although
-        nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical."""
+    def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False,
+                 dp_mode="allreduce", lr_pose=3e-3):
+        """dead_work: also run the dynamic-field forward of passes E / P3 / P4, which the reference computes
+        although nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical."""
         self.dead_work = dead_work
         self.cfg = cfg
         self.device = device
         self.st, self.dy = build_fields(cfg, device)
         if weights == "sparse":
             sparsify_(self.st, self.dy, cfg, device)
-        self.data = SyntheticBalloon(cfg, device)
-        groups = self.st.get_optparam_groups(lr_init, lr_basis) + self.dy.get_optparam_groups(lr_init, lr_basis)
-        # the reference keeps 6 + 18 groups but only two learning rates (and scales every group by the
-        # same lr_factor each iteration, train.py:2608-2612): one group per lr is the same optimiser
-        # with 4 fused multi-tensor launches per step instead of 48
-        merged = {}
-        for g_ in groups:
-            merged.setdefault(g_["lr"], []).extend(list(g_["params"]))
-        groups = [{"params": ps, "lr": lr} for lr, ps in merged.items()]
-        try:
-            self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)
-        except Exception:
-            self.opt = torch.optim.Adam(groups, betas=(0.9, 0.99))
+        self.data = SyntheticScene(cfg, device)
+        lr_factor = cfg.get("lr_decay_target_ratio", 0.1) ** (1.0 / cfg.get("n_iters", 100000))   # train.py:926-930
+        self.opt = FlatAdam([self.st, self.dy], lr_init, lr_basis, betas=(0.9, 0.99), lr_factor=lr_factor,
+                            mode=dp_mode)
+        self.optimize_poses = bool(cfg.get("optimize_poses", False))
+        if self.optimize_poses:   # train.py:972-1009: 6-D pose table + field of view, their own Adam
+            self.poses = nn.Parameter(self.data.poses.clone())
+            self.fov = nn.Parameter(torch.full((1,), 30.0 / 180.0 * math.pi, device=device))
+            self.opt_pose = torch.optim.Adam([self.poses], lr=lr_pose)
+            self.opt_focal = torch.optim.Adam([self.fov], lr=lr_pose)
         self.it = 0
-        self.coin = torch.Generator().manual_seed(7)
+        self.rng = StepRng()
         self.tv = TVLoss()
-        # backward passes accumulate straight into p.grad (views of one flat buffer per field)
-        self.st.fused_grad = self.dy.fused_grad = True
-        self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
+        self.grad_flats = self.opt.grad_flats()
+        self.last = {}
 
-    def rays_for(self, ids):
+    # ---- geometry ----------------------------------------------------------------------------------
+    def focal(self):
+        if self.optimize_poses:   # train.py:1038-1041
+            return max(self.cfg["H"], self.cfg["W"]) / 2.0 / torch.tan(self.fov[0])
+        return self.data.focal
+
+    def pose_table(self):
+        return self.poses if self.optimize_poses else self.data.poses
+
+    def rays_for(self, ids, poses=None, focal=None, uv=None, view_shift=0):
         c = self.cfg
-        return generate_rays(ids, self.data.poses, self.data.focal, c["H"], c["W"], ndc=c["ray_type"] == "ndc",
-                             near=1.0)
+        poses = self.pose_table() if poses is None else poses
+        focal = self.focal() if focal is None else focal
+        return generate_rays(ids, poses, focal, c["H"], c["W"], ndc=c["ray_type"] == "ndc", near=1.0, uv=uv,
+                             view_shift=view_shift)
 
-    def step(self, shard=None):
-        """One Nvidia.txt-shaped iteration on this rank's shard of the batch. Returns the loss
-        tensor (device)."""
-        c, d = self.cfg, self.data
-        bs, S, rt = c["batch_size"], c["n_samples"], c["ray_type"]
-        it = self.it
-        ids, ids2, ids3 = d.batch(it, bs, 0), d.batch(it, bs, 1), d.batch(it, bs, 2)
-        if shard is not None:  # (rank, world): ray-sharded data parallelism
-            r, w = shard
-            lo, hi = r * bs // w, (r + 1) * bs // w
-            ids, ids2, ids3 = ids[lo:hi], ids2[lo:hi], ids3[lo:hi]
-        ts = d.ts_of(ids)
-        rgb_t, disp_t, fg = d.rgb[ids], d.disp[ids], d.fgmask[ids]
-        rays = self.rays_for(ids)
-        dt = 2.0 / (c["T"] - 1)
-        coin = lambda: bool(torch.rand(1, generator=self.coin).item() < 0.5)
-        loss = 0.0
+    # ---- one iteration -----------------------------------------------------------------------------
+    def losses(self, b):
+        """forward of one iteration on batch `b`; returns (loss_dynamic, loss_static, tv_dynamic, tv_static):
+        the two loss groups have disjoint parameter ancestries (dynamic field | static field + pose + focal)."""
+        c = self.cfg
+        S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
+        it, rng = self.it, self.rng
+        ids, ts, rgb_t, disp_t, fg = b["ids"], b["ts"], b["rgb"], b["disp"], b["fg"]
+        N = ids.shape[0]
+        poses, focal = self.pose_table(), self.focal()
+        rays = self.rays_for(ids, poses, focal)           # with grad when the poses / focal are trained
+        rays_d = rays.detach()
+        poses_d, focal_d = poses.detach(), (focal.detach() if torch.is_tensor(focal) else focal)
+        dt = 2.0 / (T - 1)
+        col, row, view = ids2pixel(W, H, ids)
+        grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+        c2w_all = pose_to_mtx(poses)
+        temp = 1.0 / (10 ** (it // 100000))                # Temp / Temp_disp_TV / Temp_static, train.py:1034-1036
+        temp_static = 1.0 / (10 ** (it / 100000.0))
+        gt_depth = -disp_t if rt == "ndc" else disp_t      # train.py:1645-1653
+        to_depth = (lambda d: d) if rt == "ndc" else (lambda d: 1.0 / (d + 1e-6))
+        loss_d = 0.0
         # ---- pass A
-        _, oA, outA, xyzA = ray_pass(self.st, self.dy, rays, ts, S, rt, white=coin())
-        loss = loss + 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
-        loss = loss + 0.1 * (outA[12] - fg).abs().mean()
-        loss = loss + 0.04 * (outA[9] - disp_t).abs().mean()
-        # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716;
-        # configs/Nvidia.txt distortion_weight_dynamic = 0.01, ramped by iteration / n_iters)
-        w_dist = 0.01 * min(1.0, (it + 1) / 100000.0)
-        loss = loss + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
+        _, oA, outA, _ = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
+        loss_d = loss_d + 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
+        loss_d = loss_d + 0.1 * (outA[12] - fg).abs().mean()
+        loss_d = loss_d + c["monodepth_dynamic"] * temp * frame_median_depth_loss(to_depth(outA[9]), gt_depth, view, T)
+        # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters
+        w_dist = c["dist_dynamic"] * min(1.0, (it + 1) / c["n_iters"])
+        loss_d = loss_d + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
         # ---- pass B (second random time)
-        ts_b = d.ts_of(ids2)
-        _, oB, outB, _ = ray_pass(self.st, self.dy, rays, ts_b, S, rt, white=coin())
-        loss = loss + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
-        loss = loss + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
+        _, oB, outB, _ = ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
+        loss_d = loss_d + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+        loss_d = loss_d + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
         w_d = outA[11].detach()[..., None]
-        loss = loss + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
-        loss = loss + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
+        loss_d = loss_d + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
+        loss_d = loss_d + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
         # ---- induced flow of the dynamic field into the neighbour frames (train.py:1373-1413)
-        H, W, T = c["H"], c["W"], c["T"]
-        col, row, view = ids2pixel(W, H, ids)
-        grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
-        c2w_all = pose_to_mtx(d.poses)
         weights_d, pts_ref = outA[11], oA[3]
         disp_A = {}
-        for sgn, sf, flow_t, mask_t in ((1, sf_f, d.flow_f[ids], d.flow_mask_f[ids]),
-                                        (-1, sf_b, d.flow_b[ids], d.flow_mask_b[ids])):
+        for sgn, sf, flow_t, mask_t in ((1, sf_f, b["flow_f"], b["mask_f"]), (-1, sf_b, b["flow_b"], b["mask_b"])):
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
-            ind_flow, ind_disp = induce_flow(H, W, d.focal, pose_n, weights_d, pts_ref + sf, grid,
-                                             rays.detach(), ray_type=rt)
-            loss = loss + 0.02 * ((ind_flow - flow_t).abs() * mask_t).sum() / (mask_t.sum() + 1e-8) / 2.0
-            disp_A[sgn] = (ind_disp, mask_t, pose_n)
-        # ---- pass C / D: neighbour frames (train.py:1433-1528, 1530-1625): disparity consistency
-        for ids_n, sgn in ((ids2, 1), (ids3, -1)):
-            rays_n = self.rays_for(ids_n).detach()
-            ts_n = (ts + sgn * dt).clamp(-1.0, 1.0)
-            _, oN, outN, xyzN = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, white=coin())
-            ind_disp, mask_t, pose_n = disp_A[sgn]
-            _, ind_disp_n = induce_flow(H, W, d.focal, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
-            loss = loss + 0.04 * ((ind_disp - ind_disp_n).abs() * mask_t).sum() / (mask_t.sum() + 1e-8)
-            loss = loss + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
-        # ---- pass E: static field with gradient
-        _, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, static_grad=True,
-                                 dynamic=self.dead_work, white=coin())
+            pts_n = pts_ref + sf if rt == "ndc" else torch.clamp(pts_ref + sf, min=-2.0 + 1e-6, max=2.0 - 1e-6)
+            ind_flow, ind_disp = induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, grid, rays_d, ray_type=rt)
+            loss_d = loss_d + 0.02 * temp * masked_mean((ind_flow - flow_t).abs(), mask_t) / 2.0
+            disp_A[sgn] = (ind_disp, mask_t, pose_n, flow_t)
+        # ---- pass C / D: the flow-displaced rays of the neighbour frames (train.py:1433-1528, 1530-1625)
+        for sgn in (1, -1):
+            ind_disp, mask_t, pose_n, flow_t = disp_A[sgn]
+            rays_n = self.rays_for(ids, poses_d, focal_d, uv=grid + flow_t, view_shift=sgn)
+            ts_n = ts + sgn * dt
+            _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, rng)
+            _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
+            loss_d = loss_d + 0.04 * temp * masked_mean((ind_disp - ind_disp_n).abs(), mask_t)
+            loss_d = loss_d + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
+        # ---- pass E: static field with gradient, rays with gradient (pose / focal)
+        oE, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
         m = (1.0 - fg)[:, None]
-        loss = loss + (((outE[4] - rgb_t) ** 2) * m).sum() / (m.sum() + 1e-8) / 3.0
-        loss = loss + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
-        # ---- TV regularisers of every factor family (train.py:1735-1754, 1872-1885;
-        #      configs/Nvidia.txt: TV_weight_density = TV_weight_app = 1.0).  The VALUE is NaN in the
-        #      reference (line tensors have count_w = 0) while the gradients are finite, so it is
-        #      kept out of the reported loss and only its gradient is taken, by a second backward.
-        tvl = (self.dy.TV_loss_density(self.tv) + self.dy.TV_loss_blending(self.tv)
-               + self.dy.TV_loss_app(self.tv) + self.st.TV_loss_density(self.tv)
-               + self.st.TV_loss_app(self.tv))
-        self.grad_flats = [self.st.zero_grad_fused(), self.dy.zero_grad_fused()]
-        loss.backward()
-        tvl.backward()
-        return loss
+        loss_s = masked_mean((outE[4] - rgb_t) ** 2, m) / 3.0
+        if not self.optimize_poses:    # stand-in for the static depth supervision of the GT-pose configs
+            loss_s = loss_s + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
+        if c["dist_static"] > 0:       # train.py:1841-1861
+            loss_s = loss_s + c["dist_static"] * (it / c["n_iters"]) * eff_distloss(outE[7], oE[8].detach(), 1.0 / S)
+        if self.optimize_poses:
+            loss_s = loss_s + self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static,
+                                               gt_depth, to_depth)
+        # ---- factor-space regularisers (train.py:1718-1754, 1863-1885)
+        if c["l1_weight"] > 0:
+            loss_d = loss_d + c["l1_weight"] * self.dy.density_L1()
+            loss_s = loss_s + c["l1_weight"] * self.st.density_L1()
+        # TV: the VALUE is NaN in the reference (line tensors have count_w = 0) while the gradients are finite,
+        # so it is kept out of the reported loss and only its gradient is taken, by its own backward
+        tv_d = tv_s = None
+        if c["tv_density"] > 0 or c["tv_app"] > 0:
+            tv_d = (c["tv_density"] * (self.dy.TV_loss_density(self.tv) + self.dy.TV_loss_blending(self.tv))
+                    + c["tv_app"] * self.dy.TV_loss_app(self.tv))
+            tv_s = c["tv_density"] * self.st.TV_loss_density(self.tv) + c["tv_app"] * self.st.TV_loss_app(self.tv)
+        return loss_d, loss_s, tv_d, tv_s
+
+    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static, gt_depth, to_depth):
+        """train.py:1895-2311 (optimize_poses): every term reaches the static field, the poses and the focal."""
+        c = self.cfg
+        S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
+        ids, ts, fg = b["ids"], b["ts"], b["fg"]
+        rng = self.rng
+        loss = 0.0
+        weights_s, pts_ref_s, depth_s = outE[7], oE[3], outE[5]
+        for sgn, flow_t, mask_t in ((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"])):
+            pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]                       # live: allposes_refine_f / _b
+            mm = mask_t * m
+            ind_flow, ind_disp = induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, grid, rays, ray_type=rt)
+            loss = loss + 0.02 * temp_static * masked_mean((ind_flow - flow_t).abs(), mm) / 2.0
+            # P1 / P2: the static field along the flow-displaced ray of the neighbour frame
+            rays_n = self.rays_for(ids, poses, focal, uv=grid + flow_t, view_shift=sgn)
+            jit, jit_o = rng.jitter(S, rt, rays.device)
+            xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
+            o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
+            _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, ray_type=rt)
+            loss = loss + 0.04 * temp_static * masked_mean((ind_disp - ind_disp_n).abs(), mm)
+        # per-frame median-normalised monocular depth of the static field on the background rays
+        loss = loss + c["monodepth_static"] * temp_static * frame_median_depth_loss(to_depth(depth_s), gt_depth, view, T,
+                                                                                    mask=fg < 0.5)
+        # P3 / P4: disparity smoothness against the x+1 / y+1 pixel neighbours (train.py:2123-2311)
+        col, row = grid[:, 0], grid[:, 1]
+        inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)
+        sm = 0.0
+        for uv_n in (torch.stack([torch.clamp(col + 1.0, max=W - 0.5), row], -1),
+                     torch.stack([col, torch.clamp(row + 1.0, max=H - 0.5)], -1)):
+            rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
+            _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
+            sm = sm + ((inv_d - 1.0 / torch.clamp(outN[5], min=1e-6)) ** 2).mean()
+        return loss + 50.0 * temp * sm
+
+    def step(self, shard=None):
+        """One iteration on this rank's shard of the batch: forward of every pass, two-phase backward (static
+        group first; its gradient exchange starts while the dynamic group is still differentiating).
+        Returns the loss tensor (device, no sync)."""
+        b = self.data.make_batch(self.it, self.cfg["batch_size"], shard)
+        loss_d, loss_s, tv_d, tv_s = self.losses(b)
+        self.opt.zero_grad()
+        if self.optimize_poses:
+            self.poses.grad = None
+            self.fov.grad = None
+        loss_s.backward()
+        if tv_s is not None:
+            tv_s.backward()
+        self.opt.begin_exchange(0)           # static field: complete
+        loss_d.backward()
+        if tv_d is not None:
+            tv_d.backward()
+        self.opt.begin_exchange(1)
+        self.last = dict(loss_dynamic=loss_d.detach(), loss_static=loss_s.detach())
+        return (loss_d + loss_s).detach()
 
     def finish_step(self):
+        if self.optimize_poses:
+            if self.opt.world > 1:   # the pose / focal gradients are a [T*9 + 1] vector: one tiny all-reduce
+                import torch.distributed as dist
+                buf = torch.cat([self.poses.grad.reshape(-1), self.fov.grad.reshape(-1)])
+                dist.all_reduce(buf)
+                buf /= self.opt.world
+                self.poses.grad.copy_(buf[:-1].view_as(self.poses))
+                self.fov.grad.copy_(buf[-1:])
+            self.opt_pose.step()
+            self.opt_focal.step()
         self.opt.step()
         self.it += 1
+
+    def upsample(self, grid, n_samples=None):
+        """train.py:2582-2606: both fields to the new grid, a NEW Adam (moments dropped)."""
+        self.st.upsample_volume_grid(grid)
+        self.dy.upsample_volume_grid(grid)
+        self.cfg["grid"] = list(grid)
+        if n_samples is not None:
+            self.cfg["n_samples"] = int(n_samples)
+        self.opt.rebuild()
+        self.grad_flats = self.opt.grad_flats()
 
 
 @torch.no_grad()
 def render_chunk(st, dy, rays, ts, n_samples, ray_type="ndc"):
     """renderer.py:740-812 loop body (no-grad eval pass): returns rgb_map_full, depth_map_full."""
-    _, _, outs, _ = ray_pass(st, dy, rays, ts, n_samples, ray_type, is_train=False, white=False)
+    _, _, outs, _ = ray_pass(st, dy, rays, ts, n_samples, ray_type, StepRng(), is_train=False)
     return outs[0], outs[1]

@@ -26,7 +26,21 @@ def load_case(name):
     return g, sd_s, cfg_s, sd_d, cfg_d
 
 
-def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None, atol=0.0):
+def elementwise_excess(a, b, elem_rtol, elem_atol_frac):
+    """max over the elements of |a-b| / (elem_rtol |b| + elem_atol_frac max|b|): <= 1 means every element
+    satisfies |err| <= rtol |ref| + atol, with atol tied to the tensor's scale"""
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    if a.numel() == 0:
+        return 0.0
+    scale = max(float(b.abs().max()), 1e-30)
+    return float(((a - b).abs() / (elem_rtol * b.abs() + elem_atol_frac * scale)).max())
+
+
+def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None, atol=0.0, elem=None):
+    """max-norm check: max|a-b| <= rtol * max|b| (* atol_scale) + atol.  elem = (elem_rtol, elem_atol_frac)
+    adds the element-wise check |a-b| <= elem_rtol |b| + elem_atol_frac max|b| for EVERY element: small
+    entries of a gradient must be right in relative terms too, up to the accumulation noise floor."""
     a = torch.as_tensor(a).detach().cpu().double()
     b = torch.as_tensor(b).detach().cpu().double()
     assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -39,3 +53,7 @@ def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None, atol=0.0):
     err = float((a - b).abs().max())
     assert err <= rtol * scale * atol_scale + atol + 1e-30, (
         f"{name}: max abs err {err:.3e} > {rtol * atol_scale:.1e} * max|ref| ({scale:.3e})")
+    if elem is not None:
+        ex = elementwise_excess(a, b, elem[0], elem[1])
+        assert ex <= 1.0, (f"{name}: element-wise |err| exceeds {elem[0]:.0e} |ref| + {elem[1]:.0e} max|ref| by a "
+                           f"factor {ex:.2f}")

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import CASES, assert_close
+from _util import CASES, assert_close, elementwise_excess
 
 pytestmark = pytest.mark.gpu
 
@@ -62,12 +62,17 @@ def test_golden_gradients(case):
     assert not bad, "\n".join(bad)
 
 
-def _midsize_once(seed, loss_kind="full", rt="ndc"):
+def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26), rtol=2e-4, elem=None):
+    """HIP backward vs the oracle's autograd on seeded weights.  Deterministic treatment of the
+    non-differentiable points: rays with a sample within 4e-6 of a relu kink of any MLP, of the density
+    activation's kink, of the app-mask threshold or of a compositor clamp (tests/_gpu_util.kink_free_rays)
+    get loss weight 0 on BOTH sides, so a 1-ulp GPU / CPU difference cannot flip a branch; every other
+    ray must match."""
     import rodynrf
-    from _gpu_util import COMMON, make_rays, oracle_cfg, oracle_sd
+    from _gpu_util import COMMON, kink_free_rays, make_rays, oracle_cfg, oracle_sd
     from oracle import rodynrf_oracle as O
     torch.manual_seed(seed)
-    N, S, grid = 96, 70, [40, 44, 26]
+    grid = list(grid)
     contract = rt == "contract"   # configs/DAVIS.txt shape of things: aabb +-2, softplus, TimeEmbedding head
     aabb = torch.tensor([[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]] if contract else [[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]])
     nf = [0.05, 256.0] if contract else [0.0, 1.0]
@@ -93,37 +98,39 @@ def _midsize_once(seed, loss_kind="full", rt="ndc"):
     r_d = O.field_forward(sd_d, cfg_d, rays, ts, xyz, z, valid, rt, dynamic=True)
     r_o = O.raw2outputs(r_s[6], r_s[7], r_d[6], r_d[7], r_d[9], r_d[2], r_d[8], rays, True, rt)
     sf = O.scene_flow(sd_d, aabb, r_d[3], ts)
+    keep = kink_free_rays(O, sd_s, cfg_s, sd_d, cfg_d, rays, ts, xyz, z, valid, rt, r_s, r_d, r_o)
+    assert float(keep.float().mean()) > 0.5, "too many rays excluded: the kink margin is mis-calibrated"
+    wr = keep.float()
 
-    def loss(outs, sf, t):  # the three image terms of train.py:1323-1332,1827-1835 + extras
+    def loss(outs, sf, t, w):  # the three image terms of train.py:1323-1332,1827-1835 + extras, per-ray weighted
+        n = w.numel()
+        rm = lambda x: (x * w.view(-1, *([1] * (x.dim() - 1)))).sum() / (n * max(1, x[0].numel()))
         if loss_kind == "no_rgb":   # passes B-D of the trainer: only weights / depths / dynamicness
-            return (0.1 * outs[12].mean() + 0.05 * outs[9].mean() + (outs[11] ** 2).sum()
-                    + 0.01 * (sf[0] ** 2).mean())
-        return (3 * ((outs[0] - t) ** 2).mean() + ((outs[8] - t) ** 2).mean() + ((outs[4] - t) ** 2).mean()
-                + 0.1 * outs[12].mean() + 0.05 * outs[9].mean() + 0.01 * (sf[0] ** 2).mean()
-                + 0.01 * (sf[1] ** 2).mean())
+            return (0.1 * rm(outs[12]) + 0.05 * rm(outs[9]) + n * S * rm(outs[11] ** 2) + 0.01 * rm(sf[0] ** 2))
+        return (3 * rm((outs[0] - t) ** 2) + rm((outs[8] - t) ** 2) + rm((outs[4] - t) ** 2)
+                + 0.1 * rm(outs[12]) + 0.05 * rm(outs[9]) + 0.01 * rm(sf[0] ** 2) + 0.01 * rm(sf[1] ** 2))
 
-    Lr = loss(r_o, sf, tgt)
+    Lr = loss(r_o, sf, tgt, wr)
     ks, kd = list(sd_s.keys()), list(sd_d.keys())
     gref = torch.autograd.grad(Lr, [sd_s[k] for k in ks] + [sd_d[k] for k in kd], allow_unused=True)
     dev = "cuda"
     cr, ct = rays.to(dev), ts.to(dev)
-    # the samples come from the GPU sampler too (same jitter): sampleXYZ parity at this size
+    # the samples come from the GPU sampler too (same jitter): sampleXYZ parity at this size, bit-exact
     gx, gz, gv = rodynrf.sampleXYZ(dy, cr, S, ray_type=rt, is_train=True, jitter=jit.to(dev),
                                    **({"jitter_outer": jit_o.to(dev)} if contract else {}))
-    assert_close(gx, xyz, "xyz", rtol=1e-5)
-    assert_close(gz, z, "z", rtol=1e-5)
-    assert bool((gv.cpu() == valid).all())
+    assert torch.equal(gz.cpu(), z) and bool((gv.cpu() == valid).all())
+    assert_close(gx, xyz, "xyz", rtol=1e-6)
     o_s = st(cr, ct, None, xyz.to(dev), z.to(dev), valid.to(dev), ray_type=rt)
     o_d = dy(cr, ct, None, xyz.to(dev), z.to(dev), valid.to(dev), ray_type=rt)
     outs = rodynrf.raw2outputs(o_s[6], o_s[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], cr,
                                is_train=True, ray_type=rt, add_white_bg=True)
     sfg = dy.get_forward_backward_scene_flow(o_d[3], ct)
-    Lg = loss(outs, sfg, tgt.to(dev))
+    Lg = loss(outs, sfg, tgt.to(dev), wr.to(dev))
     assert_close(Lg, Lr, "loss", rtol=1e-4)
     Lg.backward()
     own = {"gs." + k: v for k, v in st.named_parameters()}
     own.update({"gd." + k: v for k, v in dy.named_parameters()})
-    bad, worst_l2 = [], 0.0
+    bad, worst_l2, worst_el = [], 0.0, 0.0
     for name, gr in zip(["gs." + k for k in ks] + ["gd." + k for k in kd], gref):
         if gr is None:
             # a branch no loss reaches: autograd gives the reference no gradient, and ours must not
@@ -134,43 +141,44 @@ def _midsize_once(seed, loss_kind="full", rt="ndc"):
         a = own[name].grad.detach().cpu().double()
         b = gr.double()
         worst_l2 = max(worst_l2, float((a - b).norm() / b.norm().clamp_min(1e-30)))
+        if elem is not None:
+            worst_el = max(worst_el, elementwise_excess(a, b, *elem))
         try:
-            assert_close(a, b, name, rtol=2e-4)
+            assert_close(a, b, name, rtol=rtol, elem=elem)
         except AssertionError as e:
             bad.append(str(e))
+    print(f"seed {seed} {rt} N={N} S={S} grid={grid}: kept {int(keep.sum())}/{N} rays, worst rel. L2 {worst_l2:.2e}, "
+          f"element-wise excess {worst_el:.2f}")
     return bad, worst_l2
 
 
-def test_oracle_gradients_midsize():
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_oracle_gradients_midsize(seed):
     """N=96 rays x S=70 samples on a 40x44x26 grid, seeded weights, against the oracle's autograd
-    (multi-tile rays, ragged last tile, partially-filled compacted tiles).
-
-    ReLU kinks: with ~1e6 hidden pre-activations per run, one within an ulp of 0 can legitimately
-    get a different relu mask on the GPU than on the CPU; that single sample then changes sparse
-    plane gradients by ~1e-3 of their max.  So: every seed must stay within 2e-2 in relative L2
-    (a real bug does not), and at least one of three seeds must match element-wise at 2e-4."""
-    msgs = []
-    for seed in (5, 6, 7):
-        bad, l2 = _midsize_once(seed)
-        assert l2 < 2e-2, f"seed {seed}: relative L2 error {l2:.2e}\n" + "\n".join(bad)
-        if not bad:
-            return
-        msgs.append(f"seed {seed}: " + "; ".join(bad))
-    raise AssertionError("no seed matched element-wise:\n" + "\n".join(msgs))
+    (multi-tile rays, ragged last tile, partially-filled compacted tiles): EVERY seed must match, max-norm
+    2e-4 and element-wise |err| <= 2e-3 |ref| + 4e-5 max|ref| for every entry of every gradient."""
+    from _gpu_util import ELEM
+    bad, l2 = _midsize_once(seed, elem=ELEM)
+    assert not bad and l2 < 1e-3, f"relative L2 error {l2:.2e}\n" + "\n".join(bad)
 
 
-def test_oracle_gradients_midsize_contract():
-    """same as above for the DAVIS-style path: contracted sampling (aabb +-2, far 256), softplus
-    density, MLP_Fea_TimeEmbedding static head.  The far-depth fill makes depth maps O(256): the
-    loss tolerance is relative to that."""
-    msgs = []
-    for seed in (5, 6, 7):
-        bad, l2 = _midsize_once(seed, "full", "contract")
-        assert l2 < 2e-2, f"seed {seed}: relative L2 error {l2:.2e}\n" + "\n".join(bad)
-        if not bad:
-            return
-        msgs.append(f"seed {seed}: " + "; ".join(bad))
-    raise AssertionError("no seed matched element-wise:\n" + "\n".join(msgs))
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_oracle_gradients_midsize_contract(seed):
+    """same for the DAVIS-style path: contracted sampling (aabb +-2, far 256), softplus density,
+    MLP_Fea_TimeEmbedding static head."""
+    from _gpu_util import ELEM
+    bad, l2 = _midsize_once(seed, "full", "contract", elem=ELEM)
+    assert not bad and l2 < 1e-3, f"relative L2 error {l2:.2e}\n" + "\n".join(bad)
+
+
+@pytest.mark.parametrize("N,S,grid", [(64, 115, (141, 157, 94)), (40, 270, (331, 368, 220))])
+def test_oracle_gradients_benchmark_grids(N, S, grid):
+    """gradients (not only forwards) on the two grids the benchmark runs -- Balloon1 stage 0 [141,157,94] /
+    S=115 and final [331,368,220] / S=270: the scatter's run merging, quad transposition and LDS line
+    accumulators depend on the grid size (at 331x368x220 the appearance lines take the 512-thread path)."""
+    from _gpu_util import ELEM
+    bad, l2 = _midsize_once(3, N=N, S=S, grid=grid, elem=ELEM)
+    assert not bad and l2 < 1e-3, f"relative L2 error {l2:.2e}\n" + "\n".join(bad)
 
 
 def test_pruned_branches_match_autograd():

@@ -67,3 +67,101 @@ def test_gradient_allreduce_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def _ref_adam(p, g, m, v, t, lr_of, b1=0.9, b2=0.99, eps=1e-8):
+    """torch.optim.Adam's update, element-wise (the arithmetic rdrf_adam_step implements)"""
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = v.sqrt() / (1 - b2 ** t) ** 0.5 + eps
+    p.sub_(lr_of / (1 - b1 ** t) * m / denom)
+
+
+def _worker_exchange(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    P = importlib.import_module("robust-dynrf_amd.parallel")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    P.init_distributed("gloo")
+    totals = [4096, 8192]
+    split = [1024, 4096 + 640]         # lr boundary inside the second buffer's second shard
+    gen = torch.Generator().manual_seed(0)
+    p0 = [torch.randn(t, generator=gen) for t in totals]
+    grads = [[torch.randn(t, generator=gen) for t in totals] for _ in range(world)]   # per rank
+    results = {}
+    for mode in ("allreduce", "zero1"):
+        ex = P.FlatExchange(totals, mode)
+        assert ex.mode == mode and ex.world == world
+        params = [p.clone() for p in p0]
+        moms = [(torch.zeros(ex.slice(i)[1]), torch.zeros(ex.slice(i)[1])) for i in range(2)]
+        for step in range(1, 4):
+            g_local = [g.clone() * step for g in grads[rank]]
+            ex.begin(0, g_local[0])              # early start of buffer 0 (static field), async
+            works = []
+            for i in range(2):
+                g, lo, n = ex.grads(i, g_local[i])
+                lr = torch.where(torch.arange(lo, lo + n) < split[i], 0.02, 1e-3)
+                _ref_adam(params[i][lo: lo + n], g / world, moms[i][0], moms[i][1], step, lr)
+                works.append(ex.gather(i, params[i]))
+            for w in works:
+                if w is not None:
+                    w.wait()
+        results[mode] = params
+    # single-process reference on the summed gradients
+    ref = [p.clone() for p in p0]
+    rm = [(torch.zeros(t), torch.zeros(t)) for t in totals]
+    for step in range(1, 4):
+        for i in range(2):
+            g = sum(grads[r][i] for r in range(world)) * step / world
+            lr = torch.where(torch.arange(totals[i]) < split[i], 0.02, 1e-3)
+            _ref_adam(ref[i], g, rm[i][0], rm[i][1], step, lr)
+    ok = all(torch.allclose(results["zero1"][i], ref[i], rtol=1e-5, atol=1e-7) and
+             torch.allclose(results["allreduce"][i], ref[i], rtol=1e-5, atol=1e-7) for i in range(2))
+    try:   # a buffer that does not split into aligned shards is refused
+        P.FlatExchange([4098], "zero1")
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_flat_exchange_zero1_equals_allreduce_world2():
+    """reduce-scatter -> Adam on the owned slice -> all-gather (ZeRO-1) gives the same parameters as
+    all-reduce + replicated Adam and as one process on the summed gradients, over 3 steps, with the async
+    early start of one buffer (the overlap the trainer uses for the static field)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, 2, 29741, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
+
+
+def test_frame_median_depth_loss_matches_reference_loop():
+    """step.frame_median_depth_loss (one segmented sort, no host sync) vs the reference's per-frame host
+    loop (train.py:797-807, 1636-1664, restated in the oracle): values and gradients, with empty frames,
+    single-ray frames (skipped), even / odd counts (lower median) and a mask."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    from oracle import rodynrf_oracle as O
+    g = torch.Generator().manual_seed(3)
+    T, N = 12, 257
+    frame = torch.randint(0, T - 2, (N,), generator=g)          # frames T-2, T-1 stay empty
+    frame[:1] = T - 2                                           # one frame with a single ray: skipped
+    pred0 = torch.randn(N, generator=g) * 3
+    gt = torch.rand(N, generator=g)
+    for mask in (None, torch.rand(N, generator=g) < 0.6):
+        p1 = pred0.clone().requires_grad_(True)
+        p2 = pred0.clone().requires_grad_(True)
+        a = S_.frame_median_depth_loss(p1, gt, frame, T, mask=mask)
+        b = O.frame_depth_loss(p2, gt, frame, T, mask=mask)
+        assert torch.allclose(a, b, rtol=1e-5), (float(a), float(b))
+        a.backward()
+        b.backward()
+        assert torch.allclose(p1.grad, p2.grad, rtol=1e-4, atol=1e-7)
