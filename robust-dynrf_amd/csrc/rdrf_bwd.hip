@@ -1695,7 +1695,133 @@ static void dw_blk(DwJobs& D, int row0, int seg, int e0) {
   j.blk_row0[j.nblk] = row0; j.blk_seg[j.nblk] = seg; j.blk_e0[j.nblk] = e0;
   j.nblk++;
 }
-static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
+// ------------------------------------------------------------------------------------------------
+// cooperative dW kernel (k_dw2).  k_dw above gives every (out-block, in-group) item its own wave and its
+// own copy of the rows it needs: a density-phase tile is requested 55 blocks at a time for 27 unique ones,
+// and each wave's 20 KB stage is written and read once per item.  Here ONE 8-wave workgroup owns a tile:
+// it stages every unique 32-row block of the tile in LDS once (27 x 4 KB = 108 KB for the density phase,
+// 30 for the appearance phases), then its waves form all (dz block) x (input block) products of all the
+// jobs from that stage -- 5 or 6 products per wave, accumulators resident for the whole launch.  The
+// global loads of the next tile are issued right after the stage is written (into registers: 14 x 16 B
+// per thread) and land while the MFMAs of the current tile run.  Per tile and CU: 108 KB of HBM traffic
+// (was ~220 KB of L2 traffic), 640 MFMAs spread over the four SIMDs.
+// ------------------------------------------------------------------------------------------------
+#define DW2_MAX_BLK 30
+#define DW2_MAX_PROD 4
+#define DW2_WAVES 12
+struct Dw2Prod {
+  short a, b;        // staged block indices of the dz block / the input block
+  short job, bo, k;  // write-out: job, out-block of the job, in-block index of the job
+  short bias;        // this product also accumulates the bias gradient of its out-block
+};
+struct Dw2Plan {
+  const float* A;    // dz rows: tile t, row r at A + (t*A_stride + r)*32
+  const float* B;    // activation rows
+  int A_stride, B_stride;
+  int nblk;
+  unsigned char src[DW2_MAX_BLK];   // 0 = A, 1 = B
+  short row0[DW2_MAX_BLK];
+  int nprod[DW2_WAVES];
+  Dw2Prod prod[DW2_WAVES][DW2_MAX_PROD];
+  const int* count;
+  int ntiles;
+  DwJob job[RDRF_MAX_DW_JOBS];
+};
+
+__global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 dw2_stage[];   // nblk x 256 float4, XOR-swizzled per block
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: indexes the plan in the kernel arguments
+  const int ntiles = P.count ? ((*P.count + 31) >> 5) : P.ntiles;
+  const int nf4 = P.nblk * 256;
+  constexpr int NT = 64 * DW2_WAVES, NPF = (DW2_MAX_BLK * 256 + NT - 1) / NT;
+  // this thread's slots of the tile image: float4 index i*NT + tid -> (block, row, 16-byte chunk)
+  f32x4 pf[NPF];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = i * NT + tid;
+      if (idx < nf4) {
+        const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), w = idx & 255;   // 256 % 64 == 0: wave-uniform
+        const float* base = P.src[blk] ? P.B + ((size_t)t * P.B_stride + P.row0[blk]) * 32
+                                       : P.A + ((size_t)t * P.A_stride + P.row0[blk]) * 32;
+        pf[i] = ld4(base + w * 4);
+      }
+    }
+  };
+  int rpos[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rpos[q] = li * 8 + ((4 * h + q) ^ ((li >> 1) & 7));
+  const int np = P.nprod[wave];
+  f32x16 acc[DW2_MAX_PROD];
+  float bsum[DW2_MAX_PROD];
+#pragma unroll
+  for (int p = 0; p < DW2_MAX_PROD; ++p) {
+    bsum[p] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  }
+  int t = blockIdx.x;
+  if (t < ntiles) gload(t);
+  while (t < ntiles) {
+    __syncthreads();   // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = i * NT + tid;
+      if (idx < nf4) {
+        const int blk = idx >> 8, w = idx & 255, row = w >> 3;
+        dw2_stage[blk * 256 + row * 8 + ((w & 7) ^ ((row >> 1) & 7))] = pf[i];
+      }
+    }
+    __syncthreads();
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) gload(tn);   // lands while the MFMAs below run
+#pragma unroll
+    for (int p = 0; p < DW2_MAX_PROD; ++p) {
+      if (p < np) {
+        const Dw2Prod pr = P.prod[wave][p];
+        const f32x4* sa = dw2_stage + pr.a * 256;
+        const f32x4* sb = dw2_stage + pr.b * 256;
+        f32x4 av4[4], bv4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av4[q] = sa[rpos[q]]; bv4[q] = sb[rpos[q]]; }
+        if (pr.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bsum[p] += av4[q].x + av4[q].y + av4[q].z + av4[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].x, bv4[q].x, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].y, bv4[q].y, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].z, bv4[q].z, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].w, bv4[q].w, acc[p], 0, 0, 0);
+        }
+      }
+    }
+    t = tn;
+  }
+  // write-out: C row i = (rr&3) + 8*(rr>>2) + 4*h (out neuron), column = li (input element)
+#pragma unroll
+  for (int p = 0; p < DW2_MAX_PROD; ++p) {
+    if (p < np) {
+      const Dw2Prod pr = P.prod[wave][p];
+      const DwJob& J = P.job[pr.job];
+      const int col = seg_imap(J.blk_seg[pr.k], J.blk_e0[pr.k] + li, J.in_dim);
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int orow = pr.bo * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h - J.out_row0;
+        if (col >= 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.dW + (size_t)orow * J.ld + col, acc[p][rr]);
+      }
+      if (pr.bias && J.db != nullptr) {
+        const float b = bsum[p] + __shfl_xor(bsum[p], 32, 64);
+        const int orow = pr.bo * 32 + li - J.out_row0;
+        if (h == 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.db + orow, b);
+      }
+    }
+  }
+}
+
+static int dw_launch_old(DwJobs& D, hipStream_t stream, const char* name) {
   int items = 0;
   for (int i = 0; i < D.n; ++i) {
     const int n = D.j[i].nbo * ((D.j[i].nblk + 3) / 4);
@@ -1709,6 +1835,76 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
   int gx = (256 * 8 + gy - 1) / gy;
   gx = gx < 1 ? 1 : gx;
   RDRF_LAUNCH(name, k_dw, dim3(gx, gy), dim3(256), stream, D);
+  return 0;
+}
+
+// one plan per group of jobs that walk the same rows (same dz array, same activation array, same tile
+// space); a group whose products or blocks exceed one plan is cut into several launches
+static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
+  static const bool use_old = getenv("RDRF_DW_OLD") != nullptr;   // A/B switch for measurements
+  if (use_old) return dw_launch_old(D, stream, name);
+  bool done[RDRF_MAX_DW_JOBS] = {false};
+  for (int g0 = 0; g0 < D.n; ++g0) {
+    if (done[g0]) continue;
+    const DwJob& R = D.j[g0];
+    Dw2Plan P;
+    auto reset = [&]() {
+      memset(&P, 0, sizeof(P));
+      P.A = R.A; P.B = R.B; P.A_stride = R.A_stride; P.B_stride = R.B_stride;
+      P.count = R.count; P.ntiles = R.ntiles;
+      for (int i = 0; i < D.n; ++i) P.job[i] = D.j[i];
+    };
+    auto flush = [&]() -> int {
+      int tot = 0;
+      for (int w = 0; w < DW2_WAVES; ++w) tot += P.nprod[w];
+      if (tot == 0) return 0;
+      const size_t lds = (size_t)P.nblk * 4096;
+      if (lds > 48 * 1024)
+        RDRF_HIP(hipFuncSetAttribute((const void*)k_dw2, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
+      int grid = 256;
+      if (P.count == nullptr && P.ntiles < grid) grid = P.ntiles < 1 ? 1 : P.ntiles;
+      rdrf_prof_begin(name, stream);
+      hipLaunchKernelGGL(k_dw2, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
+      rdrf_prof_end(name, stream);
+      RDRF_HIP(hipGetLastError());
+      return 0;
+    };
+    auto find_blk = [&](int src, int row) {
+      for (int i = 0; i < P.nblk; ++i)
+        if (P.src[i] == src && P.row0[i] == row) return i;
+      return -1;
+    };
+    reset();
+    int nprods = 0;
+    for (int ji = g0; ji < D.n; ++ji) {
+      const DwJob& J = D.j[ji];
+      if (done[ji] || J.A != R.A || J.B != R.B || J.A_stride != R.A_stride || J.B_stride != R.B_stride ||
+          J.count != R.count || J.ntiles != R.ntiles)
+        continue;
+      done[ji] = true;
+      for (int bo = 0; bo < J.nbo; ++bo)
+        for (int k = 0; k < J.nblk; ++k) {
+          int need = (find_blk(0, J.A_row0 + 32 * bo) < 0) + (find_blk(1, J.blk_row0[k]) < 0);
+          if (nprods == DW2_WAVES * DW2_MAX_PROD || P.nblk + need > DW2_MAX_BLK) {
+            int rc = flush();
+            if (rc) return rc;
+            reset();
+            nprods = 0;
+          }
+          int a = find_blk(0, J.A_row0 + 32 * bo);
+          if (a < 0) { a = P.nblk++; P.src[a] = 0; P.row0[a] = (short)(J.A_row0 + 32 * bo); }
+          int b = find_blk(1, J.blk_row0[k]);
+          if (b < 0) { b = P.nblk++; P.src[b] = 1; P.row0[b] = (short)J.blk_row0[k]; }
+          const int w = nprods % DW2_WAVES;   // round robin: consecutive products of a job share their dz block
+          Dw2Prod& pr = P.prod[w][P.nprod[w]++];
+          pr.a = (short)a; pr.b = (short)b; pr.job = (short)ji; pr.bo = (short)bo; pr.k = (short)k;
+          pr.bias = (short)(k == 0 && J.db != nullptr);
+          ++nprods;
+        }
+    }
+    int rc = flush();
+    if (rc) return rc;
+  }
   return 0;
 }
 
