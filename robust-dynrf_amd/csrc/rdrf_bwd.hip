@@ -1103,8 +1103,12 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
       constexpr int QPL = C0Q + 2 * C1Q, NLV = (2 * NQ) / QPL;
       static_assert(C0Q % 4 == 0 && NLV * QPL == 2 * NQ, "quad layout");
       const int q = lane >> 4, s16 = lane & 15;
+#ifndef RDRF_ABL_SC_NLV
+#define RDRF_ABL_SC_NLV 99
+#endif
 #pragma unroll 1
-      for (int lv = 0; lv < NLV; ++lv) {
+      for (int lv = 0; lv < NLV && lv < RDRF_ABL_SC_NLV; ++lv) {
+#ifndef RDRF_ABL_SC_NOXY
 #pragma unroll 1
         for (int it = 0; it < C0Q / 2; ++it) {
           const int grp = it >> 1, j = it & 1;
@@ -1116,6 +1120,8 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
           gather_xy4_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], lv, 4 * grp + q, j ? xb0 : xa0, j ? xb1 : xa1,
                                    j ? xb2 : xa2, dq, j ? liveb : livea, lane < 32 && q == j, dw0, dw1, dw2, ll);
         }
+#endif
+#ifndef RDRF_ABL_SC_NOZ
         if constexpr (ZSPLIT) {
 #pragma unroll 1
           for (int zq = 0; zq < 2 * C1Q; ++zq) {
@@ -1135,6 +1141,7 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
             gather_quad_bwd<C0Q, C1Q, 1>(a.vm[set], a.gvm[set], g, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
           }
         }
+#endif
       }
     }
     dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
@@ -1709,18 +1716,19 @@ static void dw_blk(DwJobs& D, int row0, int seg, int e0) {
 #define DW2_MAX_BLK 30
 #define DW2_MAX_PROD 4
 #define DW2_WAVES 12
-struct Dw2Prod {
-  short a, b;        // staged block indices of the dz block / the input block
-  short job, bo, k;  // write-out: job, out-block of the job, in-block index of the job
-  short bias;        // this product also accumulates the bias gradient of its out-block
+struct Dw2Prod {     // 32-bit fields: scalar loads (see blk_meta)
+  int a, b;          // staged block indices of the dz block / the input block
+  int job, bo, k;    // write-out: job, out-block of the job, in-block index of the job
+  int bias;          // this product also accumulates the bias gradient of its out-block
 };
 struct Dw2Plan {
   const float* A;    // dz rows: tile t, row r at A + (t*A_stride + r)*32
   const float* B;    // activation rows
   int A_stride, B_stride;
   int nblk;
-  unsigned char src[DW2_MAX_BLK];   // 0 = A, 1 = B
-  short row0[DW2_MAX_BLK];
+  int blk_meta[DW2_MAX_BLK];        // (src << 16) | row0, src 0 = A, 1 = B.  32-bit on purpose: the block index is
+                                    // wave-uniform, so these are SCALAR loads (lgkmcnt); byte / short fields
+                                    // compile to vector loads whose vmcnt(0) waits drain the data loads in flight
   int nprod[DW2_WAVES];
   Dw2Prod prod[DW2_WAVES][DW2_MAX_PROD];
   const int* count;
@@ -1743,8 +1751,9 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
       const int idx = i * NT + tid;
       if (idx < nf4) {
         const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), w = idx & 255;   // 256 % 64 == 0: wave-uniform
-        const float* base = P.src[blk] ? P.B + ((size_t)t * P.B_stride + P.row0[blk]) * 32
-                                       : P.A + ((size_t)t * P.A_stride + P.row0[blk]) * 32;
+        const int meta = P.blk_meta[blk], row0 = meta & 0xffff;
+        const float* base = (meta >> 16) ? P.B + ((size_t)t * P.B_stride + row0) * 32
+                                         : P.A + ((size_t)t * P.A_stride + row0) * 32;
         pf[i] = ld4(base + w * 4);
       }
     }
@@ -1871,7 +1880,7 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
     };
     auto find_blk = [&](int src, int row) {
       for (int i = 0; i < P.nblk; ++i)
-        if (P.src[i] == src && P.row0[i] == row) return i;
+        if (P.blk_meta[i] == ((src << 16) | row)) return i;
       return -1;
     };
     reset();
@@ -1892,13 +1901,13 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
             nprods = 0;
           }
           int a = find_blk(0, J.A_row0 + 32 * bo);
-          if (a < 0) { a = P.nblk++; P.src[a] = 0; P.row0[a] = (short)(J.A_row0 + 32 * bo); }
+          if (a < 0) { a = P.nblk++; P.blk_meta[a] = J.A_row0 + 32 * bo; }
           int b = find_blk(1, J.blk_row0[k]);
-          if (b < 0) { b = P.nblk++; P.src[b] = 1; P.row0[b] = (short)J.blk_row0[k]; }
+          if (b < 0) { b = P.nblk++; P.blk_meta[b] = (1 << 16) | J.blk_row0[k]; }
           const int w = nprods % DW2_WAVES;   // round robin: consecutive products of a job share their dz block
           Dw2Prod& pr = P.prod[w][P.nprod[w]++];
-          pr.a = (short)a; pr.b = (short)b; pr.job = (short)ji; pr.bo = (short)bo; pr.k = (short)k;
-          pr.bias = (short)(k == 0 && J.db != nullptr);
+          pr.a = a; pr.b = b; pr.job = ji; pr.bo = bo; pr.k = k;
+          pr.bias = (k == 0 && J.db != nullptr) ? 1 : 0;
           ++nprods;
         }
     }
