@@ -157,7 +157,7 @@ def timed_steps(trainer, shard, steps, warmup, world, dev):
 
 KERNELS = ["pack", "generate_rays", "generate_rays_bwd", "sample_ndc", "sample_contract", "sample_bwd", "static_density",
            "static_app", "time_branch", "dyn_density", "dyn_app", "composite", "scene_flow", "induce_flow",
-           "induce_flow_bwd", "distloss", "distloss_bwd", "tv_fwd", "tv_bwd", "dense_l1", "dense_l1_bwd", "composite_bwd",
+           "induce_flow_bwd", "distloss", "distloss_bwd", "tv_fwd", "tv_bwd", "tv_grad", "dense_l1", "dense_l1_bwd", "composite_bwd",
            "dyn_app_bwd", "scatter_dyn_app", "dyn_heads_bwd", "scatter_dyn_density", "dyn_warp_bwd", "time_branch_bwd",
            "dw_dyn", "static_app_bwd", "scatter_static_app", "static_density_bwd", "scatter_static_density",
            "dw_static", "scene_flow_bwd", "dw_sf", "adam"]
@@ -210,12 +210,12 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
         dw_b = sum(dw_bytes[k] * table[k]["launches_per_step"] for k in dw_keys)
         dw_f = sum(flops[k] * table[k]["launches_per_step"] for k in dw_keys)
-        tr = pmc_traffic("k_dw")
+        tr = pmc_traffic("k_dw2")
         dw_entry = {
             "bound": "hbm", "achieved": dw_b / (dw_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": dw_b / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": tr,
             "hbm_real": None if tr is None else tr / (dw_ms / dw_launch * 1e-3) / 1e9,
-            "kernel": "k_dw", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
+            "kernel": "k_dw2", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
             "launches_per_step": dw_launch, "algorithmic_bytes_per_launch": dw_b / dw_launch,
             "mfma": {"achieved_tflops": dw_f / (dw_ms * 1e-3) / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
                      "frac": dw_f / (dw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}

@@ -278,6 +278,11 @@ typedef struct {
 } RdrfTensor4;
 int rdrf_tv_fwd(const RdrfTensor4* t, int n, float* sums /* [n][2], overwritten */, rdrf_stream_t stream);
 int rdrf_tv_bwd(const RdrfTensor4* t, int n, const float* g_sums /* [n][2] */, rdrf_stream_t stream);
+/* The gradient of the TV terms in one pass, for any number of tensors: t[i].g (+=) receives
+ * coef_host[i][0] * d(h_tv)/dx + coef_host[i][1] * d(w_tv)/dx (the W term is skipped when W == 1).  The caller
+ * folds TVLoss_weight * 2 / (count * batch), the 1e-2 / 1e-3 plane / line factors of TV_loss_* and the
+ * config's TV weight into the HOST coefficients: no forward sums, no scalar arithmetic on the device. */
+int rdrf_tv_grad(const RdrfTensor4* t, int n, const float* coef_host /* [n][2] */, rdrf_stream_t stream);
 
 /* ---- Adam over a flat parameter range (torch.optim.Adam as train.py:924-934 builds it: betas
  * (0.9, 0.99), eps 1e-8, no weight decay / amsgrad; the learning-rate decay of train.py:2608-2612 is the

@@ -88,7 +88,7 @@ SYMBOLS = [
     "rdrf_dynamic_features_bwd",
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
-    "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
+    "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
     "rdrf_dense_l1_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",

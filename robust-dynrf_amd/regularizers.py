@@ -96,6 +96,35 @@ class TVLoss(nn.Module):
         return self._value(sums, [tuple(x.shape)], ignore_axis)[0]
 
 
+    @torch.no_grad()
+    def accumulate_grad_(self, field, families, weights):
+        """d(sum_f weights[f] * TV_loss_f)/d(factors) added straight to the field's gradients, with ONE launch
+        for all families (rdrf_tv_grad) and no value: `families` = list of (planes, lines) as TV_loss_* takes
+        them.  The value of these terms is NaN in the reference (line tensors: 0/0) -- only their gradient
+        ever matters -- so the trainer uses this instead of building the sums and back-propagating them."""
+        xs, coef = [], []
+        for (planes, lines), wt in zip(families, weights):
+            for x, fam in [(p, 1e-2) for p in planes] + [(l, 1e-3) for l in lines]:
+                b, c, h, w = x.shape
+                ch = self.TVLoss_weight * 2.0 / (c * (h - 1) * w) / b if h > 1 else 0.0
+                cw = self.TVLoss_weight * 2.0 / (c * h * (w - 1)) / b if w > 1 else 0.0
+                xs.append(x)
+                coef += [float(wt) * fam * ch, float(wt) * fam * cw]
+        L.require_device(*xs)
+        if field.fused_grad:
+            views = {p.data_ptr(): v for p, v in zip(field._param_list(), field.fused_grads())}
+            grads = [views[x.data_ptr()] for x in xs]
+        else:
+            grads = []
+            for x in xs:
+                if x.grad is None:
+                    x.grad = torch.zeros_like(x)
+                grads.append(x.grad)
+        arr = (L.RdrfTensor4 * len(xs))(*[_tensor4(x, g) for x, g in zip(xs, grads)])
+        ca = (C.c_float * len(coef))(*coef)
+        L.check(L.lib.rdrf_tv_grad(arr, len(xs), ca, L.stream_of(xs[0])), "rdrf_tv_grad")
+
+
 _coef = {}
 
 

@@ -309,8 +309,8 @@ class Trainer:
 
     # ---- one iteration -----------------------------------------------------------------------------
     def losses(self, b):
-        """forward of one iteration on batch `b`; returns (loss_dynamic, loss_static, tv_dynamic, tv_static):
-        the two loss groups have disjoint parameter ancestries (dynamic field | static field + pose + focal)."""
+        """forward of one iteration on batch `b`; returns (loss_dynamic, loss_static): the two loss groups have
+        disjoint parameter ancestries (dynamic field | static field + pose + focal)."""
         c = self.cfg
         S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
         it, rng = self.it, self.rng
@@ -379,14 +379,9 @@ class Trainer:
         if c["l1_weight"] > 0:
             loss_d = loss_d + c["l1_weight"] * self.dy.density_L1()
             loss_s = loss_s + c["l1_weight"] * self.st.density_L1()
-        # TV: the VALUE is NaN in the reference (line tensors have count_w = 0) while the gradients are finite,
-        # so it is kept out of the reported loss and only its gradient is taken, by its own backward
-        tv_d = tv_s = None
-        if c["tv_density"] > 0 or c["tv_app"] > 0:
-            tv_d = (c["tv_density"] * (self.dy.TV_loss_density(self.tv) + self.dy.TV_loss_blending(self.tv))
-                    + c["tv_app"] * self.dy.TV_loss_app(self.tv))
-            tv_s = c["tv_density"] * self.st.TV_loss_density(self.tv) + c["tv_app"] * self.st.TV_loss_app(self.tv)
-        return loss_d, loss_s, tv_d, tv_s
+        # TV (train.py:1735-1754, 1872-1885): the VALUE is NaN in the reference (line tensors have count_w = 0)
+        # while the gradients are finite; only the gradient is taken (step(): TVLoss.accumulate_grad_)
+        return loss_d, loss_s
 
     def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static, gt_depth, to_depth):
         """train.py:1895-2311 (optimize_poses): every term reaches the static field, the poses and the focal."""
@@ -427,18 +422,23 @@ class Trainer:
         group first; its gradient exchange starts while the dynamic group is still differentiating).
         Returns the loss tensor (device, no sync)."""
         b = self.data.make_batch(self.it, self.cfg["batch_size"], shard)
-        loss_d, loss_s, tv_d, tv_s = self.losses(b)
+        loss_d, loss_s = self.losses(b)
+        c = self.cfg
+        tv = c["tv_density"] > 0 or c["tv_app"] > 0
         self.opt.zero_grad()
         if self.optimize_poses:
             self.poses.grad = None
             self.fov.grad = None
+        st, dy = self.st, self.dy
         loss_s.backward()
-        if tv_s is not None:
-            tv_s.backward()
+        if tv:
+            self.tv.accumulate_grad_(st, [(st.density_plane, st.density_line), (st.app_plane, st.app_line)],
+                                     [c["tv_density"], c["tv_app"]])
         self.opt.begin_exchange(0)           # static field: complete
         loss_d.backward()
-        if tv_d is not None:
-            tv_d.backward()
+        if tv:
+            self.tv.accumulate_grad_(dy, [(dy.density_plane, dy.density_line), (dy.blending_plane, dy.blending_line),
+                                          (dy.app_plane, dy.app_line)], [c["tv_density"], c["tv_density"], c["tv_app"]])
         self.opt.begin_exchange(1)
         self.last = dict(loss_dynamic=loss_d.detach(), loss_static=loss_s.detach())
         return (loss_d + loss_s).detach()

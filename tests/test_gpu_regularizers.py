@@ -92,3 +92,27 @@ def test_l1_and_ortho_regularisers_golden():
                 gg = torch.zeros_like(ps[i]) if gg is None else gg
                 assert_close(gg, ref, f"{tag}.{nm}.g{i}", rtol=5e-5)
     assert not hasattr(dy, "vector_comp_diffs")
+
+
+def test_tv_accumulate_grad_matches_autograd_path():
+    """TVLoss.accumulate_grad_ (one launch, no value) adds exactly the gradient that TV_loss_* + backward give,
+    for fused and plain gradient storage, with per-family weights."""
+    import rodynrf
+    from _gpu_util import fields_from_case
+    g, st, dy, _ = fields_from_case("ndc_relu")
+    tv = rodynrf.TVLoss()
+    fams = [(dy.density_plane, dy.density_line), (dy.blending_plane, dy.blending_line), (dy.app_plane, dy.app_line)]
+    wts = [0.7, 0.7, 0.2]
+    (0.7 * (dy.TV_loss_density(tv) + dy.TV_loss_blending(tv)) + 0.2 * dy.TV_loss_app(tv)).backward()
+    ref = [p.grad.clone() for pl, ln in fams for p in list(pl) + list(ln)]
+    for fused in (False, True):
+        for p in dy.parameters():
+            p.grad = None
+        dy.fused_grad = fused
+        if fused:
+            dy.zero_grad_fused()
+        tv.accumulate_grad_(dy, fams, wts)
+        tv.accumulate_grad_(dy, fams, wts)          # accumulates
+        got = [p.grad for pl, ln in fams for p in list(pl) + list(ln)]
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert_close(a, 2 * b, f"fused={fused} tensor {i}", rtol=1e-5)
