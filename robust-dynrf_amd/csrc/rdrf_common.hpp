@@ -327,90 +327,6 @@ RDRF_D f32x4 gather_quad(const RdrfVM& vm, int g, float x0, float x1, float x2) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward gathers of the MLP kernels: lane half h gathers quad g = 2*O + h, O a compile-time constant of
-// the unrolled loop.  The factor-set metadata (plane / line pointers, sizes, strides) is wave-uniform, but
-// written as `pi == 0 ? vm.plane[0] : ...` with a per-lane pi hipcc turns the select of three kernel-argument
-// loads into ONE VECTOR load from a selected address: a dependent memory round trip in front of the six tap
-// loads of every quad.  VmS holds the metadata as scalars (readfirstlane pins them in SGPRs); the two quads
-// of a pair are on the same plane except for one pair per level (XZ | YZ), so almost every select folds
-// away at compile time and the rest are v_cndmask between SGPRs.
-// ---------------------------------------------------------------------------------------------
-struct VmS {
-  unsigned plo[3], phi[3], llo[3], lhi[3];
-  int H[3], W[3], L[3], sH[3], sW[3];
-};
-RDRF_D VmS vm_scalars(const RdrfVM& vm) {
-  VmS v;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const unsigned long long p = (unsigned long long)vm.plane[i], l = (unsigned long long)vm.line[i];
-    v.plo[i] = __builtin_amdgcn_readfirstlane((unsigned)p);
-    v.phi[i] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-    v.llo[i] = __builtin_amdgcn_readfirstlane((unsigned)l);
-    v.lhi[i] = __builtin_amdgcn_readfirstlane((unsigned)(l >> 32));
-    v.H[i] = __builtin_amdgcn_readfirstlane(vm.H[i]);
-    v.W[i] = __builtin_amdgcn_readfirstlane(vm.W[i]);
-    v.L[i] = __builtin_amdgcn_readfirstlane(vm.L[i]);
-    v.sH[i] = __builtin_amdgcn_readfirstlane(vm.sH[i]);
-    v.sW[i] = __builtin_amdgcn_readfirstlane(vm.sW[i]);
-  }
-  return v;
-}
-template <int C0Q, int C1Q, int O>
-RDRF_D f32x4 gather_quad_pair(const VmS& v, int h, float x0, float x1, float x2) {
-#ifdef RDRF_ABL_NOGATHER
-  return f32x4{x0, x1, x2, (float)(2 * O + h)};
-#endif
-  constexpr int QPL = C0Q + 2 * C1Q;
-  constexpr int G0 = 2 * O, G1 = 2 * O + 1, lv = G0 / QPL, st = 1 << lv;
-  static_assert(G1 / QPL == lv, "the two quads of a pair sit on the same level");
-  constexpr int W0 = G0 - lv * QPL, W1 = G1 - lv * QPL;
-  constexpr int PI0 = W0 < C0Q ? 0 : (W0 < C0Q + C1Q ? 1 : 2), PI1 = W1 < C0Q ? 0 : (W1 < C0Q + C1Q ? 1 : 2);
-  constexpr int Q0 = W0 - (PI0 == 0 ? 0 : (PI0 == 1 ? C0Q : C0Q + C1Q)), Q1 = W1 - (PI1 == 0 ? 0 : (PI1 == 1 ? C0Q : C0Q + C1Q));
-  constexpr int CC0 = 4 * (PI0 == 0 ? C0Q : C1Q), CC1 = 4 * (PI1 == 0 ? C0Q : C1Q);
-#define RDRF_SEL(a, b) (h ? (b) : (a))
-  const int pi = RDRF_SEL(PI0, PI1);
-  const float cx = pi == 2 ? x1 : x0;
-  const float cy = pi == 0 ? x1 : x2;
-  const float cl = pi == 0 ? x2 : (pi == 1 ? x1 : x0);
-  const unsigned long long pa = ((unsigned long long)RDRF_SEL(v.phi[PI0], v.phi[PI1]) << 32) | RDRF_SEL(v.plo[PI0], v.plo[PI1]);
-  const unsigned long long la = ((unsigned long long)RDRF_SEL(v.lhi[PI0], v.lhi[PI1]) << 32) | RDRF_SEL(v.llo[PI0], v.llo[PI1]);
-  const float* P = (const float*)pa;
-  const float* Lp = (const float*)la;
-  const int H = RDRF_SEL(v.H[PI0], v.H[PI1]), W = RDRF_SEL(v.W[PI0], v.W[PI1]), L = RDRF_SEL(v.L[PI0], v.L[PI1]);
-  const int sH = RDRF_SEL(v.sH[PI0], v.sH[PI1]), sW = RDRF_SEL(v.sW[PI0], v.sW[PI1]);
-  const int qo = 4 * RDRF_SEL(Q0, Q1), C = RDRF_SEL(CC0, CC1);
-#undef RDRF_SEL
-  const int Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv, Ls = (L + st - 1) >> lv;
-  Tap1 tx = tap1d(cx, Ws), ty = tap1d(cy, Hs), tl = tap1d(cl, Ls);
-  const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
-  const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
-  const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
-  const f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo);
-  const f32x4 v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
-  const f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo);
-  const f32x4 v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
-  const f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo);
-  const f32x4 a1 = ld4(Lp + (size_t)l1c * C + qo);
-  const float wx0 = tx.ok0 ? tx.w0 : 0.f, wx1 = tx.ok1 ? tx.w1 : 0.f;
-  const float wy0 = ty.ok0 ? ty.w0 : 0.f, wy1 = ty.ok1 ? ty.w1 : 0.f;
-  const float wl0 = tl.ok0 ? tl.w0 : 0.f, wl1 = tl.ok1 ? tl.w1 : 0.f;
-  const f32x4 pv = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
-  const f32x4 lvv = a0 * wl0 + a1 * wl1;
-  return pv * lvv;
-}
-// compile-time loop over the NQ/2 quad pairs of a factor set: F[4*O .. 4*O+3] = quad 2*O + h
-template <int C0Q, int C1Q, int NP, int O = 0>
-RDRF_D void gather_pairs(float (&F)[4 * NP], const VmS& v, int h, bool live, float x0, float x1, float x2) {
-  if constexpr (O < NP) {
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (live) q = gather_quad_pair<C0Q, C1Q, O>(v, h, x0, x1, x2);
-    F[4 * O + 0] = q.x; F[4 * O + 1] = q.y; F[4 * O + 2] = q.z; F[4 * O + 3] = q.w;
-    gather_pairs<C0Q, C1Q, NP, O + 1>(F, v, h, live, x0, x1, x2);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // shared input blocks X0 (xn, t, PE10(xn)) and X1 (PE8(t)) in canonical layout
 // (models/tensorBase.py:13-19 positional_encoding: q[d*F+k] = p[d]*2^k; [sin(q), cos(q)])
 // ---------------------------------------------------------------------------------------------

@@ -94,7 +94,6 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, Stat
   const int count = FEAT ? a.M : *a.counter;
   const int ntiles = (count + 31) >> 5;
   const float* pkw = lds;
-  const VmS vapp = vm_scalars(w.app);
   for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
     const int li = tile * 32 + s;
     const bool act = li < count;
@@ -112,7 +111,12 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, Stat
       x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
     }
     float G[36];
-    gather_pairs<12, 3, 9>(G, vapp, h, act, x0, x1, x2);
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, x0, x1, x2);
+      G[o * 4 + 0] = v.x; G[o * 4 + 1] = v.y; G[o * 4 + 2] = v.z; G[o * 4 + 3] = v.w;
+    }
     f32x16 accF[1];
     acc_bias<1>(accF, nullptr, h);
     mfma_seg<1, 36>(accF, G, pkw + pk::S3_BASIS, lane);
@@ -211,7 +215,6 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const float* pkw = lds;
-  const VmS vden = vm_scalars(w.density), vble = vm_scalars(w.blending);
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
   float t = 0.f, nrm = 1.0f;
   float T[16];
@@ -289,7 +292,12 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
     float fd, fb;
     {
       float Fv[36];
-      gather_pairs<4, 1, 9>(Fv, vden, h, vld, xw0, xw1, xw2);
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.density, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BD1, h);
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_DEN1_F, lane);
@@ -303,7 +311,12 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
     }
     {
       float Fv[36];
-      gather_pairs<4, 1, 9>(Fv, vble, h, vld, xw0, xw1, xw2);
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.blending, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BB1, h);
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_BLE1_F, lane);
@@ -367,7 +380,6 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app(FieldArgs a, DynW w)
   const int count = FEAT ? a.M : *a.counter;
   const int ntiles = (count + 31) >> 5;
   const float* pkw = lds;
-  const VmS vapp = vm_scalars(w.app);
   for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
     const int li = tile * 32 + s;
     const bool act = li < count;
@@ -388,7 +400,12 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app(FieldArgs a, DynW w)
     float F[16];
     {
       float A[108];
-      gather_pairs<12, 3, 27>(A, vapp, h, act, xw0, xw1, xw2);
+#pragma unroll
+      for (int o = 0; o < 27; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, xw0, xw1, xw2);
+        A[o * 4 + 0] = v.x; A[o * 4 + 1] = v.y; A[o * 4 + 2] = v.z; A[o * 4 + 3] = v.w;
+      }
       f32x16 accF[1];
       acc_bias<1>(accF, nullptr, h);
       mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
