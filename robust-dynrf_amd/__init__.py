@@ -3,7 +3,9 @@
 Hand-written HIP kernels for gfx950 behind a C ABI (include/rodynrf.h, librodynrf.so), exposed
 through the reference's own call surface:
 
-    TensorVMSplit, TensorVMSplit_TimeEmbedding     (models/tensoRF.py)
+    TensorVMSplit, TensorVMSplit_TimeEmbedding     (models/tensoRF.py: forward, compute_densityfeature /
+                                                    compute_appfeature / compute_blendingfeature / warp_coordinate,
+                                                    get_forward_backward_scene_flow, density_L1, TV_loss_*, ...)
     sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, induce_flow, render_3d_point   (renderer.py)
     generate_rays                                  (train.py ray-generation block)
 
