@@ -2052,7 +2052,8 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;   // one big workgroup per CU vs. two or three
   const int wpb = threads / 64;
   long g = (ntiles + wpb - 1) / wpb;
-  const long cap = threads == 512 ? 256 : 768;
+  static const long cap_env = getenv("RDRF_SC_CAP") ? atol(getenv("RDRF_SC_CAP")) : 0;   // experiments
+  const long cap = threads == 512 ? 256 : (cap_env > 0 ? cap_env : 768);
   g = g < 1 ? 1 : (g > cap ? cap : g);
   rdrf_prof_begin(name, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(threads), (size_t)sa.lds_bytes, stream, sa);
