@@ -364,9 +364,9 @@ def main():
                                "per-frame depth loss, distortion loss, compositor, factor regularisers, full backward, Adam",
                    "config": args.config, "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
                    "global_batch": cfg["batch_size"], "weights": args.weights,
-                   "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if world > 1 else ""),
-                   "ranks": world, "backend": dist.get_backend() if world > 1 else None,
-                   "exchange_bytes_per_step": trainer.opt.nbytes_exchanged() if world > 1 else 0,
+                   "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if trainer.opt.ex.active else ""),
+                   "ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+                   "exchange_bytes_per_step": trainer.opt.nbytes_exchanged() if trainer.opt.ex.active else 0,
                    "final_loss": loss_val,
                    "dead_dynamic_forwards": "skipped (dead work, SURVEY 3.1)" if args.exploit_liveness
                    else "executed (dead work the reference also computes)"},
@@ -410,7 +410,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, args.cpu_repeats, dead_work=not args.exploit_liveness)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

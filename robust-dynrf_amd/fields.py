@@ -13,6 +13,8 @@ one bilinear tap of 4 components is a single 16-byte load on the GPU.
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -74,7 +76,7 @@ class MLPRender_Fea_late_view(_Head):
 # storage order of the XZ / YZ planes: False = [z][x|y][C] (x fastest: the two bilinear columns of a
 # tap are 16-32 bytes apart and the scatter's column-split atomics merge into one L2 request each);
 # True = [x|y][z][C].  The kernels take explicit strides, either works.
-Z_FAST = False
+Z_FAST = os.environ.get("RDRF_Z_FAST", "0") == "1"
 
 
 def channel_last_(t, h_fast=False):

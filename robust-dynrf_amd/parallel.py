@@ -12,13 +12,20 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    """RDRF_FORCE_COLLECTIVES=1: create the process group and issue every collective even at world size 1,
+    so that the RCCL call sequence (reduce_scatter_tensor / in-place all_gather_into_tensor / async handles)
+    can be exercised on a single-GPU box (tests/test_gpu_trainer.py)."""
+    return os.environ.get("RDRF_FORCE_COLLECTIVES", "0") == "1"
+
+
 def init_distributed(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns
     (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:   # RDRF_DIST_BACKEND=gloo: functional test of the N>1 path on one GPU
@@ -103,7 +110,8 @@ class FlatExchange:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        self.mode = mode if self.world > 1 else "allreduce"
+        self.active = self.world > 1 or (force_collectives() and dist.is_available() and dist.is_initialized())
+        self.mode = mode if self.active else "allreduce"
         self.totals = list(totals)
         if self.mode == "zero1":
             for t in self.totals:
@@ -121,7 +129,7 @@ class FlatExchange:
         if i in self._g:
             return
         self._g[i] = g
-        if self.world == 1:
+        if not self.active:
             return
         if self.mode == "zero1":
             lo, n = self.slice(i)
@@ -142,11 +150,11 @@ class FlatExchange:
             w.wait()
         g = self._g.pop(i)
         lo, n = self.slice(i)
-        return (self._shards[i] if (self.mode == "zero1" and self.world > 1) else g), lo, n
+        return (self._shards[i] if (self.mode == "zero1" and self.active) else g), lo, n
 
     def gather(self, i, p, async_op=True):
         """zero1: all-gather the updated parameter slices into the flat parameter buffer p (in place)"""
-        if self.world == 1 or self.mode != "zero1":
+        if not self.active or self.mode != "zero1":
             return None
         lo, n = self.slice(i)
         src = p[lo: lo + n]

@@ -445,7 +445,7 @@ class Trainer:
 
     def finish_step(self):
         if self.optimize_poses:
-            if self.opt.world > 1:   # the pose / focal gradients are a [T*9 + 1] vector: one tiny all-reduce
+            if self.opt.ex.active:   # the pose / focal gradients are a [T*9 + 1] vector: one tiny all-reduce
                 import torch.distributed as dist
                 buf = torch.cat([self.poses.grad.reshape(-1), self.fov.grad.reshape(-1)])
                 dist.all_reduce(buf)

@@ -82,6 +82,33 @@ def test_bench_two_ranks_functional(dp):
     assert "roofline" in d and d["roofline"]["kernel_ms_per_step"]["adam"] > 0
 
 
+@pytest.mark.parametrize("dp", ["zero1", "allreduce"])
+def test_bench_rccl_call_sequence_on_one_gpu(dp):
+    """The RCCL transport itself: RDRF_FORCE_COLLECTIVES=1 makes a world-size-1 `nccl` process group and issues
+    every collective of the N>1 step on it (reduce_scatter_tensor into the shard / in-place all_gather_into_tensor
+    of the updated slice, or the in-place all_reduce, with their asynchronous handles and stream hand-over).  At
+    world size 1 every collective is the identity, so the loss after 6 steps must equal the plain run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RDRF_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
+           "--rays-per-gpu", "512", "--no-render", "--no-final-stage", "--no-cpu-baseline", "--dp", dp]
+    res = []
+    for force in ("0", "1"):
+        env = dict(base, RDRF_FORCE_COLLECTIVES=force, MASTER_PORT=str(29611 + (dp == "zero1")))
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    plain, forced = res
+    assert plain["config"]["backend"] is None and forced["config"]["backend"] == "nccl"
+    assert forced["config"]["exchange_bytes_per_step"] > 1e6 and dp in forced["config"]["parallelism"]
+    a, b = plain["config"]["final_loss"], forced["config"]["final_loss"]
+    assert abs(a - b) <= 2e-3 * abs(a), (a, b)   # same arithmetic; atomics order differs run to run
+
+
 def test_bench_refuses_world_size_mismatch():
     import os
     import subprocess
