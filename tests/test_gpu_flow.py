@@ -106,6 +106,10 @@ def test_distortion_loss_vs_bruteforce(N, S):
         ggot, = torch.autograd.grad(got, wg)
         assert_close(got, ref.float(), "distloss", rtol=2e-5)
         assert_close(ggot, gref.float(), "d distloss / dw", rtol=1e-4)
+        # ... and against the library's PUBLISHED prefix-sum form and analytic gradient (second restatement)
+        assert_close(got, O.eff_distloss_published(wr.detach(), m.double(), iv_ref).float(), "distloss (published form)", rtol=2e-5)
+        assert_close(ggot, O.eff_distloss_published_grad(wr.detach(), m.double(), iv_ref).float(),
+                     "d distloss / dw (published form)", rtol=1e-4)
     got2 = rodynrf.eff_distloss(w.cuda(), m.cuda(), 1.0 / S)
     assert_close(got2, O.eff_distloss(w.double(), m.double(), 1.0 / S).float(), "eff_distloss", rtol=2e-5)
     with pytest.raises(NotImplementedError):
