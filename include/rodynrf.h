@@ -307,6 +307,39 @@ int rdrf_dense_l1_fwd(const RdrfVM* vm, int act, float density_shift, float* sum
 int rdrf_dense_l1_bwd(const RdrfVM* vm, const RdrfVM* gvm, int act, float density_shift, const float* g_mean,
                       rdrf_stream_t stream);
 
+/* ---- the per-ray / per-sample loss terms of one iteration, reduced in one launch (+ a finishing launch)
+ * and differentiated in one launch.  Replaces the elementwise chains of train.py:1323-1331 (photometric),
+ * :1341-1365 (dynamicness mask), :1392-1410 (induced flow, masked means), :1421, 1627 (scene flow, weighted by
+ * the sample weights in this path), :1522-1524, 1619-1621 (induced disparity), :1828-1832 (static photometric,
+ * background-masked), :2293-2299 (disparity smoothness).
+ *   term = coef * sum_rows w[row] * sum_cols rho(x + ysign * y) / Z
+ *   rho = r^2 | |r| | r ;  Z = rows * cols (NORM_MEAN)  or  sum_rows w + 1e-8 (NORM_WEIGHT, a masked mean)
+ * x, y: [rows][cols] contiguous (y nullable); w: [rows] (nullable = 1).  gx / gy (backward only, nullable):
+ * d loss / d x, d loss / d y, WRITTEN (not accumulated).
+ * fwd: partial = rdrf_loss_terms_workspace_floats(n) floats of scratch; out = 1 + 2 n floats:
+ *      out[0] = sum of the terms, out[1 + k] = coef_k / Z_k, out[1 + n + k] = value of term k.
+ * bwd: out as written by fwd; g_loss[0] (device) = d L / d out[0].  Deterministic (no float atomics). */
+enum { RDRF_LOSS_SQUARE = 0, RDRF_LOSS_ABS = 1, RDRF_LOSS_IDENTITY = 2 };
+enum { RDRF_LOSS_NORM_MEAN = 0, RDRF_LOSS_NORM_WEIGHT = 1 };
+#define RDRF_MAX_LOSS_TERMS 24
+typedef struct {
+  const float* x;
+  const float* y;
+  const float* w;
+  float* gx;
+  float* gy;
+  long long rows;
+  int cols;
+  int kind;   /* RDRF_LOSS_* */
+  int norm;   /* RDRF_LOSS_NORM_* */
+  float ysign;
+  float coef;
+} RdrfLossTerm;
+size_t rdrf_loss_terms_workspace_floats(int n);
+int rdrf_loss_terms_fwd(const RdrfLossTerm* terms, int n, float* partial, float* out, rdrf_stream_t stream);
+int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float* out, const float* g_loss,
+                        rdrf_stream_t stream);
+
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
  * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].
  * scratch for the per-sample tensors comes out of ws (rdrf_render_workspace_bytes). */

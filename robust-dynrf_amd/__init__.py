@@ -18,7 +18,10 @@ from .renderer import (sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, samp
                        eff_distloss, flatten_eff_distloss, render_frame, psnr)
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
+from .losses import LossTerms
+from ._lib import RdrfError
 
 __all__ = ["render_frame", "psnr", "TVLoss", "pose_to_mtx", "eff_distloss", "flatten_eff_distloss", "induce_flow", "induce_flow_single", "render_3d_point", "render_single_3d_point",
            "TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
-           "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "generate_rays", "ids2pixel"]
+           "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "generate_rays", "ids2pixel", "LossTerms",
+           "RdrfError"]

@@ -67,6 +67,8 @@ def _load():
     lib.rdrf_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
                                    C.c_void_p]
+    lib.rdrf_loss_terms_workspace_floats.restype = C.c_size_t
+    lib.rdrf_loss_terms_workspace_floats.argtypes = [C.c_int]
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
     lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -89,7 +91,7 @@ SYMBOLS = [
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
     "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
-    "rdrf_dense_l1_bwd",
+    "rdrf_dense_l1_bwd", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]
@@ -101,6 +103,15 @@ class RdrfTensor4(C.Structure):
 
 
 TV_MAX = 16
+
+
+class RdrfLossTerm(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("w", C.c_void_p), ("gx", C.c_void_p), ("gy", C.c_void_p),
+                ("rows", C.c_longlong), ("cols", C.c_int), ("kind", C.c_int), ("norm", C.c_int),
+                ("ysign", C.c_float), ("coef", C.c_float)]
+
+
+MAX_LOSS_TERMS = 24
 
 
 class RdrfError(RuntimeError):

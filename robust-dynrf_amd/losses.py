@@ -1,0 +1,94 @@
+"""Fused loss terms (csrc/rdrf_loss.hip): the photometric / mask / flow / disparity / scene-flow terms of an
+iteration -- each `coef * reduce(rho(x -+ y) * w) / Z` -- collected with LossTerms.add(...) and evaluated by
+LossTerms.total() in one reduction launch forward and one launch backward, instead of the 5-15 elementwise
+torch launches per term the expressions of train.py:1323-1421, 1522-1627, 1828-1832, 2293-2299 cost."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+SQUARE, ABS, IDENTITY = 0, 1, 2
+_KINDS = {"square": SQUARE, "abs": ABS, "identity": IDENTITY}
+
+
+class _LossTermsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        n = len(meta)
+        dev = tensors[0].device
+        arr = (L.RdrfLossTerm * n)()
+        held = []
+        for k, (kind, norm, ysign, coef, rows, cols) in enumerate(meta):
+            x, y, w = tensors[3 * k: 3 * k + 3]
+            x = L.f32c(x)
+            y = None if y is None else L.f32c(y)
+            w = None if w is None else L.f32c(w)
+            held += [x, y, w]
+            t = arr[k]
+            t.x, t.y, t.w = x.data_ptr(), (0 if y is None else y.data_ptr()), (0 if w is None else w.data_ptr())
+            t.gx = t.gy = 0
+            t.rows, t.cols, t.kind, t.norm, t.ysign, t.coef = rows, cols, kind, norm, ysign, coef
+        partial = torch.empty(int(L.lib.rdrf_loss_terms_workspace_floats(n)), device=dev)
+        out = torch.empty(1 + 2 * n, device=dev)
+        L.check(L.lib.rdrf_loss_terms_fwd(arr, n, L.ptr(partial), L.ptr(out), L.stream_of(out)), "rdrf_loss_terms_fwd")
+        ctx.meta, ctx.held, ctx.out = meta, held, out
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        meta, held, out = ctx.meta, ctx.held, ctx.out
+        n = len(meta)
+        arr = (L.RdrfLossTerm * n)()
+        grads = []
+        for k, (kind, norm, ysign, coef, rows, cols) in enumerate(meta):
+            x, y, w = held[3 * k: 3 * k + 3]
+            need_x, need_y = ctx.needs_input_grad[1 + 3 * k], ctx.needs_input_grad[2 + 3 * k]
+            if ctx.needs_input_grad[3 + 3 * k]:
+                raise L.RdrfError("LossTerms: the row weights are constants of the term (detach them)")
+            gx = torch.empty_like(x) if need_x else None
+            gy = torch.empty_like(y) if (need_y and y is not None) else None
+            t = arr[k]
+            t.x, t.y, t.w = x.data_ptr(), (0 if y is None else y.data_ptr()), (0 if w is None else w.data_ptr())
+            t.gx, t.gy = (0 if gx is None else gx.data_ptr()), (0 if gy is None else gy.data_ptr())
+            t.rows, t.cols, t.kind, t.norm, t.ysign, t.coef = rows, cols, kind, norm, ysign, coef
+            grads += [gx, gy, None]
+        g = L.f32c(g_loss.reshape(1))
+        L.check(L.lib.rdrf_loss_terms_bwd(arr, n, L.ptr(out), L.ptr(g), L.stream_of(out)), "rdrf_loss_terms_bwd")
+        return (None, *grads)
+
+
+class LossTerms:
+    """terms = LossTerms(); terms.add(3.0, "square", rgb_map, rgb_gt); ...; loss = terms.total()"""
+
+    def __init__(self):
+        self._meta, self._tensors = [], []
+        self.values = None   # after total(): per-term values (device tensor [n]), for logging
+
+    def __len__(self):
+        return len(self._meta)
+
+    def add(self, coef, kind, x, y=None, ysign=-1.0, w=None, norm="mean"):
+        """+= coef * sum(rho(x + ysign*y) * w[row]) / Z.   kind: "square" | "abs" | "identity";
+        w: one weight per row (x viewed as [w.numel(), -1]; no w: every element is a row);
+        norm: "mean" (Z = x.numel()) or "weight" (Z = w.sum() + 1e-8: the reference's masked mean)."""
+        if len(self._meta) >= L.MAX_LOSS_TERMS:
+            raise L.RdrfError(f"LossTerms: more than {L.MAX_LOSS_TERMS} terms in one group")
+        L.require_device(x, y, w)
+        if y is not None and y.shape != x.shape:
+            raise L.RdrfError(f"LossTerms: x {tuple(x.shape)} and y {tuple(y.shape)} differ")
+        rows = x.numel() if w is None else w.numel()
+        if rows == 0 or x.numel() % rows != 0:
+            raise L.RdrfError(f"LossTerms: {x.numel()} elements do not split into {rows} weighted rows")
+        if norm == "weight" and w is None:
+            raise L.RdrfError("LossTerms: norm='weight' needs row weights")
+        self._meta.append((_KINDS[kind], 1 if norm == "weight" else 0, float(ysign), float(coef), rows, x.numel() // rows))
+        self._tensors += [x, y, None if w is None else w.detach()]
+        return self
+
+    def total(self):
+        loss, out = _LossTermsFn.apply(tuple(self._meta), *self._tensors)
+        n = len(self._meta)
+        self.values = out[1 + n:]
+        return loss

@@ -37,6 +37,7 @@ from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
 from .optim import FlatAdam
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
+from .losses import LossTerms
 from .renderer import eff_distloss, induce_flow, raw2outputs, sampleXYZ
 
 NDC_AABB = [[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]]
@@ -329,23 +330,24 @@ class Trainer:
         gt_depth = -disp_t if rt == "ndc" else disp_t      # train.py:1645-1653
         to_depth = (lambda d: d) if rt == "ndc" else (lambda d: 1.0 / (d + 1e-6))
         loss_d = 0.0
+        Ld = LossTerms()   # the elementwise terms of the dynamic group: one fused reduction (losses.py)
         # ---- pass A
         _, oA, outA, _ = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
-        loss_d = loss_d + 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
-        loss_d = loss_d + 0.1 * (outA[12] - fg).abs().mean()
+        Ld.add(3.0, "square", outA[0], rgb_t).add(1.0, "square", outA[8], rgb_t)      # train.py:1323, 1331
+        Ld.add(0.1, "abs", outA[12], fg)                                                # :1341-1350
         loss_d = loss_d + c["monodepth_dynamic"] * temp * frame_median_depth_loss(to_depth(outA[9]), gt_depth, view, T)
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters
         w_dist = c["dist_dynamic"] * min(1.0, (it + 1) / c["n_iters"])
         loss_d = loss_d + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
         # ---- pass B (second random time)
         _, oB, outB, _ = ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
-        loss_d = loss_d + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
+        Ld.add(0.01, "identity", outB[12]).add(0.01, "abs", outB[9], outB[5].detach())  # :1267, 1277-1291
         loss_d = loss_d + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
-        w_d = outA[11].detach()[..., None]
-        loss_d = loss_d + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
-        loss_d = loss_d + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
+        w_d = outA[11].detach()                                                         # one weight per sample
+        Ld.add(0.01, "abs", sf_f, w=w_d).add(0.01, "abs", sf_b, w=w_d)                  # :1421
+        Ld.add(0.01, "square", sf_f, sf_b, ysign=1.0, w=w_d)                            # :1627
         # ---- induced flow of the dynamic field into the neighbour frames (train.py:1373-1413)
         weights_d, pts_ref = outA[11], oA[3]
         disp_A = {}
@@ -353,7 +355,7 @@ class Trainer:
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
             pts_n = pts_ref + sf if rt == "ndc" else torch.clamp(pts_ref + sf, min=-2.0 + 1e-6, max=2.0 - 1e-6)
             ind_flow, ind_disp = induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, grid, rays_d, ray_type=rt)
-            loss_d = loss_d + 0.02 * temp * masked_mean((ind_flow - flow_t).abs(), mask_t) / 2.0
+            Ld.add(0.01 * temp, "abs", ind_flow, flow_t, w=mask_t, norm="weight")       # :1392-1410 (x 0.02 / 2)
             disp_A[sgn] = (ind_disp, mask_t, pose_n, flow_t)
         # ---- pass C / D: the flow-displaced rays of the neighbour frames (train.py:1433-1528, 1530-1625)
         for sgn in (1, -1):
@@ -362,19 +364,24 @@ class Trainer:
             ts_n = ts + sgn * dt
             _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, rng)
             _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
-            loss_d = loss_d + 0.04 * temp * masked_mean((ind_disp - ind_disp_n).abs(), mask_t)
+            Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
             loss_d = loss_d + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
         # ---- pass E: static field with gradient, rays with gradient (pose / focal)
         oE, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
         m = (1.0 - fg)[:, None]
-        loss_s = masked_mean((outE[4] - rgb_t) ** 2, m) / 3.0
+        Ls = LossTerms()
+        loss_s = 0.0
+        Ls.add(1.0 / 3.0, "square", outE[4], rgb_t, w=m, norm="weight")                  # :1828-1832
         if not self.optimize_poses:    # stand-in for the static depth supervision of the GT-pose configs
-            loss_s = loss_s + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
+            Ls.add(0.04, "abs", outE[5], disp_t, w=m)
         if c["dist_static"] > 0:       # train.py:1841-1861
             loss_s = loss_s + c["dist_static"] * (it / c["n_iters"]) * eff_distloss(outE[7], oE[8].detach(), 1.0 / S)
         if self.optimize_poses:
             loss_s = loss_s + self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static,
-                                               gt_depth, to_depth)
+                                               gt_depth, to_depth, Ls)
+        loss_s = loss_s + Ls.total()
+        loss_d = loss_d + Ld.total()
+        self.terms = (Ld, Ls)
         # ---- factor-space regularisers (train.py:1718-1754, 1863-1885)
         if c["l1_weight"] > 0:
             loss_d = loss_d + c["l1_weight"] * self.dy.density_L1()
@@ -383,7 +390,7 @@ class Trainer:
         # while the gradients are finite; only the gradient is taken (step(): TVLoss.accumulate_grad_)
         return loss_d, loss_s
 
-    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static, gt_depth, to_depth):
+    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static, gt_depth, to_depth, Ls):
         """train.py:1895-2311 (optimize_poses): every term reaches the static field, the poses and the focal."""
         c = self.cfg
         S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
@@ -395,27 +402,26 @@ class Trainer:
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]                       # live: allposes_refine_f / _b
             mm = mask_t * m
             ind_flow, ind_disp = induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, grid, rays, ray_type=rt)
-            loss = loss + 0.02 * temp_static * masked_mean((ind_flow - flow_t).abs(), mm) / 2.0
+            Ls.add(0.01 * temp_static, "abs", ind_flow, flow_t, w=mm, norm="weight")    # :1909-1941 (x 0.02 / 2)
             # P1 / P2: the static field along the flow-displaced ray of the neighbour frame
             rays_n = self.rays_for(ids, poses, focal, uv=grid + flow_t, view_shift=sgn)
             jit, jit_o = rng.jitter(S, rt, rays.device)
             xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
             o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
             _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, ray_type=rt)
-            loss = loss + 0.04 * temp_static * masked_mean((ind_disp - ind_disp_n).abs(), mm)
+            Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
         loss = loss + c["monodepth_static"] * temp_static * frame_median_depth_loss(to_depth(depth_s), gt_depth, view, T,
                                                                                     mask=fg < 0.5)
         # P3 / P4: disparity smoothness against the x+1 / y+1 pixel neighbours (train.py:2123-2311)
         col, row = grid[:, 0], grid[:, 1]
         inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)
-        sm = 0.0
         for uv_n in (torch.stack([torch.clamp(col + 1.0, max=W - 0.5), row], -1),
                      torch.stack([col, torch.clamp(row + 1.0, max=H - 0.5)], -1)):
             rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
             _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
-            sm = sm + ((inv_d - 1.0 / torch.clamp(outN[5], min=1e-6)) ** 2).mean()
-        return loss + 50.0 * temp * sm
+            Ls.add(50.0 * temp, "square", inv_d, 1.0 / torch.clamp(outN[5], min=1e-6))  # :2293-2299
+        return loss
 
     def step(self, shard=None):
         """One iteration on this rank's shard of the batch: forward of every pass, two-phase backward (static
