@@ -2104,6 +2104,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
                                rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 2048, -1, "static_bwd: bad arguments (S <= 2048)");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "static_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   // z_vals never depends on a trainable quantity in the reference (linspace + jitter)
@@ -2188,6 +2189,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 float* g_z, float* g_rays, void* saved, size_t saved_bytes, void* ws,
                                 size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 1024, -1, "dynamic_bwd: bad arguments (S <= 1024)");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "dynamic_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   BwdArgs a;
@@ -2300,6 +2302,7 @@ extern "C" int rdrf_static_features_bwd(const RdrfStaticParams* P, const RdrfFie
                                         const RdrfStaticParams* G, float* g_xn, void* saved, size_t saved_bytes,
                                         void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && G && xn && M > 0 && (g_density || g_app), -1, "static_features_bwd: bad arguments");
   RDRF_CHECK(g_app == nullptr || saved != nullptr, -1, "static_features_bwd: the appearance features need the "
              "saved buffer of their forward call");
@@ -2363,6 +2366,7 @@ extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfF
                                          const RdrfDynamicParams* G, float* g_x, void* saved, size_t saved_bytes,
                                          void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && G && x && t && saved && M > 0 && (g_density || g_blending || g_app || g_xyz_prime), -1,
              "dynamic_features_bwd: bad arguments");
   const int Np = (M + 31) / 32;
@@ -2430,6 +2434,7 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
                                    size_t saved_bytes, void* ws, size_t ws_bytes,
                                    rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0, -1, "scene_flow_bwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "scene_flow_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   const size_t tiles = ((size_t)N * S + 31) / 32;
@@ -2556,6 +2561,7 @@ extern "C" int rdrf_generate_rays_uv_bwd(const int64_t* ids, const float* uv, in
                                          const float* grad_rays, float* grad_poses9, float* grad_focal,
                                          rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && T > 0 && grad_rays && grad_poses9 && grad_focal, -1, "generate_rays_bwd: bad arguments");
   RDRF_LAUNCH("generate_rays_bwd", k_generate_rays_bwd, dim3((N + 255) / 256), dim3(256), stream, ids, uv,
               view_shift, poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9, grad_focal);

@@ -665,6 +665,7 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                float* weight, float* dists, void* saved, size_t saved_bytes,
                                void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "static_fwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "static_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
@@ -700,6 +701,7 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 float* sigma, float* dists, void* saved, size_t saved_bytes,
                                 void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "dynamic_fwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "dynamic_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
@@ -757,6 +759,7 @@ extern "C" int rdrf_static_features_fwd(const RdrfStaticParams* P, const RdrfFie
                                         int M, float* density, float* app, void* saved, size_t saved_bytes,
                                         void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && xn && M > 0 && (density || app), -1, "static_features_fwd: bad arguments");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
              "static_features_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
@@ -788,6 +791,7 @@ extern "C" int rdrf_dynamic_features_fwd(const RdrfDynamicParams* P, const RdrfF
                                          size_t saved_bytes, void* ws, size_t ws_bytes,
                                          rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && x && t && M > 0 && (density || blending || app || xyz_prime), -1,
              "dynamic_features_fwd: bad arguments");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
@@ -817,6 +821,7 @@ extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCf
                                    float* sf_b, void* saved, size_t saved_bytes, void* ws,
                                    size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "scene_flow_fwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "scene_flow_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   FieldArgs a;

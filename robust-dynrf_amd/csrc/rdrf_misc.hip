@@ -60,6 +60,7 @@ extern "C" int rdrf_generate_rays_uv(const int64_t* ids, const float* uv, int vi
                                      const float* focal, int N, int T, int H, int W, int ndc, float near,
                                      float* rays, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(ids && poses9 && focal && rays && N > 0 && T > 0 && H > 0 && W > 0, -1, "generate_rays: bad arguments");
   RDRF_LAUNCH("generate_rays", k_generate_rays, dim3((N + 255) / 256), dim3(256), stream, ids, uv, view_shift,
               poses9, focal, N, T, H, W, ndc, near, rays);
@@ -165,6 +166,7 @@ extern "C" int rdrf_sample_ndc(const float* rays, int N, int S, float near, floa
                                const float* jitter, const float aabb_host[6], float* xyz, float* z,
                                uint8_t* valid, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && aabb_host, -1, "sample_ndc: bad arguments");
   Box b;
   for (int i = 0; i < 3; ++i) {
@@ -182,6 +184,7 @@ extern "C" int rdrf_sample_contract(const float* rays, int N, int S, float near,
                                     const float* jitter_inner, const float* jitter_outer,
                                     float* xyz, float* z, uint8_t* valid, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 1, -1, "sample_contract: bad arguments");
   const long total = (long)N * S;
   RDRF_LAUNCH("sample_contract", k_sample_contract, dim3((unsigned)((total + 255) / 256)),
@@ -299,6 +302,7 @@ extern "C" int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, cons
                                   const float* z, const float* rays, int N, int S, int ray_type,
                                   int add_white_bg, float* const out13[13], rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && out13, -1, "composite_fwd: bad arguments");
   CompArgs a;
   a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
@@ -496,6 +500,7 @@ extern "C" int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, cons
                                   int add_white_bg, const float* const g_out13[13],
                                   float* const g_in8[8], rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && S <= 2048 && g_out13 && g_in8, -1, "composite_bwd: bad arguments (S <= 2048)");
   CompBArgs a;
   a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(64) void k_sample_bwd(const float* __restrict__ ray
 extern "C" int rdrf_sample_bwd(const float* rays, const float* z, int N, int S, int ray_type,
                                const float* grad_xyz, float* grad_rays, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && rays && z && grad_xyz && grad_rays, -1, "sample_bwd: bad arguments");
   RDRF_LAUNCH("sample_bwd", k_sample_bwd, dim3(N), dim3(64), stream, rays, z, N, S, ray_type, grad_xyz,
               grad_rays);
@@ -752,6 +758,7 @@ extern "C" int rdrf_induce_flow_fwd(int H, int W, const float* focal, const floa
                                     const float* rays, int N, int S, int ray_type, float* flow,
                                     float* disp, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && H > 0 && W > 0 && focal && c2w && weights && pts && pts_2d && rays && flow && disp,
              -1, "induce_flow_fwd: bad arguments");
   RDRF_CHECK(ray_type == RDRF_RAY_NDC || ray_type == RDRF_RAY_CONTRACT, -1,
@@ -767,6 +774,7 @@ extern "C" int rdrf_induce_flow_bwd(int H, int W, const float* focal, const floa
                                     float* g_weights, float* g_pts, float* g_rays, float* g_c2w,
                                     float* g_focal, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && H > 0 && W > 0 && focal && c2w && weights && pts && rays, -1,
              "induce_flow_bwd: bad arguments");
   RDRF_CHECK(ray_type == RDRF_RAY_NDC || ray_type == RDRF_RAY_CONTRACT, -1,
@@ -844,6 +852,7 @@ __global__ __launch_bounds__(64) void k_distloss_bwd(const float* __restrict__ w
 extern "C" int rdrf_distloss_fwd(const float* w, const float* m, float interval, const float* interval_pt,
                                  int N, int S, float* loss_ray, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(w && m && loss_ray && N > 0 && S > 0, -1, "distloss_fwd: bad arguments");
   RDRF_LAUNCH("distloss", k_distloss, dim3(N), dim3(64), stream, w, m, interval, interval_pt, N, S, loss_ray);
   return 0;
@@ -851,6 +860,7 @@ extern "C" int rdrf_distloss_fwd(const float* w, const float* m, float interval,
 extern "C" int rdrf_distloss_bwd(const float* w, const float* m, float interval, const float* interval_pt,
                                  int N, int S, const float* g_ray, float* g_w, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(w && m && g_ray && g_w && N > 0 && S > 0, -1, "distloss_bwd: bad arguments");
   RDRF_LAUNCH("distloss_bwd", k_distloss_bwd, dim3(N), dim3(64), stream, w, m, interval, interval_pt, N, S,
               g_ray, g_w);

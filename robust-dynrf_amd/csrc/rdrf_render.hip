@@ -14,6 +14,7 @@ extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* c
                                const float* rays, const float* ts, int N, int S, float near,
                                float far, float* rgb_map, float* depth_map, void* ws, size_t ws_bytes,
                                rdrf_stream_t stream) {
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(PS && PD && cfg_s && cfg_d && rays && ts && rgb_map && depth_map && N > 0 && S > 0, -1,
              "render_fwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "render_fwd: N * S * 3 must stay below 2^31: render in chunks");
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64) void k_selftest(const float* __restrict__ x,
 extern "C" int rdrf_selftest_mlp(const float* x, const float* w, const float* b, int M, int K,
                                  int OUT, float* y, void* ws, size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(x && w && b && y && M > 0, -1, "selftest_mlp: bad arguments");
   RDRF_CHECK(K == 64 && OUT == 64, -1, "selftest_mlp: the self-test layer is 64 -> 64");
   RDRF_CHECK(ws_bytes >= (2 * 32 * 64 + 64) * sizeof(float), -3, "selftest_mlp: workspace too small");
