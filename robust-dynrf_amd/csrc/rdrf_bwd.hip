@@ -1716,6 +1716,7 @@ static void dw_blk(DwJobs& D, int row0, int seg, int e0) {
 #define DW2_MAX_BLK 30
 #define DW2_MAX_PROD 4
 #define DW2_WAVES 12
+#define DW2_MAX_SEG 2
 struct Dw2Prod {     // 32-bit fields: scalar loads (see blk_meta)
   int a, b;          // staged block indices of the dz block / the input block
   int job, bo, k;    // write-out: job, out-block of the job, in-block index of the job
@@ -1729,6 +1730,12 @@ struct Dw2Plan {
   int blk_meta[DW2_MAX_BLK];        // (src << 16) | row0, src 0 = A, 1 = B.  32-bit on purpose: the block index is
                                     // wave-uniform, so these are SCALAR loads (lgkmcnt); byte / short fields
                                     // compile to vector loads whose vmcnt(0) waits drain the data loads in flight
+  // the staged blocks, sorted by (source, first row), form at most DW2_MAX_SEG runs of consecutive rows: a run
+  // is ONE contiguous byte range per tile, so a slot's address needs no per-block metadata (see k_dw2)
+  int nseg;
+  int seg_blk0[DW2_MAX_SEG];          // first staged block of the run
+  int seg_src[DW2_MAX_SEG];           // 0 = A, 1 = B
+  int seg_row0[DW2_MAX_SEG];          // first row of the run inside a tile
   int nprod[DW2_WAVES];
   Dw2Prod prod[DW2_WAVES][DW2_MAX_PROD];
   const int* count;
@@ -1736,6 +1743,7 @@ struct Dw2Plan {
   DwJob job[RDRF_MAX_DW_JOBS];
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dw2_stage[];   // nblk x 256 float4, XOR-swizzled per block
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
@@ -1745,16 +1753,42 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
   constexpr int NT = 64 * DW2_WAVES, NPF = (DW2_MAX_BLK * 256 + NT - 1) / NT;
   // this thread's slots of the tile image: float4 index i*NT + tid -> (block, row, 16-byte chunk)
   f32x4 pf[NPF];
+  // Slot i of this thread is float4 number idx = i*NT + tid of the tile image; its staged block idx >> 8 is
+  // wave-uniform.  The blocks are sorted so that they form <= DW2_MAX_SEG runs of consecutive rows, each run one
+  // contiguous range of a tile: the address is (run base of this tile, scalar) + idx*16 bytes, selected with
+  // scalar compares.  (Looking the block up in the plan inside the loop cost two dependent scalar loads + waits
+  // in front of each of the 10 global loads: 2-4 thousand cycles per tile in which the wave issued no MFMA.)
+  static_assert(DW2_MAX_SEG == 2, "segment select below");
+  // every plan of this path is [dz rows 0..nA) | activation rows 0..nB): two runs (checked on the host)
+  const int sb1 = P.nseg > 1 ? P.seg_blk0[1] : 1 << 20;
+  const int s1 = P.nseg > 1 ? 1 : 0;
+  const float* seg0a = (P.seg_src[0] ? P.B : P.A) + (size_t)P.seg_row0[0] * 32;
+  const float* seg0b = (P.seg_src[s1] ? P.B : P.A) + (size_t)P.seg_row0[s1] * 32 - (size_t)P.seg_blk0[s1] * 1024;
+  const size_t st0 = (size_t)(P.seg_src[0] ? P.B_stride : P.A_stride) * 32,
+               st1 = (size_t)(P.seg_src[s1] ? P.B_stride : P.A_stride) * 32;
+  static_assert(NT == 768, "a slot is three 256-float4 blocks: slot i of wave w holds block 3*i + (w >> 2)");
+  const int wgrp = wave >> 2;   // scalar
+  const int voffb = tid * 16;   // the only per-thread part of an address
+  // Buffer loads: descriptor (scalar, rebuilt per tile from the run's tile base) + voffb + a per-slot scalar
+  // offset.  No vector address temporaries: with 64-bit flat addresses the compiler built them in the prefetch
+  // registers themselves and its waitcnt pass then put `s_waitcnt vmcnt(0)` in front of every load of the batch.
   auto gload = [&](int t) {
+    const float* g0 = seg0a + (size_t)t * st0;
+    const float* g1 = seg0b + (size_t)t * st1;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)g0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)g1, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int idx = i * NT + tid;
-      if (idx < nf4) {
-        const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), w = idx & 255;   // 256 % 64 == 0: wave-uniform
-        const int meta = P.blk_meta[blk], row0 = meta & 0xffff;
-        const float* base = (meta >> 16) ? P.B + ((size_t)t * P.B_stride + row0) * 32
-                                         : P.A + ((size_t)t * P.A_stride + row0) * 32;
-        pf[i] = ld4(base + w * 4);
+      const int blk = 3 * i + wgrp;          // wave-uniform: uniform branches
+      if (blk < P.nblk) {
+#ifndef RDRF_ABL_DW_NOLOAD
+        u32x4 v;
+        if (blk < sb1) v = __builtin_amdgcn_raw_buffer_load_b128(r0, voffb, i * (NT * 16), 0);
+        else v = __builtin_amdgcn_raw_buffer_load_b128(r1, voffb, i * (NT * 16), 0);
+        pf[i] = __builtin_bit_cast(f32x4, v);
+#else
+        pf[i] = f32x4{(float)t, 1.f, 2.f, (float)i};
+#endif
       }
     }
   };
@@ -1762,6 +1796,12 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) rpos[q] = li * 8 + ((4 * h + q) ^ ((li >> 1) & 7));
   const int np = P.nprod[wave];
+  int pa[DW2_MAX_PROD], pb[DW2_MAX_PROD];   // staged block offsets of each product, bias flag in bit 30 of pa (scalars)
+#pragma unroll
+  for (int p = 0; p < DW2_MAX_PROD; ++p) {
+    pa[p] = __builtin_amdgcn_readfirstlane(P.prod[wave][p].a * 256 | (P.prod[wave][p].bias << 30));
+    pb[p] = __builtin_amdgcn_readfirstlane(P.prod[wave][p].b * 256);
+  }
   f32x16 acc[DW2_MAX_PROD];
   float bsum[DW2_MAX_PROD];
 #pragma unroll
@@ -1776,8 +1816,8 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
     __syncthreads();   // every wave is done reading the previous tile
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int idx = i * NT + tid;
-      if (idx < nf4) {
+      if (3 * i + wgrp < P.nblk) {   // uniform
+        const int idx = i * NT + tid;
         const int blk = idx >> 8, w = idx & 255, row = w >> 3;
         dw2_stage[blk * 256 + row * 8 + ((w & 7) ^ ((row >> 1) & 7))] = pf[i];
       }
@@ -1785,16 +1825,20 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
     __syncthreads();
     const int tn = t + gridDim.x;
     if (tn < ntiles) gload(tn);   // lands while the MFMAs below run
+#ifndef RDRF_ABL_DW_NOMFMA
 #pragma unroll
     for (int p = 0; p < DW2_MAX_PROD; ++p) {
       if (p < np) {
-        const Dw2Prod pr = P.prod[wave][p];
-        const f32x4* sa = dw2_stage + pr.a * 256;
-        const f32x4* sb = dw2_stage + pr.b * 256;
+        int oa = pa[p] & 0xffffff, ob = pb[p];
+        // (opaque to the optimiser: with loop-invariant offsets it hoists all 32 LDS read addresses of the
+        // four products out of the tile loop and spills them -- reloads whose vmcnt(0) drain the prefetch)
+        asm volatile("" : "+s"(oa), "+s"(ob));
+        const f32x4* sa = dw2_stage + oa;
+        const f32x4* sb = dw2_stage + ob;
         f32x4 av4[4], bv4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { av4[q] = sa[rpos[q]]; bv4[q] = sb[rpos[q]]; }
-        if (pr.bias) {
+        if (pa[p] >> 30) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) bsum[p] += av4[q].x + av4[q].y + av4[q].z + av4[q].w;
         }
@@ -1807,6 +1851,9 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
         }
       }
     }
+#else
+    if (np > 0) acc[0][0] += dw2_stage[tid & 255].x;   // keep the stage alive
+#endif
     t = tn;
   }
   // write-out: C row i = (rr&3) + 8*(rr>>2) + 4*h (out neuron), column = li (input element)
@@ -1867,6 +1914,31 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
       int tot = 0;
       for (int w = 0; w < DW2_WAVES; ++w) tot += P.nprod[w];
       if (tot == 0) return 0;
+      {  // stage order = (source, first row) order; runs of consecutive rows become segments
+        int order[DW2_MAX_BLK], rank[DW2_MAX_BLK], meta[DW2_MAX_BLK];
+        for (int i = 0; i < P.nblk; ++i) order[i] = i;
+        std::sort(order, order + P.nblk, [&](int x, int y) { return P.blk_meta[x] < P.blk_meta[y]; });
+        for (int i = 0; i < P.nblk; ++i) { rank[order[i]] = i; meta[i] = P.blk_meta[order[i]]; }
+        for (int i = 0; i < P.nblk; ++i) P.blk_meta[i] = meta[i];
+        for (int w = 0; w < DW2_WAVES; ++w)
+          for (int k = 0; k < P.nprod[w]; ++k) { P.prod[w][k].a = rank[P.prod[w][k].a]; P.prod[w][k].b = rank[P.prod[w][k].b]; }
+        P.nseg = 0;
+        for (int i = 0; i < P.nblk; ++i) {
+          if (i == 0 || (meta[i] >> 16) != (meta[i - 1] >> 16) || (meta[i] & 0xffff) != (meta[i - 1] & 0xffff) + 32) {
+            RDRF_CHECK(P.nseg < DW2_MAX_SEG, -2, "dw: the staged rows form more than %d contiguous runs", DW2_MAX_SEG);
+            P.seg_blk0[P.nseg] = i; P.seg_src[P.nseg] = meta[i] >> 16; P.seg_row0[P.nseg] = meta[i] & 0xffff;
+            ++P.nseg;
+          }
+        }
+      }
+      if (getenv("RDRF_DW_DEBUG")) {
+        fprintf(stderr, "dw plan %s: nblk %d products %d segs", name, P.nblk, tot);
+        for (int g = 0; g < P.nseg; ++g) {
+          const int end = g + 1 < P.nseg ? P.seg_blk0[g + 1] : P.nblk;
+          fprintf(stderr, " [%c rows %d..%d]", P.seg_src[g] ? 'B' : 'A', P.seg_row0[g], P.seg_row0[g] + 32 * (end - P.seg_blk0[g]) - 1);
+        }
+        fprintf(stderr, " strides A %d B %d\n", P.A_stride, P.B_stride);
+      }
       const size_t lds = (size_t)P.nblk * 4096;
       if (lds > 48 * 1024)
         RDRF_HIP(hipFuncSetAttribute((const void*)k_dw2, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
