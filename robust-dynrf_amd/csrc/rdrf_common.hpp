@@ -242,6 +242,11 @@ struct Tap1 {
 RDRF_D Tap1 tap1d(float c, int Ls) {
 #pragma clang fp contract(off)
   Tap1 t;
+  // Ls is wave-uniform and loop-invariant: left alone, the optimiser hoists (float)(Ls-1), (float)Ls+1,
+  // (float)(Ls-2) of every (axis, level, factor set) out of the tile loop -- as VECTOR registers (gfx950 has no
+  // scalar float ALU) -- and spills them; each reload is a scratch load + `s_waitcnt vmcnt(0)` in the middle of
+  // the gather sequence, which also waits for every store and gather in flight.  Opaque here = three v_cvt per call.
+  asm volatile("" : "+v"(Ls));   // ("v": Ls differs between the half-waves of some callers)
   float f = ((c + 1.0f) / 2.0f) * (float)(Ls - 1);
   float fl = floorf(f);
   t.w1 = f - fl;
