@@ -339,6 +339,11 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
   const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
   const f32x4 dp = live ? dq * lvv : zero;  // grad wrt the interpolated plane quad
   const f32x4 dl = live ? dq * pv : zero;   // grad wrt the interpolated line quad
+  // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part), before the
+  // atomics: see gather_xy4_bwd
+  const float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
+  const float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
+  const float gcl = 0.5f * (float)(Ls - 1) * dot4(dl, a1 - a0);
   if (MODE == 0) {
     atomic_add4(GP, o00, dp * (tx.w0 * ty.w0), k00);
     atomic_add4(GP, o01, dp * (tx.w1 * ty.w0), k01);
@@ -432,10 +437,6 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
       if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, l1, r, okl);
     }
   }
-  // coordinate gradients (grid_sampler_2d_backward: piecewise-linear in the fractional part)
-  const float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
-  const float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
-  const float gcl = 0.5f * (float)(Ls - 1) * dot4(dl, a1 - a0);
   if (pi == 0) { dx0 += gcx; dx1 += gcy; dx2 += gcl; }
   else if (pi == 1) { dx0 += gcx; dx2 += gcy; dx1 += gcl; }
   else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
@@ -521,6 +522,16 @@ RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, 
   const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
   const f32x4 dp = live ? dq * lvv : zero;
   const f32x4 dl = live ? dq * pv : zero;
+  // coordinate gradients FIRST: they are the last consumers of the gathered taps.  Computed after the atomics
+  // (as the formulas read), the wait for the taps sat behind 16 conditional atomics -- vmcnt is one in-order
+  // counter on gfx9, and with conditional issues the compiler must assume the smallest count -- so every
+  // iteration waited for all of its own atomics to be acknowledged by the memory side.
+  float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
+  float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
+  float gcl = 0.5f * (float)(Ls - 1) * dot4(dl, a1 - a0);
+  // sum over the four quads (rows) of this sample, then hand it to the lane that owns the sample
+  gcx += __shfl_xor(gcx, 16, 64); gcy += __shfl_xor(gcy, 16, 64); gcl += __shfl_xor(gcl, 16, 64);
+  gcx += __shfl_xor(gcx, 32, 64); gcy += __shfl_xor(gcy, 32, 64); gcl += __shfl_xor(gcl, 32, 64);
   const int pkey = ((ty.i0 + 4) << 16) | ((tx.i0 + 4) & 0xffff);
   const Run pr = run_of16(pkey, s16);
   f32x4 r00 = run_scan4_16(k00 ? dp * (tx.w0 * ty.w0) : zero, pr.start, s16);
@@ -566,12 +577,6 @@ RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, 
     okl = lr.tail && tl.ok1 && nz4(r);
     if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)((tl.i0 + 1) << lv) * C + qo, r, okl);
   }
-  float gcx = 0.5f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
-  float gcy = 0.5f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
-  float gcl = 0.5f * (float)(Ls - 1) * dot4(dl, a1 - a0);
-  // sum over the four quads (rows) of this sample, then hand it to the lane that owns the sample
-  gcx += __shfl_xor(gcx, 16, 64); gcy += __shfl_xor(gcy, 16, 64); gcl += __shfl_xor(gcl, 16, 64);
-  gcx += __shfl_xor(gcx, 32, 64); gcy += __shfl_xor(gcy, 32, 64); gcl += __shfl_xor(gcl, 32, 64);
   if (q_is_owner) { dx0 += gcx; dx1 += gcy; dx2 += gcl; }
 }
 
@@ -620,6 +625,10 @@ RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, 
   const f32x4 lvv = a0 * tl.w0 + a1 * tl.w1;
   const f32x4 dp = live ? dq * lvv : zero;
   const f32x4 dl = live ? dq * pv : zero;
+  // (coordinate gradients before the atomics: see gather_xy4_bwd)
+  const float gcx = 0.25f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
+  const float gcy = 0.25f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
+  const float gcl = 0.25f * (float)(Ls - 1) * dot4(dl, a1 - a0);
   // this half's column
   const float wxc = h ? tx.w1 : tx.w0;
   const bool okc = h ? tx.ok1 : tx.ok0;
@@ -652,9 +661,6 @@ RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, 
     if (ll.base) lds_add4(ll.base + (pi == 1 ? ll.off[1] : ll.off[2]), (li << lv) * lds_stride(C) + qo, r, doit);
     else atomic_add4(GL, (size_t)(li << lv) * C + qo, r, doit);
   }
-  const float gcx = 0.25f * (float)(Ws - 1) * dot4(dp, (v01 - v00) * ty.w0 + (v11 - v10) * ty.w1);
-  const float gcy = 0.25f * (float)(Hs - 1) * dot4(dp, (v10 - v00) * tx.w0 + (v11 - v01) * tx.w1);
-  const float gcl = 0.25f * (float)(Ls - 1) * dot4(dl, a1 - a0);
   if (pi == 1) { dx0 += gcx; dx2 += gcy; dx1 += gcl; }
   else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
 }
