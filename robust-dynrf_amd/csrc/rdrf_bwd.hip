@@ -691,6 +691,26 @@ RDRF_D float act_grad(float f, int act, float shift) {
   return act == RDRF_ACT_RELU ? (f > 0.0f ? 1.0f : 0.0f) : sigmoidf_(f + shift);
 }
 
+// backward of a small output layer kept on the VALU (NO <= 6 outputs): dz[kk] = relu'(H[kk]) * sum_o W[o][kk] dzo[o]
+// for this lane half's KK inputs.  ws = [NO][2][KK] in LDS, read as 16-byte quads (element-wise `lds[...]` reads
+// compiled to one ds_read_b32 + lgkmcnt(0) wait per weight).
+template <int KK, int NO>
+RDRF_D void small_layer_bwd(float (&dz)[KK], const float (&H)[KK], const float* __restrict__ ws, int h,
+                            const float (&dzo)[NO]) {
+#pragma unroll
+  for (int q = 0; q < KK / 4; ++q) {
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + o * 2 * KK + h * KK + 4 * q);
+      d.x = fmaf(wv.x, dzo[o], d.x); d.y = fmaf(wv.y, dzo[o], d.y);
+      d.z = fmaf(wv.z, dzo[o], d.z); d.w = fmaf(wv.w, dzo[o], d.w);
+    }
+    dz[4 * q + 0] = H[4 * q + 0] > 0.f ? d.x : 0.f; dz[4 * q + 1] = H[4 * q + 1] > 0.f ? d.y : 0.f;
+    dz[4 * q + 2] = H[4 * q + 2] > 0.f ? d.z : 0.f; dz[4 * q + 3] = H[4 * q + 3] > 0.f ? d.w : 0.f;
+  }
+}
+
 template <int NB>
 RDRF_D void acc_zero(f32x16 (&acc)[NB]) {
 #pragma unroll
@@ -756,13 +776,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
       if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
     }
     float dz2[64];
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) {
-      float d = 0.f;
-#pragma unroll
-      for (int o = 0; o < 3; ++o) d = fmaf(lds[pkb::K3_RGBV + o * 128 + h * 64 + kk], dzv[o], d);
-      dz2[kk] = H2[kk] > 0.f ? d : 0.f;
-    }
+    small_layer_bwd<64, 3>(dz2, H2, lds + pkb::K3_RGBV, h, dzv);
     save_rows<64>(gb, sv::K3G_DZ2, dz2, s, h);
     // ---- layer 2 backward: dH1 = W2^T dz2
     float dz1[64];
@@ -855,13 +869,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
       if (h == 0) gb[(size_t)(sv::K3G_DZV + o) * 32 + s] = dzv[o];
     }
     float dz2[64];
-#pragma unroll
-    for (int kk = 0; kk < 64; ++kk) {
-      float d = 0.f;
-#pragma unroll
-      for (int o = 0; o < 3; ++o) d = fmaf(lds[pkb::S3_W3 + o * 128 + h * 64 + kk], dzv[o], d);
-      dz2[kk] = H2[kk] > 0.f ? d : 0.f;
-    }
+    small_layer_bwd<64, 3>(dz2, H2, lds + pkb::S3_W3, h, dzv);
     save_rows<64>(gb, sv::K3G_DZ2, dz2, s, h);
     float dz1[64];
     {
@@ -1275,8 +1283,14 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
           float Hh[32], dzh[32];
           load_rows<32>(svb, head == 0 ? sv::K1_HD : sv::K1_HB, Hh, s, h);
           const float* w2 = lds + (head == 0 ? pkb::K1H_DEN2 : pkb::K1H_BLE2) + h * 32;
+          float w2r[32];   // eight 16-byte LDS reads up front (element-wise reads were 32 x {ds_read_b32, lgkmcnt(0)})
 #pragma unroll
-          for (int kk = 0; kk < 32; ++kk) dzh[kk] = Hh[kk] > 0.f ? w2[kk] * gfh : 0.f;
+          for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w2 + 4 * q);
+            w2r[4 * q] = v.x; w2r[4 * q + 1] = v.y; w2r[4 * q + 2] = v.z; w2r[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int kk = 0; kk < 32; ++kk) dzh[kk] = Hh[kk] > 0.f ? w2r[kk] * gfh : 0.f;
           save_rows<32>(gb, head == 0 ? sv::K1G_DZD : sv::K1G_DZB, dzh, s, h);
           f32x16 accF[3];
           acc_zero<3>(accF);
@@ -1319,9 +1333,15 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
           load_rows<32>(svb, sv::K1_H4, H4, s, h);
           const float* w5 = lds + pkb::K1W_W5 + h * 32;
 #pragma unroll
-          for (int kk = 0; kk < 32; ++kk) {
-            const float d = w5[kk] * dd0 + w5[64 + kk] * dd1 + w5[128 + kk] * dd2;
-            dz4[kk] = H4[kk] > 0.f ? d : 0.f;
+          for (int q = 0; q < 8; ++q) {   // 16-byte LDS reads (see the heads above)
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(w5 + 4 * q);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w5 + 64 + 4 * q);
+            const f32x4 wc = *reinterpret_cast<const f32x4*>(w5 + 128 + 4 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float d = wa[c] * dd0 + wb[c] * dd1 + wc[c] * dd2;
+              dz4[4 * q + c] = H4[4 * q + c] > 0.f ? d : 0.f;
+            }
           }
         }
         save_rows<32>(gb, sv::K1G_DZ4, dz4, s, h);
@@ -1514,13 +1534,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_scene_flow_bwd(int N, int S,
     }
     float dz[32], Hh[32];
     load_rows<32>(svb, sv::SF_H4, Hh, s, h);
-#pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-      float d = 0.f;
-#pragma unroll
-      for (int o = 0; o < 6; ++o) d = fmaf(lds[pkb::SF_W6 + o * 64 + h * 32 + kk], dz6[o], d);
-      dz[kk] = Hh[kk] > 0.f ? d : 0.f;
-    }
+    small_layer_bwd<32, 6>(dz, Hh, lds + pkb::SF_W6, h, dz6);
     save_rows<32>(gb, sv::SFG_DZ4, dz, s, h);
     f32x16 acc[2];
     acc_zero<2>(acc);
