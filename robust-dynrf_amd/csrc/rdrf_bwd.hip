@@ -437,9 +437,12 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
       if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, l1, r, okl);
     }
   }
-  if (pi == 0) { dx0 += gcx; dx1 += gcy; dx2 += gcl; }
-  else if (pi == 1) { dx0 += gcx; dx2 += gcy; dx1 += gcl; }
-  else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
+  // plane 0 = (x, y | z), 1 = (x, z | y), 2 = (y, z | x).  Selects, not branches: pi differs between the lane
+  // halves of the appearance scatter, and the branchy form made the compiler keep dx0..2 in a scratch array
+  // indexed per lane (scratch load + vmcnt(0) + store per update, draining the atomics in flight).
+  dx0 += pi == 2 ? gcl : gcx;
+  dx1 += pi == 0 ? gcy : (pi == 1 ? gcl : gcx);
+  dx2 += pi == 0 ? gcl : gcy;
 }
 
 // XY quads, four at a time: the wave works on 16 samples (sub-tile j of the 32-sample tile) and the
@@ -661,8 +664,9 @@ RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, 
     if (ll.base) lds_add4(ll.base + (pi == 1 ? ll.off[1] : ll.off[2]), (li << lv) * lds_stride(C) + qo, r, doit);
     else atomic_add4(GL, (size_t)(li << lv) * C + qo, r, doit);
   }
-  if (pi == 1) { dx0 += gcx; dx2 += gcy; dx1 += gcl; }
-  else { dx1 += gcx; dx2 += gcy; dx0 += gcl; }
+  dx0 += pi == 1 ? gcx : gcl;   // plane 1 = (x, z | y), 2 = (y, z | x)
+  dx1 += pi == 1 ? gcl : gcx;
+  dx2 += gcy;
 }
 
 // d(X0)/d(xn): X0 = [xn, t | (sin q, cos q) pairs], q_j = xn[j/10] * 2^(j%10); returns this lane
