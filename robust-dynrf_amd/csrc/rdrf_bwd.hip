@@ -685,7 +685,8 @@ RDRF_D void x0_bwd(const float (&X0)[32], const float (&dX0)[32], int h, float& 
         const int d = j / 10, f = j - d * 10;
         const float sv = X0[o * 4 + 2 * p], cv = X0[o * 4 + 2 * p + 1];
         const float dq = ldexpf(dX0[o * 4 + 2 * p] * cv - dX0[o * 4 + 2 * p + 1] * sv, f);
-        if (d == 0) d0 += dq; else if (d == 1) d1 += dq; else d2 += dq;
+        // (selects: d differs between the lane halves, and a branchy update makes d0..2 a scratch array indexed per lane)
+        d0 += d == 0 ? dq : 0.f; d1 += d == 1 ? dq : 0.f; d2 += d == 2 ? dq : 0.f;
       }
     }
   }
@@ -1502,7 +1503,7 @@ RDRF_D void sf_x_bwd(const float (&X)[20], const float (&dX)[20], int h, float& 
           const int d = pr >> 2, f = pr & 3;
           const float dq = ldexpf(dX[o * 4 + 2 * p] * X[o * 4 + 2 * p + 1] -
                                   dX[o * 4 + 2 * p + 1] * X[o * 4 + 2 * p], f);
-          if (d == 0) d0 += dq; else if (d == 1) d1 += dq; else d2 += dq;
+          d0 += d == 0 ? dq : 0.f; d1 += d == 1 ? dq : 0.f; d2 += d == 2 ? dq : 0.f;   // selects, see x0_bwd
         }
       }
     }

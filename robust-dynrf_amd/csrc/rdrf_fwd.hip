@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) {
         int base = 0;
         if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
         base = __shfl(base, 0, 64);
-        if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+        if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
       }
     }
   }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, Dyn
       int base = 0;
       if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
       base = __shfl(base, 0, 64);
-      if (m) a.list[base + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+      if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
     }
     }
   }
