@@ -163,14 +163,21 @@ class SyntheticScene:
         self.flow_mask_b = (torch.rand(self.total, 1, generator=g) < 0.8).float().to(device)
         self.perm = torch.randperm(self.total, generator=g).to(device)
         self.device = device
+        # per-pixel tables the loader keeps next to the colours (train.py:826-846 stores rays / grids per pixel
+        # the same way): pixel centre (col + 0.5, row + 0.5), frame index, normalised time -- one gather each
+        # per batch instead of a dozen integer kernels
+        pix = torch.arange(self.total)
+        col, row, view = pix % W, (pix // W) % H, pix // (W * H)
+        self.grid_table = torch.stack([col.float() + 0.5, row.float() + 0.5], -1).to(device)
+        self.view_table = view.to(device)
+        self.ts_table = (view.float() * (2.0 / (T - 1)) - 1.0).to(device)
 
     def batch(self, it, bs, which=0):
         off = ((it * 3 + which) * bs) % (self.total - bs)
         return self.perm[off: off + bs]
 
     def ts_of(self, ids):
-        T, H, W = self.cfg["T"], self.cfg["H"], self.cfg["W"]
-        return (ids // (H * W)).float() * (2.0 / (T - 1)) - 1.0
+        return self.ts_table[ids]
 
     def make_batch(self, it, bs, shard=None):
         """everything one iteration reads, as a dict of device tensors (train.py:1043-1060)"""
@@ -179,7 +186,8 @@ class SyntheticScene:
             r, w = shard
             lo, hi = r * bs // w, (r + 1) * bs // w
             ids, ids2 = ids[lo:hi], ids2[lo:hi]
-        return dict(ids=ids, ts=self.ts_of(ids), ts_rand=self.ts_of(ids2), rgb=self.rgb[ids], disp=self.disp[ids],
+        return dict(ids=ids, ts=self.ts_of(ids), ts_rand=self.ts_of(ids2), grid=self.grid_table[ids],
+                    view=self.view_table[ids], rgb=self.rgb[ids], disp=self.disp[ids],
                     fg=self.fgmask[ids], flow_f=self.flow_f[ids], flow_b=self.flow_b[ids],
                     mask_f=self.flow_mask_f[ids], mask_b=self.flow_mask_b[ids])
 
@@ -291,6 +299,7 @@ class Trainer:
         self.tv = TVLoss()
         self.grad_flats = self.opt.grad_flats()
         self.last = {}
+        self._c2w_fixed = None
 
     # ---- geometry ----------------------------------------------------------------------------------
     def focal(self):
@@ -322,9 +331,17 @@ class Trainer:
         rays_d = rays.detach()
         poses_d, focal_d = poses.detach(), (focal.detach() if torch.is_tensor(focal) else focal)
         dt = 2.0 / (T - 1)
-        col, row, view = ids2pixel(W, H, ids)
-        grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
-        c2w_all = pose_to_mtx(poses)
+        if "grid" in b:
+            grid, view = b["grid"], b["view"]
+        else:
+            col, row, view = ids2pixel(W, H, ids)
+            grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+        if self.optimize_poses:
+            c2w_all = pose_to_mtx(poses)
+        else:   # fixed poses: the [T,3,4] table is a constant of the run
+            if self._c2w_fixed is None:
+                self._c2w_fixed = pose_to_mtx(poses).detach()
+            c2w_all = self._c2w_fixed
         temp = 1.0 / (10 ** (it // 100000))                # Temp / Temp_disp_TV / Temp_static, train.py:1034-1036
         temp_static = 1.0 / (10 ** (it / 100000.0))
         gt_depth = -disp_t if rt == "ndc" else disp_t      # train.py:1645-1653
