@@ -149,6 +149,23 @@ def workspace(device, nbytes):
     return buf
 
 
+def zeros_like_many(tensors, want=None):
+    """torch.zeros_like for several tensors with ONE fill launch: contiguous fp32 views (256-byte aligned) of a
+    single zeroed buffer; entries that are None (or whose `want` flag is false) come back as None."""
+    want = [t is not None for t in tensors] if want is None else [bool(w) and t is not None for t, w in zip(tensors, want)]
+    sizes = [((t.numel() + 63) // 64) * 64 if w else 0 for t, w in zip(tensors, want)]
+    total = sum(sizes)
+    if total == 0:
+        return [None] * len(tensors)
+    dev = next(t.device for t, w in zip(tensors, want) if w)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    out, o = [], 0
+    for t, w, n in zip(tensors, want, sizes):
+        out.append(flat[o: o + t.numel()].view(t.shape) if w else None)
+        o += n
+    return out
+
+
 def f32c(t):
     """contiguous fp32 view (no copy when already so)"""
     if t.dtype != torch.float32:

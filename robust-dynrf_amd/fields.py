@@ -228,9 +228,7 @@ class _StaticFn(torch.autograd.Function):
         P = _static_struct(params)
         cfg = _cfg_struct(ctx.field, ctx.ray_type)
         need = ctx.needs_input_grad
-        g_rays = torch.zeros_like(rays) if need[2] else None
-        g_xyz = torch.zeros_like(xyz) if need[4] else None
-        g_z = torch.zeros_like(z) if need[5] else None
+        g_rays, g_xyz, g_z = L.zeros_like_many([rays, xyz, z], [need[2], need[4], need[5]])
         cont = lambda g: None if g is None else L.f32c(g)
         g_rgb, g_sigma, g_weight, g_dists = cont(g_rgb), cont(g_sigma), cont(g_weight), cont(g_dists)
         ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
@@ -289,9 +287,7 @@ class _DynamicFn(torch.autograd.Function):
         P = _dynamic_struct(params)
         cfg = _cfg_struct(ctx.field, ctx.ray_type)
         need = ctx.needs_input_grad
-        g_rays = torch.zeros_like(rays) if need[2] else None
-        g_xyz = torch.zeros_like(xyz) if need[4] else None
-        g_z = torch.zeros_like(z) if need[5] else None
+        g_rays, g_xyz, g_z = L.zeros_like_many([rays, xyz, z], [need[2], need[4], need[5]])
         cont = lambda g: None if g is None else L.f32c(g)
         gb, gw, gxp, gr, gs, gd = (cont(g) for g in (g_blending, g_weight, g_xyz_prime, g_rgb,
                                                       g_sigma, g_dists))

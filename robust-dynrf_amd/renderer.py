@@ -117,7 +117,7 @@ class _CompositeFn(torch.autograd.Function):
         need[1] = need[1] and have((0, 1, 2, 3, 4, 5, 6, 7, 12))
         need[3] = need[3] and have((0, 1, 2, 3, 8, 9, 10, 11, 12))
         need[5] = need[5] and have((0, 1, 2, 3, 8, 9, 10, 11, 12))
-        g_in = [torch.zeros_like(t) if n else None for t, n in zip(ins, need)]
+        g_in = L.zeros_like_many(ins, need)   # one fill for the (up to eight) gradient tensors
         ga = (C.c_void_p * 13)(*[0 if g is None else g.data_ptr() for g in g_out])
         gi = (C.c_void_p * 8)(*[0 if g is None else g.data_ptr() for g in g_in])
         L.check(L.lib.rdrf_composite_bwd(*[L.ptr(t) for t in ins], N, S,
@@ -253,11 +253,8 @@ class _InduceFlowFn(torch.autograd.Function):
         focal, c2w, weights, pts, rays = ctx.saved_tensors
         N, S = weights.shape
         need = ctx.needs_input_grad     # H, W, focal, c2w, weights, pts, pts_2d, rays, ray_type
-        g_focal = torch.zeros_like(focal) if need[2] else None
-        g_c2w = torch.zeros_like(c2w) if need[3] else None
-        g_w = torch.zeros_like(weights) if need[4] else None
-        g_pts = torch.zeros_like(pts) if need[5] else None
-        g_rays = torch.zeros_like(rays) if need[7] else None
+        g_focal, g_c2w, g_w, g_pts, g_rays = L.zeros_like_many([focal, c2w, weights, pts, rays],
+                                                               [need[2], need[3], need[4], need[5], need[7]])
         g_flow = None if g_flow is None else L.f32c(g_flow)
         g_disp = None if g_disp is None else L.f32c(g_disp)
         L.check(L.lib.rdrf_induce_flow_bwd(ctx.hw[0], ctx.hw[1], L.ptr(focal), L.ptr(c2w), L.ptr(weights),
