@@ -74,6 +74,10 @@ typedef struct {
   float *w1, *b1;       /* renderModule.mlp.0 (128,138) | (128,135) */
   float *w2, *b2;       /* renderModule.mlp.2 (128,128) */
   float *w3, *b3;       /* renderModule.mlp.4 (3,128) | renderModule.mlp_view.0 (3,131) */
+  /* optional (NULL = the entry point packs into its workspace, as before): images written by rdrf_static_pack
+   * for THESE weights.  The caller owns their validity: re-pack after every change of w1..b3 / basis. */
+  const float* packed_fwd;
+  const float* packed_bwd;
 } RdrfStaticParams;
 
 /* Dynamic TensorVMSplit_TimeEmbedding parameters. */
@@ -91,6 +95,8 @@ typedef struct {
   float *dw1, *db1, *dw2, *db2; /* density_layer1 (64,152), density_layer2 (1,64) */
   float *bw1, *bb1, *bw2, *bb2; /* blending_layer1/2 */
   float *sfw[4], *sfb[4];       /* scene_flow_mlp.{0,2,4,6}: (64,36)(64,64)(64,64)(6,64) */
+  const float* packed_fwd;      /* optional images of rdrf_dynamic_pack (see RdrfStaticParams) */
+  const float* packed_bwd;
 } RdrfDynamicParams;
 
 int rdrf_abi_version(void);
@@ -306,6 +312,16 @@ int rdrf_upsample_bilinear(const RdrfTensor4* src, const RdrfTensor4* dst, int n
 int rdrf_dense_l1_fwd(const RdrfVM* vm, int act, float density_shift, float* sum_out, rdrf_stream_t stream);
 int rdrf_dense_l1_bwd(const RdrfVM* vm, const RdrfVM* gvm, int act, float density_shift, const float* g_mean,
                       rdrf_stream_t stream);
+
+/* ---- packed weight images.  Every field entry point first re-lays its MLP weights out for the MFMA kernels
+ * (a ~6 us launch, ~40 of them per training iteration).  The weights of a field do not change between the passes
+ * of one iteration or the chunks of a render, so a caller may pack once and hand the image in through
+ * packed_fwd / packed_bwd of the parameter struct.  image: rdrf_pack_floats() floats, 16-byte aligned.
+ * backward = 0: the image of *_fwd / *_features_fwd / scene_flow_fwd / render_fwd; 1: of the *_bwd entry points.
+ * The factor tensors (planes / lines) are NOT part of the image. */
+size_t rdrf_pack_floats(void);
+int rdrf_static_pack(const RdrfStaticParams* P, int static_head, int backward, float* image, rdrf_stream_t stream);
+int rdrf_dynamic_pack(const RdrfDynamicParams* P, int backward, float* image, rdrf_stream_t stream);
 
 /* ---- the per-ray / per-sample loss terms of one iteration, reduced in one launch (+ a finishing launch)
  * and differentiated in one launch.  Replaces the elementwise chains of train.py:1323-1331 (photometric),

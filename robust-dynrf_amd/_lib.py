@@ -33,7 +33,7 @@ class RdrfFieldCfg(C.Structure):
 class RdrfStaticParams(C.Structure):
     _fields_ = [("density", RdrfVM), ("app", RdrfVM), ("basis", C.c_void_p),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
-                ("w3", C.c_void_p), ("b3", C.c_void_p)]
+                ("w3", C.c_void_p), ("b3", C.c_void_p), ("packed_fwd", C.c_void_p), ("packed_bwd", C.c_void_p)]
 
 
 class RdrfDynamicParams(C.Structure):
@@ -45,7 +45,7 @@ class RdrfDynamicParams(C.Structure):
                 ("l5w", C.c_void_p), ("l5b", C.c_void_p),
                 ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
                 ("bw1", C.c_void_p), ("bb1", C.c_void_p), ("bw2", C.c_void_p), ("bb2", C.c_void_p),
-                ("sfw", C.c_void_p * 4), ("sfb", C.c_void_p * 4)]
+                ("sfw", C.c_void_p * 4), ("sfb", C.c_void_p * 4), ("packed_fwd", C.c_void_p), ("packed_bwd", C.c_void_p)]
 
 
 def _load():
@@ -67,6 +67,8 @@ def _load():
     lib.rdrf_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
                                    C.c_void_p]
+    lib.rdrf_pack_floats.restype = C.c_size_t
+    lib.rdrf_pack_floats.argtypes = []
     lib.rdrf_loss_terms_workspace_floats.restype = C.c_size_t
     lib.rdrf_loss_terms_workspace_floats.argtypes = [C.c_int]
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
@@ -91,7 +93,7 @@ SYMBOLS = [
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
     "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
-    "rdrf_dense_l1_bwd", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
+    "rdrf_dense_l1_bwd", "rdrf_pack_floats", "rdrf_static_pack", "rdrf_dynamic_pack", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]

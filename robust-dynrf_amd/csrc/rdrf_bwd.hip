@@ -2218,10 +2218,13 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   fill_static_w(w, P);
   StaticG gw;
   gw.density = G->density; gw.app = G->app; gw.b3 = G->b3; gw.w3 = G->w3;
-  PackJobs J;
-  static_pack_jobs_bwd(J, P, cfg->static_head);
-  rc = pack_launch(J, b.pk, stream);
-  if (rc) return rc;
+  if (P->packed_bwd != nullptr) a.pk = P->packed_bwd;   // caller-packed image (rdrf_static_pack)
+  else {
+    PackJobs J;
+    static_pack_jobs_bwd(J, P, cfg->static_head);
+    rc = pack_launch(J, b.pk, stream);
+    if (rc) return rc;
+  }
   const size_t t3 = ((size_t)N * S + 31) / 32;
   if (g_rgb != nullptr) {
     const Geo g = geo_for_units((long)t3);
@@ -2304,10 +2307,13 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   DynG gw;
   gw.density = G->density; gw.blending = G->blending; gw.app = G->app;
   gw.rbv = G->rbv; gw.rwv = G->rwv; gw.l5b = G->l5b; gw.db2 = G->db2; gw.bb2 = G->bb2;
-  PackJobs J;
-  dyn_pack_jobs_bwd(J, P);
-  rc = pack_launch(J, b.pk, stream);
-  if (rc) return rc;
+  if (P->packed_bwd != nullptr) a.pk = P->packed_bwd;   // caller-packed image (rdrf_dynamic_pack)
+  else {
+    PackJobs J;
+    dyn_pack_jobs_bwd(J, P);
+    rc = pack_launch(J, b.pk, stream);
+    if (rc) return rc;
+  }
   const size_t ns = (size_t)N * S, t3 = (ns + 31) / 32, t1 = (size_t)N * ((S + 31) / 32);
   RDRF_HIP(hipMemsetAsync(b.dxw, 0, ns * 3 * 4, stream));
   RDRF_HIP(hipMemsetAsync(b.dxn, 0, ns * 3 * 4, stream));
@@ -2435,10 +2441,13 @@ extern "C" int rdrf_static_features_bwd(const RdrfStaticParams* P, const RdrfFie
     fill_static_w(w, P);
     StaticG gw;
     gw.density = G->density; gw.app = G->app; gw.b3 = G->b3; gw.w3 = G->w3;
-    PackJobs J;
-    static_pack_jobs_bwd(J, P, cfg->static_head);
-    rc = pack_launch(J, b.pk, stream);
-    if (rc) return rc;
+    if (P->packed_bwd != nullptr) a.pk = P->packed_bwd;
+    else {
+      PackJobs J;
+      static_pack_jobs_bwd(J, P, cfg->static_head);
+      rc = pack_launch(J, b.pk, stream);
+      if (rc) return rc;
+    }
     const Geo g = geo_for_units(Np);
     RDRF_LAUNCH("feat_static_app_bwd", (k_static_app_bwd<RDRF_HEAD_MLP_FEA, true>), dim3(g.grid), dim3(g.block),
                 stream, a, w, gw);
@@ -2482,10 +2491,13 @@ extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfF
   DynG gw;
   gw.density = G->density; gw.blending = G->blending; gw.app = G->app;
   gw.rbv = G->rbv; gw.rwv = G->rwv; gw.l5b = G->l5b; gw.db2 = G->db2; gw.bb2 = G->bb2;
-  PackJobs J;
-  dyn_pack_jobs_bwd(J, P);
-  rc = pack_launch(J, b.pk, stream);
-  if (rc) return rc;
+  if (P->packed_bwd != nullptr) a.pk = P->packed_bwd;   // caller-packed image (rdrf_dynamic_pack)
+  else {
+    PackJobs J;
+    dyn_pack_jobs_bwd(J, P);
+    rc = pack_launch(J, b.pk, stream);
+    if (rc) return rc;
+  }
   RDRF_HIP(hipMemsetAsync(b.valid, 0, mp, stream));
   RDRF_HIP(hipMemsetAsync(b.valid, 1, (size_t)M, stream));
   RDRF_HIP(hipMemsetAsync(b.dxw, 0, mp * 3 * 4, stream));
@@ -2540,13 +2552,18 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
   float* pkbuf = c.take<float>(PACK_AREA_FLOATS);
   float* grows = c.take<float>(tiles * sv::SFG_ROWS * 32);
   RDRF_CHECK(c.ok(), -3, "scene_flow_bwd: workspace too small: need %zu have %zu", c.off, ws_bytes);
-  PackJobs J;
-  dyn_pack_jobs_bwd(J, P);
-  int rc = pack_launch(J, pkbuf, stream);
-  if (rc) return rc;
+  const float* pkimg = pkbuf;
+  int rc = 0;
+  if (P->packed_bwd != nullptr) pkimg = P->packed_bwd;
+  else {
+    PackJobs J;
+    dyn_pack_jobs_bwd(J, P);
+    rc = pack_launch(J, pkbuf, stream);
+    if (rc) return rc;
+  }
   const Geo g = geo_for_units((long)tiles);
   RDRF_LAUNCH("scene_flow_bwd", k_scene_flow_bwd, dim3(g.grid), dim3(g.block), stream, N, S,
-              make_box(cfg), pkbuf, (const float*)saved, grows, g_sf_f, g_sf_b, G->sfb[3], g_pts);
+              make_box(cfg), pkimg, (const float*)saved, grows, g_sf_f, g_sf_b, G->sfb[3], g_pts);
   const float* act = (const float*)saved;
   const int T = (int)tiles;
   DwJobs D;
@@ -2670,4 +2687,24 @@ extern "C" int rdrf_generate_rays_bwd(const int64_t* ids, const float* poses9, c
                                       rdrf_stream_t stream_) {
   return rdrf_generate_rays_uv_bwd(ids, nullptr, 0, poses9, focal, N, T, H, W, ndc, near, grad_rays, grad_poses9,
                                    grad_focal, stream_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// caller-managed packed weight images (include/rodynrf.h)
+// ------------------------------------------------------------------------------------------------
+void dyn_pack_jobs_fwd(PackJobs& J, const RdrfDynamicParams* P);
+void static_pack_jobs_fwd(PackJobs& J, const RdrfStaticParams* P, int head);
+extern "C" size_t rdrf_pack_floats(void) { return PACK_AREA_FLOATS; }
+extern "C" int rdrf_static_pack(const RdrfStaticParams* P, int static_head, int backward, float* image,
+                                rdrf_stream_t stream_) {
+  RDRF_CHECK(P && image && (((uintptr_t)image) & 15) == 0, -1, "static_pack: bad arguments");
+  PackJobs J;
+  if (backward) static_pack_jobs_bwd(J, P, static_head); else static_pack_jobs_fwd(J, P, static_head);
+  return pack_launch(J, image, (hipStream_t)stream_);
+}
+extern "C" int rdrf_dynamic_pack(const RdrfDynamicParams* P, int backward, float* image, rdrf_stream_t stream_) {
+  RDRF_CHECK(P && image && (((uintptr_t)image) & 15) == 0, -1, "dynamic_pack: bad arguments");
+  PackJobs J;
+  if (backward) dyn_pack_jobs_bwd(J, P); else dyn_pack_jobs_fwd(J, P);
+  return pack_launch(J, image, (hipStream_t)stream_);
 }

@@ -677,10 +677,13 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   if (rc) return rc;
   StaticW w;
   fill_static_w(w, P);
-  PackJobs J;
-  static_pack_jobs_fwd(J, P, cfg->static_head);
-  rc = pack_launch(J, (float*)a.pk, stream);
-  if (rc) return rc;
+  if (P->packed_fwd != nullptr) a.pk = P->packed_fwd;   // caller-packed image (rdrf_static_pack)
+  else {
+    PackJobs J;
+    static_pack_jobs_fwd(J, P, cfg->static_head);
+    rc = pack_launch(J, (float*)a.pk, stream);
+    if (rc) return rc;
+  }
   RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
   RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
   RDRF_LAUNCH("static_density", k_static_density<false>, dim3(N), dim3(64), stream, a, w);
@@ -714,10 +717,13 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   if (rc) return rc;
   DynW w;
   fill_dyn_w(w, P);
-  PackJobs J;
-  dyn_pack_jobs_fwd(J, P);
-  rc = pack_launch(J, (float*)a.pk, stream);
-  if (rc) return rc;
+  if (P->packed_fwd != nullptr) a.pk = P->packed_fwd;   // caller-packed image (rdrf_dynamic_pack)
+  else {
+    PackJobs J;
+    dyn_pack_jobs_fwd(J, P);
+    rc = pack_launch(J, (float*)a.pk, stream);
+    if (rc) return rc;
+  }
   RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
   RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
   RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout);
@@ -774,10 +780,13 @@ extern "C" int rdrf_static_features_fwd(const RdrfStaticParams* P, const RdrfFie
   if (density != nullptr)
     RDRF_LAUNCH("feat_static_density", k_static_density<true>, dim3(Np), dim3(64), stream, a, w);
   if (app != nullptr) {
-    PackJobs J;
-    static_pack_jobs_fwd(J, P, cfg->static_head);
-    rc = pack_launch(J, (float*)a.pk, stream);
-    if (rc) return rc;
+    if (P->packed_fwd != nullptr) a.pk = P->packed_fwd;
+    else {
+      PackJobs J;
+      static_pack_jobs_fwd(J, P, cfg->static_head);
+      rc = pack_launch(J, (float*)a.pk, stream);
+      if (rc) return rc;
+    }
     const Geo g = geo_for_units(Np);
     RDRF_LAUNCH("feat_static_app", (k_static_app<RDRF_HEAD_MLP_FEA, true>), dim3(g.grid), dim3(g.block), stream,
                 a, w);
@@ -805,10 +814,13 @@ extern "C" int rdrf_dynamic_features_fwd(const RdrfDynamicParams* P, const RdrfF
   if (rc) return rc;
   DynW w;
   fill_dyn_w(w, P);
-  PackJobs J;
-  dyn_pack_jobs_fwd(J, P);
-  rc = pack_launch(J, (float*)a.pk, stream);
-  if (rc) return rc;
+  if (P->packed_fwd != nullptr) a.pk = P->packed_fwd;   // caller-packed image (rdrf_dynamic_pack)
+  else {
+    PackJobs J;
+    dyn_pack_jobs_fwd(J, P);
+    rc = pack_launch(J, (float*)a.pk, stream);
+    if (rc) return rc;
+  }
   RDRF_LAUNCH("time_branch", k_time_branch, dim3((M + 7) / 8), dim3(256), stream, t, w, M, a.tout);
   const Geo g = geo_for_units(Np);
   RDRF_LAUNCH("feat_dyn_density", k_dyn_density<true>, dim3(g.grid), dim3(g.block), stream, a, w);
@@ -832,10 +844,13 @@ extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCf
   if (rc) return rc;
   DynW w;
   fill_dyn_w(w, P);
-  PackJobs J;
-  dyn_pack_jobs_fwd(J, P);
-  rc = pack_launch(J, (float*)a.pk, stream);
-  if (rc) return rc;
+  if (P->packed_fwd != nullptr) a.pk = P->packed_fwd;   // caller-packed image (rdrf_dynamic_pack)
+  else {
+    PackJobs J;
+    dyn_pack_jobs_fwd(J, P);
+    rc = pack_launch(J, (float*)a.pk, stream);
+    if (rc) return rc;
+  }
   const Geo g = geo_for_tiles(N, S);
   RDRF_LAUNCH("scene_flow", k_scene_flow, dim3(g.grid), dim3(g.block), stream, pts, ts, N, S,
               make_box(cfg), a.pk, w, sf_f, sf_b, (float*)saved);

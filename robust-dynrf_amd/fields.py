@@ -165,6 +165,36 @@ def _dynamic_struct(t):
     return P
 
 
+# Packed weight images (rdrf_static_pack / rdrf_dynamic_pack): the MLP weights of a field do not change between the
+# passes of an iteration or the chunks of a render, so the image is packed once per (weights, stream) and handed to
+# the entry points through packed_fwd / packed_bwd instead of being re-packed by every call (~40 launches of ~6 us
+# per training iteration).  The key is every MLP tensor's (data_ptr, torch version counter) plus the field's
+# `_pack_epoch`, which optim.FlatAdam bumps because rdrf_adam_step writes the parameters through raw pointers.
+PACK_CACHE = os.environ.get("RDRF_PACK_CACHE", "1") == "1"
+
+
+def _attach_packed(field, P, params, backward, dynamic):
+    if not PACK_CACHE or field is None:
+        return
+    first = 18 if dynamic else 12
+    stream = torch.cuda.current_stream(params[0].device).cuda_stream
+    key = (tuple((p.data_ptr(), p._version) for p in params[first:]), field._pack_epoch, stream)
+    cache = field.__dict__.setdefault("_pack_cache", {})
+    slot = cache.get(backward)
+    if slot is None or slot[0] != key:
+        img = slot[1] if slot is not None else torch.empty(int(L.lib.rdrf_pack_floats()), device=params[0].device)
+        if dynamic:
+            L.check(L.lib.rdrf_dynamic_pack(C.byref(P), int(backward), L.ptr(img), C.c_void_p(stream)), "rdrf_dynamic_pack")
+        else:
+            L.check(L.lib.rdrf_static_pack(C.byref(P), L.HEADS.get(field.shadingMode, 0), int(backward), L.ptr(img),
+                                           C.c_void_p(stream)), "rdrf_static_pack")
+        cache[backward] = slot = (key, img)
+    if backward:
+        P.packed_bwd = slot[1].data_ptr()
+    else:
+        P.packed_fwd = slot[1].data_ptr()
+
+
 def _alloc_saved(ctx, kind, N, S, dev):
     """training mode: a per-call buffer the forward fills with the activations its backward needs
     (inference -- no input requires grad -- keeps nothing)."""
@@ -197,6 +227,7 @@ class _StaticFn(torch.autograd.Function):
         ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
         saved, sbytes = _alloc_saved(ctx, 0, N, S, dev)
         P = _static_struct(params)
+        _attach_packed(field, P, params, False, False)
         cfg = _cfg_struct(field, ray_type)
         L.check(L.lib.rdrf_static_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
                                       L.ptr(z), L.ptr(valid), N, S, L.ptr(rgb), L.ptr(sigma),
@@ -226,6 +257,7 @@ class _StaticFn(torch.autograd.Function):
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G = _static_struct(grads)
         P = _static_struct(params)
+        _attach_packed(ctx.field, P, params, True, False)
         cfg = _cfg_struct(ctx.field, ctx.ray_type)
         need = ctx.needs_input_grad
         g_rays, g_xyz, g_z = L.zeros_like_many([rays, xyz, z], [need[2], need[4], need[5]])
@@ -257,6 +289,7 @@ class _DynamicFn(torch.autograd.Function):
         ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
         saved, sbytes = _alloc_saved(ctx, 1, N, S, dev)
         P = _dynamic_struct(params)
+        _attach_packed(field, P, params, False, True)
         cfg = _cfg_struct(field, ray_type)
         L.check(L.lib.rdrf_dynamic_fwd(C.byref(P), C.byref(cfg), L.ptr(rays), L.ptr(ts), L.ptr(xyz),
                                        L.ptr(z), L.ptr(valid), N, S, L.ptr(blending), L.ptr(weight),
@@ -285,6 +318,7 @@ class _DynamicFn(torch.autograd.Function):
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G = _dynamic_struct(grads)
         P = _dynamic_struct(params)
+        _attach_packed(ctx.field, P, params, True, True)
         cfg = _cfg_struct(ctx.field, ctx.ray_type)
         need = ctx.needs_input_grad
         g_rays, g_xyz, g_z = L.zeros_like_many([rays, xyz, z], [need[2], need[4], need[5]])
@@ -316,6 +350,7 @@ class _SceneFlowFn(torch.autograd.Function):
         ws = L.workspace(pts.device, L.lib.rdrf_workspace_bytes(N, S))
         saved, sbytes = _alloc_saved(ctx, 2, N, S, pts.device)
         P = _dynamic_struct(params)
+        _attach_packed(field, P, params, False, True)
         cfg = _cfg_struct(field, "ndc")
         L.check(L.lib.rdrf_scene_flow_fwd(C.byref(P), C.byref(cfg), L.ptr(pts), L.ptr(ts), N, S,
                                           L.ptr(sf_f), L.ptr(sf_b), L.ptr(saved), C.c_size_t(sbytes),
@@ -335,6 +370,7 @@ class _SceneFlowFn(torch.autograd.Function):
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G = _dynamic_struct(grads)
         P = _dynamic_struct(params)
+        _attach_packed(ctx.field, P, params, True, True)
         cfg = _cfg_struct(ctx.field, "ndc")
         g_pts = torch.zeros_like(pts) if ctx.needs_input_grad[1] else None
         g_f = None if g_f is None else L.f32c(g_f)
@@ -375,6 +411,7 @@ class _StaticFeatFn(torch.autograd.Function):
         ws = L.workspace(dev, L.lib.rdrf_features_workspace_bytes(M))
         saved, sbytes = _feat_saved(ctx, 0, M, dev)
         P = _static_struct(params)
+        _attach_packed(field, P, params, False, False)
         cfg = _cfg_struct(field, "ndc")
         L.check(L.lib.rdrf_static_features_fwd(C.byref(P), C.byref(cfg), L.ptr(xn), M, L.ptr(dens), L.ptr(app),
                                                L.ptr(saved), C.c_size_t(sbytes), L.ptr(ws),
@@ -395,6 +432,7 @@ class _StaticFeatFn(torch.autograd.Function):
         if g_dens is None and g_app is None:
             return (None,) * (4 + len(params))
         G, P = _static_struct(grads), _static_struct(params)
+        _attach_packed(ctx.field, P, params, True, False)
         cfg = _cfg_struct(ctx.field, "ndc")
         g_xn = torch.zeros_like(xn) if ctx.needs_input_grad[3] else None
         g_dens = None if g_dens is None else L.f32c(g_dens)
@@ -427,6 +465,7 @@ class _DynFeatFn(torch.autograd.Function):
         ws = L.workspace(dev, L.lib.rdrf_features_workspace_bytes(M))
         saved, sbytes = _feat_saved(ctx, 1, M, dev)
         P = _dynamic_struct(params)
+        _attach_packed(field, P, params, False, True)
         cfg = _cfg_struct(field, "ndc")
         L.check(L.lib.rdrf_dynamic_features_fwd(C.byref(P), C.byref(cfg), L.ptr(x), L.ptr(t), M,
                                                 int(x_is_normalized), L.ptr(dens), L.ptr(blend), L.ptr(app),
@@ -448,6 +487,7 @@ class _DynFeatFn(torch.autograd.Function):
         fused = ctx.field.fused_grad
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G, P = _dynamic_struct(grads), _dynamic_struct(params)
+        _attach_packed(ctx.field, P, params, True, True)
         cfg = _cfg_struct(ctx.field, "ndc")
         g_x = torch.zeros_like(x) if ctx.needs_input_grad[3] else None
         c = lambda g: None if g is None else L.f32c(g)
@@ -635,6 +675,12 @@ class TensorBase(nn.Module):
     # exchange all-reduces the flat buffer in place.  Off by default: plain autograd semantics
     # (torch.autograd.grad, retain_graph, ...) need freshly returned gradients.
     fused_grad = False
+    _pack_epoch = 0    # bumped by whoever writes the parameters through raw pointers (optim.FlatAdam): see _attach_packed
+
+    def invalidate_packed(self):
+        """Drop the cached packed weight images.  Needed only after an MLP weight was edited in a way torch's version
+        counters do not see: through `.data`, or through raw pointers (optim.FlatAdam does it itself)."""
+        self._pack_epoch += 1
 
     FLAT_ALIGN = 4096   # floats: the flat buffers split evenly over 1, 2, 4, 8 ... ranks in 16-byte units
 

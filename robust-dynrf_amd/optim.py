@@ -85,5 +85,7 @@ class FlatAdam:
         for w in gathers:
             if w is not None:
                 w.wait()
+        for f in self.fields:   # the parameters changed behind torch's version counters: packed weight images are stale
+            f._pack_epoch += 1
         self.lr0 *= self.lr_factor
         self.lr1 *= self.lr_factor

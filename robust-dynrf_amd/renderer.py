@@ -163,7 +163,7 @@ def OctreeRender_trilinear_fast(rays, ts, timeembeddings, tensorf, xyz_sampled, 
 def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc"):
     """No-grad render of a ray chunk through ONE C-ABI call (rdrf_render_fwd): the loop body of
     renderer.py:740-812.  Returns (rgb_map_full[N,3], depth_map_full[N])."""
-    from .fields import _cfg_struct, _dynamic_struct, _static_struct
+    from .fields import _attach_packed, _cfg_struct, _dynamic_struct, _static_struct
     L.require_device(rays, ts)
     rays, ts = L.f32c(rays), L.f32c(ts)
     N = rays.shape[0]
@@ -173,8 +173,10 @@ def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc")
     depth = torch.empty(N, device=dev)
     nbytes = int(L.lib.rdrf_render_workspace_bytes(N, S))
     ws = L.workspace(dev, nbytes)
-    PS = _static_struct(tensorf_static._param_list())
-    PD = _dynamic_struct(tensorf._param_list())
+    ps_list, pd_list = tensorf_static._param_list(), tensorf._param_list()
+    PS, PD = _static_struct(ps_list), _dynamic_struct(pd_list)
+    _attach_packed(tensorf_static, PS, ps_list, False, False)   # packed once per (weights, stream), not per chunk
+    _attach_packed(tensorf, PD, pd_list, False, True)
     cs, cd = _cfg_struct(tensorf_static, ray_type), _cfg_struct(tensorf, ray_type)
     near, far = tensorf.near_far
     L.check(L.lib.rdrf_render_fwd(C.byref(PS), C.byref(cs), C.byref(PD), C.byref(cd), L.ptr(rays),

@@ -220,3 +220,61 @@ def test_sample_ray_wrappers(case):
     xyz, zrow, valid = fn(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=S)
     assert zrow.shape == (1, S) and xyz.shape == (rays.shape[0], S, 3)
     assert torch.equal(zrow.cpu(), z_r[:1]) and torch.equal(xyz.cpu(), xyz_r) and torch.equal(valid.cpu(), valid_r)
+
+
+def test_packed_weight_images_follow_the_weights():
+    """The packed MLP images are cached per (weights, stream): an optimiser-style in-place update, a `.data` edit
+    followed by invalidate_packed(), and a FlatAdam step must all be seen by the next call; results equal the
+    uncached path bit for bit."""
+    import importlib
+    import rodynrf
+    from _gpu_util import COMMON, make_rays
+    F = importlib.import_module("robust-dynrf_amd.fields")
+    O_ = importlib.import_module("robust-dynrf_amd.optim")
+    torch.manual_seed(2)
+    aabb = torch.tensor([[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]])
+    kw = dict(COMMON, near_far=[0.0, 1.0], density_shift=-10.0, fea2denseAct="relu")
+    st = rodynrf.TensorVMSplit(aabb, [20, 22, 14], 12, "cuda", shadingMode="MLP_Fea", fea_pe=2, **kw)
+    dy = rodynrf.TensorVMSplit_TimeEmbedding(aabb, [20, 22, 14], 12, "cuda", shadingMode="MLP_Fea_late_view", fea_pe=0, **kw)
+    rays, ts = make_rays(64, 3)
+    rays, ts = rays.cuda(), ts.cuda()
+
+    def run():
+        with torch.no_grad():
+            xyz, z, valid = rodynrf.sampleXYZ(dy, rays, 16, ray_type="ndc", is_train=False)
+            a = st(rays, ts, None, xyz, z, valid, is_train=False, ray_type="ndc")[6]
+            b = dy(rays, ts, None, xyz, z, valid, is_train=False, ray_type="ndc")[6]
+            c = rodynrf.render_rays(st, dy, rays, ts, N_samples=16)[0]
+        return a.clone(), b.clone(), c.clone()
+
+    def uncached():
+        F.PACK_CACHE = False
+        try:
+            return run()
+        finally:
+            F.PACK_CACHE = True
+
+    assert F.PACK_CACHE
+    base = run()
+    assert all(torch.equal(x, y) for x, y in zip(base, uncached()))
+    assert all(torch.equal(x, y) for x, y in zip(base, run()))          # cache hit: identical
+    with torch.no_grad():                                                # what torch.optim does
+        st.renderModule.mlp[2].weight.mul_(1.5)
+        dy.renderModule.mlp[0].bias.add_(0.3)
+    upd = run()
+    assert not torch.equal(upd[0], base[0]) and not torch.equal(upd[1], base[1]) and not torch.equal(upd[2], base[2])
+    assert all(torch.equal(x, y) for x, y in zip(upd, uncached()))
+    dy.renderModule.mlp[2].weight.data.mul_(0.5)                         # invisible to the version counter ...
+    dy.invalidate_packed()                                               # ... so the caller says so
+    upd2 = run()
+    assert not torch.equal(upd2[1], upd[1])
+    assert all(torch.equal(x, y) for x, y in zip(upd2, uncached()))
+    opt = O_.FlatAdam([st, dy], 0.02, 1e-3)                              # raw-pointer Adam: bumps the epoch itself
+    loss = st(rays, ts, None, *rodynrf.sampleXYZ(dy, rays, 16, ray_type="ndc", is_train=False), is_train=True,
+              ray_type="ndc")[6].sum()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    upd3 = run()
+    assert not torch.equal(upd3[0], upd2[0])
+    assert all(torch.equal(x, y) for x, y in zip(upd3, uncached()))
