@@ -90,6 +90,7 @@ def test_bench_rccl_call_sequence_on_one_gpu(dp):
     world size 1 every collective is the identity, so the loss after 6 steps must equal the plain run's."""
     import json
     import os
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -98,7 +99,10 @@ def test_bench_rccl_call_sequence_on_one_gpu(dp):
            "--rays-per-gpu", "512", "--no-render", "--no-final-stage", "--no-cpu-baseline", "--dp", dp]
     res = []
     for force in ("0", "1"):
-        env = dict(base, RDRF_FORCE_COLLECTIVES=force, MASTER_PORT=str(29611 + (dp == "zero1")))
+        with socket.socket() as sk:   # a free rendezvous port
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(base, RDRF_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-3000:]
         res.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
