@@ -30,6 +30,22 @@ class FixedRng:
                 torch.rand(S // 2 + 1, generator=self.gen).to(device))
 
 
+class ReplayRng:
+    """replays recorded draws in call order (tests/golden/pass_structure_*.npz: the reference's own jitter
+    vectors and white-background coins of pass A and pass E)"""
+
+    def __init__(self, jitters, coins):
+        self.jitters, self.coins = list(jitters), list(coins)
+
+    def coin(self):
+        return bool(self.coins.pop(0))
+
+    def jitter(self, S, ray_type, device="cpu"):
+        j = self.jitters.pop(0)
+        j = j if isinstance(j, (tuple, list)) else (j, None)
+        return tuple(None if v is None else torch.as_tensor(v).reshape(-1).to(device) for v in j)
+
+
 def masked_mean(x, m):
     return (x * m).sum() / (m.sum() + 1e-8)
 
@@ -58,9 +74,13 @@ def ray_pass(sd_s, cfg_s, sd_d, cfg_d, rays, ts, S, rt, near_far, rng, static_gr
     return o_s, o_d, outs, (xyz, z, valid)
 
 
-def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False):
+def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, terms="all", capture=None):
     """(loss_dynamic, loss_static, tv_dynamic, tv_static) of one iteration; `poses` [T,9] and `focal`
-    (0-dim tensor or float) may require grad (optimize_poses)."""
+    (0-dim tensor or float) may require grad (optimize_poses).
+    terms="image_AE": only pass A, pass E and the three image terms (train.py:1323-1332, 1827-1835) -- the
+    subset the reference-generated fixture tests/golden/pass_structure_*.npz holds; the
+    passes are the SAME calls as in the full recipe.  `batch["rays"]` (optional) replaces the generated rays.
+    `capture` (dict) receives the per-pass tuples."""
     S, rt, T, H, W = cfg["n_samples"], cfg["ray_type"], cfg["T"], cfg["H"], cfg["W"]
     aabb = torch.tensor(cfg["aabb"], dtype=torch.float32)
     cfg_s, cfg_d = _cfgs(cfg, aabb)
@@ -69,7 +89,9 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False):
     b = batch
     ids, ts, rgb_t, disp_t, fg = b["ids"], b["ts"], b["rgb"], b["disp"], b["fg"]
     opt_poses = bool(cfg.get("optimize_poses", False))
-    rays = O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0)
+    full = terms == "all"
+    assert terms in ("all", "image_AE")
+    rays = b["rays"] if "rays" in b else O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0)
     rays_d = rays.detach()
     poses_d = poses.detach()
     focal_d = focal.detach() if torch.is_tensor(focal) else focal
@@ -83,8 +105,15 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False):
     to_depth = (lambda d: d) if ndc else (lambda d: 1.0 / (d + 1e-6))
     rp = lambda rays_, ts_, **kw: ray_pass(sd_s, cfg_s, sd_d, cfg_d, rays_, ts_, S, rt, nf, rng, **kw)
     # ---- pass A
-    _, oA, outA, _ = rp(rays_d, ts)
+    osA, oA, outA, smpA = rp(rays_d, ts)
+    if capture is not None:
+        capture["A"] = (osA, oA, outA, smpA)
     loss_d = 3.0 * ((outA[0] - rgb_t) ** 2).mean() + ((outA[8] - rgb_t) ** 2).mean()
+    if not full:
+        oE, oEd, outE, smpE = rp(rays, ts, static_grad=True, dynamic=dead_work)
+        if capture is not None:
+            capture["E"] = (oE, oEd, outE, smpE)
+        return loss_d, masked_mean((outE[4] - rgb_t) ** 2, (1.0 - fg)[:, None]) / 3.0, None, None
     loss_d = loss_d + 0.1 * (outA[12] - fg).abs().mean()
     loss_d = loss_d + cfg["monodepth_dynamic"] * temp * O.frame_depth_loss(to_depth(outA[9]), gt_depth, view, T)
     w_dist = cfg["dist_dynamic"] * min(1.0, (it + 1) / cfg["n_iters"])

@@ -318,16 +318,23 @@ class Trainer:
                              view_shift=view_shift)
 
     # ---- one iteration -----------------------------------------------------------------------------
-    def losses(self, b):
+    def losses(self, b, terms="all", capture=None):
         """forward of one iteration on batch `b`; returns (loss_dynamic, loss_static): the two loss groups have
-        disjoint parameter ancestries (dynamic field | static field + pose + focal)."""
+        disjoint parameter ancestries (dynamic field | static field + pose + focal).
+        terms="image_AE" keeps pass A, pass E and the three image terms only (train.py:1323-1332, 1827-1835): the
+        subset the reference-generated fixture tests/golden/pass_structure_*.npz pins; the
+        two passes are the same calls either way.  b["rays"] (optional) replaces the generated rays;
+        `capture` (dict) receives the per-pass tuples."""
         c = self.cfg
         S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
         it, rng = self.it, self.rng
         ids, ts, rgb_t, disp_t, fg = b["ids"], b["ts"], b["rgb"], b["disp"], b["fg"]
         N = ids.shape[0]
         poses, focal = self.pose_table(), self.focal()
-        rays = self.rays_for(ids, poses, focal)           # with grad when the poses / focal are trained
+        if terms not in ("all", "image_AE"):
+            raise ValueError(terms)
+        full = terms == "all"
+        rays = b["rays"] if "rays" in b else self.rays_for(ids, poses, focal)   # with grad when the poses / focal are trained
         rays_d = rays.detach()
         poses_d, focal_d = poses.detach(), (focal.detach() if torch.is_tensor(focal) else focal)
         dt = 2.0 / (T - 1)
@@ -349,8 +356,17 @@ class Trainer:
         loss_d = 0.0
         Ld = LossTerms()   # the elementwise terms of the dynamic group: one fused reduction (losses.py)
         # ---- pass A
-        _, oA, outA, _ = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
+        osA, oA, outA, xyzA = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
+        if capture is not None:
+            capture["A"] = (osA, oA, outA, xyzA)
         Ld.add(3.0, "square", outA[0], rgb_t).add(1.0, "square", outA[8], rgb_t)      # train.py:1323, 1331
+        if not full:
+            oE, oEd, outE, xyzE = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
+            if capture is not None:
+                capture["E"] = (oE, oEd, outE, xyzE)
+            Ls = LossTerms().add(1.0 / 3.0, "square", outE[4], rgb_t, w=(1.0 - fg)[:, None], norm="weight")
+            self.terms = (Ld, Ls)
+            return Ld.total(), Ls.total()
         Ld.add(0.1, "abs", outA[12], fg)                                                # :1341-1350
         loss_d = loss_d + c["monodepth_dynamic"] * temp * frame_median_depth_loss(to_depth(outA[9]), gt_depth, view, T)
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters

@@ -386,6 +386,109 @@ def gen_fn_grads(mods):
     print("fn_grads: ok", float(L))
 
 
+def gen_pass_structure(mods):
+    """the detach / liveness pattern of the trainer, re-enacted on the imported
+    reference models.  train.py itself does not import here (configargparse, tensorboard, dataset files), so
+    the two call sequences are replayed call by call with the argument lists of the trainer:
+
+      pass A  train.py:1092-1162  sampleXYZ(rays.detach(), is_train=True) -> tensorf_static(rays.detach(), ...)
+              -> tensorf(rays.detach(), ...) -> raw2outputs(rgb_s.detach(), sigma_s.detach(), ..., rays.detach(),
+              is_train=True)
+      pass E  train.py:1756-1823  the same three calls on rays WITH grad, static outputs live
+      L = 3 mse(rgb_map_full_A) + mse(rgb_map_d_A)              train.py:1323-1332
+          + sum((rgb_map_s_E - rgb)^2 (1 - fg)) / (sum(1 - fg) + 1e-8) / 3       train.py:1827-1835
+
+    on the weights / rays / times of two existing cases (their state_dicts are NOT stored again).  The global
+    RNG is seeded once; the draws (jitter A, coin A, jitter E, coin E -- models/tensorBase.py:492, 530-545,
+    renderer.py:269) are recorded by replaying the generator."""
+    TS, TD, renderer, _, _ = mods
+    names = ["_0", "_1", "blending", "pts_ref", "weight", "xyz_prime", "rgb", "sigma", "z", "dists"]
+    onames = ["rgb_map_full", "depth_map_full", "acc_map_full", "weights_full", "rgb_map_s",
+              "depth_map_s", "acc_map_s", "weights_s", "rgb_map_d", "depth_map_d", "acc_map_d",
+              "weights_d", "dynamicness_map"]
+    for case_name, want in (("ndc_relu", (True, False)), ("contract_relu_te", (False, True))):
+        case = np.load(os.path.join(HERE, case_name + ".npz"), allow_pickle=True)
+        rt, act, head = str(case["meta.ray_type"]), str(case["meta.act"]), str(case["meta.static_head"])
+        grid = [int(v) for v in case["meta.grid"]]
+        st, dy = build_fields(TS, TD, torch.from_numpy(case["aabb"]), grid, act, head,
+                              float(case["meta.density_shift"]), 1)
+        st.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("s.")})
+        dy.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("d.")})
+        nf = [float(v) for v in case["meta.near_far"]]
+        st.near_far = nf
+        dy.near_far = nf
+        rays = torch.from_numpy(case["rays"]).clone().requires_grad_(True)
+        ts = torch.from_numpy(case["ts"])
+        N, S = rays.shape[0], int(case["z"].shape[1])
+        g = torch.Generator().manual_seed(606)
+        rgb_t = torch.rand(N, 3, generator=g)
+        fg = (torch.rand(N, 1, generator=g) < 0.3).float()       # allforegroundmasks_train[..., 0:1]
+
+        def draws():
+            if rt == "ndc":
+                return (torch.rand(1, S),)
+            return torch.rand(1, S - S // 2 + 1), torch.rand(1, S // 2 + 1)
+
+        seed = 0
+        while True:   # a seed whose two coins are `want` (white background in A / not in E, and vice versa)
+            torch.manual_seed(seed)
+            jA = draws()
+            cA = bool(torch.rand((1,)) < 0.5)
+            jE = draws()
+            cE = bool(torch.rand((1,)) < 0.5)
+            if (cA, cE) == want:
+                break
+            seed += 1
+        out = {"meta.case": np.array(case_name), "meta.seed": np.array(seed), "rgb_train": rgb_t.numpy(),
+               "fg": fg.numpy(), "A.white": np.array(cA), "E.white": np.array(cE),
+               "A.jitter": jA[0].numpy(), "E.jitter": jE[0].numpy()}
+        if rt != "ndc":
+            out["A.jitter_outer"], out["E.jitter_outer"] = jA[1].numpy(), jE[1].numpy()
+        torch.manual_seed(seed)
+        kw = dict(is_train=True, white_bg=True, ray_type=rt, N_samples=S)
+        # ---- pass A (train.py:1092-1162)
+        xyz, z, valid = renderer.sampleXYZ(dy, rays.detach(), N_samples=S, ray_type=rt, is_train=True)
+        oAs = st(rays.detach(), ts, None, xyz, z, valid, **kw)
+        oAd = dy(rays.detach(), ts, None, xyz, z, valid, **kw)
+        cA_out = renderer.raw2outputs(oAs[6].detach(), oAs[7].detach(), oAd[6], oAd[7], oAd[9], oAd[2], oAd[8],
+                                      rays.detach(), is_train=True, ray_type=rt)
+        # ---- pass E (train.py:1756-1823)
+        xyzE, zE, validE = renderer.sampleXYZ(dy, rays, N_samples=S, ray_type=rt, is_train=True)
+        oEs = st(rays, ts, None, xyzE, zE, validE, **kw)
+        oEd = dy(rays, ts, None, xyzE, zE, validE, **kw)
+        cE_out = renderer.raw2outputs(oEs[6], oEs[7], oEd[6], oEd[7], oEd[9], oEd[2], oEd[8], rays,
+                                      is_train=True, ray_type=rt)
+        for tag, smp, o_s, o_d, c in (("A", (xyz, z, valid), oAs, oAd, cA_out), ("E", (xyzE, zE, validE), oEs, oEd, cE_out)):
+            out[tag + ".xyz"], out[tag + ".z"], out[tag + ".valid"] = (smp[0].detach().numpy(), smp[1].detach().numpy(),
+                                                                       smp[2].numpy())
+            for k, v in zip(names, o_s):
+                if v is not None:
+                    out[f"{tag}.fs.{k}"] = v.detach().numpy()
+            for k, v in zip(names, o_d):
+                if v is not None:
+                    out[f"{tag}.fd.{k}"] = v.detach().numpy()
+            for k, v in zip(onames, c):
+                out[f"{tag}.c.{k}"] = v.detach().numpy()
+        rgb_map_full, rgb_map_d, rgb_map_s = cA_out[0], cA_out[8], cE_out[4]
+        l_full = torch.mean((rgb_map_full - rgb_t) ** 2)
+        l_d = torch.mean((rgb_map_d - rgb_t) ** 2)
+        l_s = torch.sum((rgb_map_s - rgb_t) ** 2 * (1.0 - fg)) / (torch.sum(1.0 - fg) + 1e-8) / rgb_map_s.shape[-1]
+        L = 3.0 * l_full + 1.0 * l_d + 1.0 * l_s
+        out["loss"], out["loss_full"], out["loss_d"], out["loss_s"] = (L.detach().numpy(), l_full.detach().numpy(),
+                                                                     l_d.detach().numpy(), l_s.detach().numpy())
+        ps, pd = list(st.parameters()), list(dy.parameters())
+        grads = torch.autograd.grad(L, ps + pd + [rays], allow_unused=True)
+        for (k, p), gv in zip(st.named_parameters(), grads[: len(ps)]):
+            out["gs." + k] = (gv if gv is not None else torch.zeros_like(p)).numpy()
+        for (k, p), gv in zip(dy.named_parameters(), grads[len(ps): len(ps) + len(pd)]):
+            out["gd." + k] = (gv if gv is not None else torch.zeros_like(p)).numpy()
+            out["gd_none." + k] = np.array(gv is None)      # which dynamic parameters the A + E graph never reaches
+        out["g.rays"] = grads[-1].numpy()
+        np.savez(os.path.join(HERE, f"pass_structure_{case_name}.npz"), **out)
+        print(f"pass_structure_{case_name}: seed {seed} coins {cA, cE} loss {float(L):.6f} "
+              f"|g.rays| {float(grads[-1].abs().max()):.3e}")
+
+
 if __name__ == "__main__":
     mods = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "fn_grads":
@@ -393,6 +496,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tv":
         gen_tv(mods)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pass_structure":
+        gen_pass_structure(mods)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "induce_flow":
         gen_induce_flow(mods)
@@ -408,3 +514,4 @@ if __name__ == "__main__":
     gen_induce_flow(mods)
     gen_tv(mods)
     gen_fn_grads(mods)
+    gen_pass_structure(mods)

@@ -1,7 +1,7 @@
 """GPU parity (backward): gradients of every parameter of both fields through the HIP backward
 kernels vs (a) the reference's own autograd (golden vectors) and (b) the CPU oracle's autograd on a
-seeded mid-size batch.  Tolerance 2e-4 relative to each gradient tensor's max magnitude (atomics
-reorder the fp32 sums)."""
+seeded mid-size batch.  Tolerance 1e-4 relative to each gradient tensor's max magnitude (north_star; atomics
+reorder the fp32 sums) plus the element-wise bound of tests/_gpu_util.ELEM."""
 import numpy as np
 import pytest
 import torch
@@ -56,13 +56,13 @@ def test_golden_gradients(case):
                 continue
             assert p.grad is not None, f"no grad for {pre}{k}"
             try:
-                assert_close(p.grad, ref, pre + k, rtol=2e-4)
+                assert_close(p.grad, ref, pre + k, rtol=1e-4)
             except AssertionError as e:
                 bad.append(str(e))
     assert not bad, "\n".join(bad)
 
 
-def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26), rtol=2e-4, elem=None):
+def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26), rtol=1e-4, elem=None):
     """HIP backward vs the oracle's autograd on seeded weights.  Deterministic treatment of the
     non-differentiable points: rays with a sample within 2e-6 (relative to the layer's scale) of a relu kink of any MLP, of the density
     activation's kink, of the app-mask threshold or of a compositor clamp (tests/_gpu_util.kink_free_rays)
@@ -96,7 +96,7 @@ def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26
         r_d = O.field_forward(sd_d, cfg_d, rays, ts, xyz, z, valid, rt, dynamic=True)
         r_o = O.raw2outputs(r_s[6], r_s[7], r_d[6], r_d[7], r_d[9], r_d[2], r_d[8], rays, True, rt)
     keep = kink_free_rays(O, sd_s, cfg_s, sd_d, cfg_d, rays, ts, xyz, z, valid, rt, r_s, r_d, r_o)
-    assert float(keep.float().mean()) > 0.4, f"too many rays excluded ({float(keep.float().mean()):.2f} kept)"
+    assert float(keep.float().mean()) > 0.8, f"too many rays excluded ({float(keep.float().mean()):.2f} kept)"
     wr = keep.float()
 
     def loss(outs, sf, t, w):  # the three image terms of train.py:1323-1332,1827-1835 + extras, per-ray weighted
@@ -181,7 +181,7 @@ def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26
 def test_oracle_gradients_midsize(seed):
     """N=96 rays x S=70 samples on a 40x44x26 grid, seeded weights, against the oracle's autograd
     (multi-tile rays, ragged last tile, partially-filled compacted tiles): EVERY seed must match, max-norm
-    2e-4 and element-wise |err| <= 2e-3 |ref| + 4e-5 max|ref| for every entry of every gradient."""
+    1e-4 and element-wise |err| <= 2e-3 |ref| + 4e-5 max|ref| for every entry of every gradient."""
     from _gpu_util import ELEM
     bad, l2 = _midsize_once(seed, elem=ELEM)
     assert not bad and l2 < 1e-3, f"relative L2 error {l2:.2e}\n" + "\n".join(bad)
@@ -196,7 +196,7 @@ def test_oracle_gradients_midsize_contract(seed):
     assert not bad and l2 < 1e-3, f"relative L2 error {l2:.2e}\n" + "\n".join(bad)
 
 
-@pytest.mark.parametrize("N,S,grid", [(64, 115, (141, 157, 94)), (40, 270, (331, 368, 220))])
+@pytest.mark.parametrize("N,S,grid", [(512, 115, (141, 157, 94)), (96, 270, (331, 368, 220))])
 def test_oracle_gradients_benchmark_grids(N, S, grid):
     """gradients (not only forwards) on the two grids the benchmark runs -- Balloon1 stage 0 [141,157,94] /
     S=115 and final [331,368,220] / S=270: the scatter's run merging, quad transposition and LDS line
@@ -272,7 +272,7 @@ def test_golden_ray_gradients(case):
     sf_f, sf_b = dy.get_forward_backward_scene_flow(o_d[3], ts)
     L = _golden_loss(g, o_s, o_d, outs, sf_f, sf_b, dev)
     L.backward()
-    assert_close(rays.grad, g["g.rays"], "g.rays", rtol=5e-4)
+    assert_close(rays.grad, g["g.rays"], "g.rays", rtol=1e-4)
 
 
 def test_fused_grad_accumulation_matches_autograd():
@@ -368,4 +368,4 @@ def test_z_vals_gradient_matches_oracle(rt):
     assert_close(Lg, Lr, "loss", rtol=2e-4, atol=at)
     gg, = torch.autograd.grad(Lg, zg)
     assert float(gref.abs().max()) > 0
-    assert_close(gg, gref, "d loss / d z_vals", rtol=3e-4)
+    assert_close(gg, gref, "d loss / d z_vals", rtol=1e-4)
