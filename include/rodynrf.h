@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define RDRF_ABI_VERSION 1
+/* 2: RdrfStaticParams / RdrfDynamicParams grew the trailing packed_fwd / packed_bwd pointers (round 2);
+ * 3: sorted scatter workspace + fused render entry points (round 3).  A binding built against another version must
+ * refuse to load: the structs are passed by pointer and read to their full length. */
+#define RDRF_ABI_VERSION 3
 
 typedef void* rdrf_stream_t; /* hipStream_t */
 

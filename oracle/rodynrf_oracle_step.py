@@ -99,11 +99,23 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
     col, row, view = O.ids2pixel(W, H, ids)
     grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
     c2w_all = O.pose_to_mtx(poses)
-    temp = 1.0 / (10 ** (it // 100000))
+    temp = 1.0 / (10 ** (it // 100000))              # train.py:1034-1036
+    temp_disp_tv = 1.0 / (10 ** (it // 50000))
     temp_static = 1.0 / (10 ** (it / 100000.0))
+    ups = cfg.get("upsamp_list", [0, 0, 0, 0])
+    early, late = it >= ups[0], it >= ups[3]
     gt_depth = -disp_t if ndc else disp_t
     to_depth = (lambda d: d) if ndc else (lambda d: 1.0 / (d + 1e-6))
     rp = lambda rays_, ts_, **kw: ray_pass(sd_s, cfg_s, sd_d, cfg_d, rays_, ts_, S, rt, nf, rng, **kw)
+
+    def skewed(dyn):          # train.py:1349-1358
+        m2 = torch.clamp(dyn, min=1e-6, max=1.0 - 1e-6) ** 2
+        return torch.mean(-(m2 * torch.log(m2) + (1 - m2) * torch.log(1 - m2)))
+
+    def order(outs):          # train.py:1277-1291, 1666-1683
+        w = 1.0 - outs[12].detach()
+        return 10.0 * torch.sum((to_depth(outs[9]) - to_depth(outs[5].detach())) ** 2 * w) / (torch.sum(w) + 1e-8)
+
     # ---- pass A
     osA, oA, outA, smpA = rp(rays_d, ts)
     if capture is not None:
@@ -114,19 +126,26 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
         if capture is not None:
             capture["E"] = (oE, oEd, outE, smpE)
         return loss_d, masked_mean((outE[4] - rgb_t) ** 2, (1.0 - fg)[:, None]) / 3.0, None, None
-    loss_d = loss_d + 0.1 * (outA[12] - fg).abs().mean()
+    if early:
+        loss_d = loss_d + 0.1 * temp_disp_tv * (outA[12] - fg).abs().mean()
+    if late:
+        loss_d = loss_d + 0.01 * skewed(outA[12]) + 0.01 * outA[12].abs().mean()
+    loss_d = loss_d + order(outA)
     loss_d = loss_d + cfg["monodepth_dynamic"] * temp * O.frame_depth_loss(to_depth(outA[9]), gt_depth, view, T)
-    w_dist = cfg["dist_dynamic"] * min(1.0, (it + 1) / cfg["n_iters"])
-    loss_d = loss_d + w_dist * O.eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
+    w_dist = cfg["dist_dynamic"] * (it / cfg["n_iters"])
+    if w_dist > 0:
+        loss_d = loss_d + w_dist * O.eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
     # ---- pass B
     _, oB, outB, _ = rp(rays_d, b["ts_rand"])
-    loss_d = loss_d + 0.01 * outB[12].mean() + 0.01 * (outB[9] - outB[5].detach()).abs().mean()
-    loss_d = loss_d + w_dist * O.eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
+    if late:
+        loss_d = loss_d + 0.01 * skewed(outB[12]) + 0.01 * outB[12].abs().mean()
+    loss_d = loss_d + order(outB)
+    if w_dist > 0:
+        loss_d = loss_d + w_dist * O.eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
     # ---- scene flow
     sf_f, sf_b = O.scene_flow(sd_d, aabb, oA[3], ts)
-    w_d = outA[11].detach()[..., None]
-    loss_d = loss_d + 0.01 * (sf_f.abs() * w_d).mean() + 0.01 * (sf_b.abs() * w_d).mean()
-    loss_d = loss_d + 0.01 * ((sf_f + sf_b) ** 2 * w_d).mean()
+    loss_d = loss_d + cfg["small_scene_flow_weight"] * (sf_f.abs().mean() + sf_b.abs().mean())
+    loss_d = loss_d + cfg["smooth_scene_flow_weight"] * (sf_f + sf_b).abs().mean()
     weights_d, pts_ref = outA[11], oA[3]
     disp_A = {}
     for sgn, sf, flow_t, mask_t in ((1, sf_f, b["flow_f"], b["mask_f"]), (-1, sf_b, b["flow_b"], b["mask_b"])):
@@ -142,13 +161,12 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
         _, oN, outN, _ = rp(rays_n, ts + sgn * dt)
         _, ind_disp_n = O.induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, rt)
         loss_d = loss_d + 0.04 * temp * masked_mean((ind_disp - ind_disp_n).abs(), mask_t)
-        loss_d = loss_d + w_dist * O.eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
+        if w_dist > 0:
+            loss_d = loss_d + w_dist * O.eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
     # ---- pass E
     oE, _, outE, _ = rp(rays, ts, static_grad=True, dynamic=dead_work)
     m = (1.0 - fg)[:, None]
     loss_s = masked_mean((outE[4] - rgb_t) ** 2, m) / 3.0
-    if not opt_poses:
-        loss_s = loss_s + 0.04 * ((outE[5] - disp_t).abs() * m[:, 0]).mean()
     if cfg["dist_static"] > 0:
         loss_s = loss_s + cfg["dist_static"] * (it / cfg["n_iters"]) * O.eff_distloss(outE[7], oE[8].detach(), 1.0 / S)
     if opt_poses:   # train.py:1895-2311
@@ -174,13 +192,15 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
             rays_n = O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0, uv=uv_n)
             _, _, outN, _ = rp(rays_n, ts, static_grad=True, dynamic=dead_work)
             sm = sm + ((inv_d - 1.0 / torch.clamp(outN[5], min=1e-6)) ** 2).mean()
-        loss_s = loss_s + 50.0 * temp * sm
+        loss_s = loss_s + 50.0 * temp_disp_tv * sm
     fam = lambda sd, name: ([sd[f"{name}_plane.{i}"] for i in range(3)], [sd[f"{name}_line.{i}"] for i in range(3)])
     if cfg["l1_weight"] > 0:
         loss_d = loss_d + cfg["l1_weight"] * O.dense_l1(*fam(sd_d, "density"), "relu", -10.0)
         loss_s = loss_s + cfg["l1_weight"] * O.dense_l1(*fam(sd_s, "density"), "relu", -10.0)
     tv_d = tv_s = None
     if cfg["tv_density"] > 0 or cfg["tv_app"] > 0:
+        f = (cfg.get("lr_decay_target_ratio", 0.1) ** (1.0 / cfg.get("n_iters", 100000))) ** (it + 1)   # train.py:1734-1750
+        cfg = dict(cfg, tv_density=cfg["tv_density"] * f, tv_app=cfg["tv_app"] * f)
         tv_d = (cfg["tv_density"] * (O.tv_family(*fam(sd_d, "density")) + O.tv_family(*fam(sd_d, "blending")))
                 + cfg["tv_app"] * O.tv_family(*fam(sd_d, "app")))
         tv_s = cfg["tv_density"] * O.tv_family(*fam(sd_s, "density")) + cfg["tv_app"] * O.tv_family(*fam(sd_s, "app"))

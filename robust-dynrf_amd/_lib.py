@@ -11,6 +11,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf.so"))  # RDRF_LIB: A/B builds
 
+ABI_VERSION = 3   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
+
 RAY_TYPES = {"ndc": 0, "contract": 1}
 ACTS = {"relu": 0, "softplus": 1}
 HEADS = {"MLP_Fea": 0, "MLP_Fea_TimeEmbedding": 1}
@@ -74,7 +76,7 @@ def _load():
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
     lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    if lib.rdrf_abi_version() != 1:
+    if lib.rdrf_abi_version() != ABI_VERSION:
         raise ImportError("librodynrf.so ABI version mismatch")
     return lib
 

@@ -178,9 +178,11 @@ def _attach_packed(field, P, params, backward, dynamic):
         return
     first = 18 if dynamic else 12
     stream = torch.cuda.current_stream(params[0].device).cuda_stream
-    key = (tuple((p.data_ptr(), p._version) for p in params[first:]), field._pack_epoch, stream)
+    key = (tuple((p.data_ptr(), p._version) for p in params[first:]), field._pack_epoch)
     cache = field.__dict__.setdefault("_pack_cache", {})
-    slot = cache.get(backward)
+    # one image per (direction, stream): a re-pack into an image is ordered behind that stream's earlier readers;
+    # another stream gets its own image instead of racing with kernels still reading this one
+    slot = cache.get((backward, stream))
     if slot is None or slot[0] != key:
         img = slot[1] if slot is not None else torch.empty(int(L.lib.rdrf_pack_floats()), device=params[0].device)
         if dynamic:
@@ -188,7 +190,7 @@ def _attach_packed(field, P, params, backward, dynamic):
         else:
             L.check(L.lib.rdrf_static_pack(C.byref(P), L.HEADS.get(field.shadingMode, 0), int(backward), L.ptr(img),
                                            C.c_void_p(stream)), "rdrf_static_pack")
-        cache[backward] = slot = (key, img)
+        cache[(backward, stream)] = slot = (key, img)
     if backward:
         P.packed_bwd = slot[1].data_ptr()
     else:

@@ -23,18 +23,25 @@ from .parallel import FlatExchange
 
 class FlatAdam:
     def __init__(self, fields, lr_init=0.02, lr_basis=1e-3, betas=(0.9, 0.99), eps=1e-8, lr_factor=1.0,
-                 mode="allreduce", group=None):
+                 mode="allreduce", group=None, lr_upsample_reset=True):
         self.fields = list(fields)
-        self.lr0, self.lr1 = float(lr_init), float(lr_basis)
+        self.lr_init, self.lr_basis = float(lr_init), float(lr_basis)
+        self.lr0, self.lr1 = self.lr_init, self.lr_basis
         self.betas, self.eps, self.lr_factor = betas, float(eps), float(lr_factor)
+        self.lr_upsample_reset = bool(lr_upsample_reset)   # opt.py:73-77, default 1 in every shipped config
         self.t = 0
         self._mode, self._group = mode, group
         self.rebuild()
 
     # ---- state -----------------------------------------------------------------------------------
-    def rebuild(self):
+    def rebuild(self, iteration=None):
         """(re)allocate the flat views and zero moments: at construction and after upsample_volume_grid,
-        where the reference also builds a NEW Adam (train.py:2582-2606: the moments are dropped)."""
+        where the reference also builds a NEW Adam (train.py:2582-2606): the moments are dropped and the
+        learning rates restart at lr_init / lr_basis (lr_upsample_reset, the default) or at
+        lr * lr_decay_target_ratio ** (iteration / n_iters) = lr * lr_factor ** iteration."""
+        if iteration is not None:
+            scale = 1.0 if self.lr_upsample_reset else self.lr_factor ** int(iteration)
+            self.lr0, self.lr1 = self.lr_init * scale, self.lr_basis * scale
         layouts = []
         for f in self.fields:
             pflat = f.flatten_params_()
@@ -73,9 +80,17 @@ class FlatAdam:
     def step(self):
         """finish the exchange, Adam on the owned range, parameter all-gather (zero1), lr decay."""
         self.t += 1
-        scale = 1.0 / self.world   # every rank's loss is a mean over ITS rays: mean over ranks = global mean
+        # every rank's loss is a mean over ITS rays, so the mean over ranks is the global mean for the plain means
+        # (equal shard sizes).  The masked means (norm="weight": flow / disparity / static image terms) and the
+        # per-frame median depth losses are normalised by per-SHARD statistics unless the trainer all-reduces them
+        # (Trainer(dp_exact_stats=True): the numerators / denominators of train.py:1391-1394, 797-807): without
+        # that an N-rank run optimises a slightly different objective from the 1-rank run (SURVEY.md 5).
+        scale = 1.0 / self.world
         gathers = []
-        for i, st in enumerate(self.state):
+        for i, (f, st) in enumerate(zip(self.fields, self.state)):
+            if f.flatten_params_().data_ptr() != st["p"].data_ptr():
+                raise L.RdrfError("a field's parameters left the flat buffer FlatAdam updates (Module.to / .cuda / "
+                                  "p.data = ... after construction): call FlatAdam.rebuild()")
             g, lo, n = self.ex.grads(i, st["g"])
             p = st["p"][lo: lo + n]
             L.check(L.lib.rdrf_adam_step(L.ptr(p), L.ptr(g), L.ptr(st["m"]), L.ptr(st["v"]), C.c_size_t(n),

@@ -70,7 +70,10 @@ def scene_config(name="nvidia", stage="stage0"):
         raise ValueError(f"{name}: stage must be one of {sorted(stages)}")
     cfg["grid"], cfg["n_samples"] = stages[stage]
     cfg.update(name=name, stage=stage, monodepth_static=0.04, monodepth_dynamic=0.04, n_iters=100000,
-               lr_decay_target_ratio=0.1)
+               lr_decay_target_ratio=0.1, small_scene_flow_weight=0.1, smooth_scene_flow_weight=0.1,   # opt.py:96-105
+               upsamp_list=[8000, 12000, 16000, 22000] if name == "nvidia" else [2000, 4000, 6000, 8000, 12000, 16000, 22000])
+    # the iteration a run of this stage starts at (train.py:2582-2588: grids change at upsamp_list)
+    cfg["start_iteration"] = 0 if stage == "stage0" else cfg["upsamp_list"][-1]
     cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * math.sqrt(3.0)
     return cfg
 
@@ -288,13 +291,19 @@ class Trainer:
         lr_factor = cfg.get("lr_decay_target_ratio", 0.1) ** (1.0 / cfg.get("n_iters", 100000))   # train.py:926-930
         self.opt = FlatAdam([self.st, self.dy], lr_init, lr_basis, betas=(0.9, 0.99), lr_factor=lr_factor,
                             mode=dp_mode)
+        self.lr_factor = lr_factor
         self.optimize_poses = bool(cfg.get("optimize_poses", False))
+        self.it = int(cfg.get("start_iteration", 0))
         if self.optimize_poses:   # train.py:972-1009: 6-D pose table + field of view, their own Adam
             self.poses = nn.Parameter(self.data.poses.clone())
             self.fov = nn.Parameter(torch.full((1,), 30.0 / 180.0 * math.pi, device=device))
+            self.lr_pose = lr_pose
+            ups = cfg.get("upsamp_list", [0, 0, 0, 0])
+            # ExponentialLR of both (train.py:993-1009); the focal Adam starts at lr 0 and is switched on by the first
+            # upsample at or after upsamp_list[3] (train.py:2589-2595)
+            self.pose_gamma = (1e-5 / lr_pose) ** (1.0 / max(1, cfg.get("n_iters", 100000) // 2 - ups[-1]))
             self.opt_pose = torch.optim.Adam([self.poses], lr=lr_pose)
-            self.opt_focal = torch.optim.Adam([self.fov], lr=lr_pose)
-        self.it = 0
+            self.opt_focal = torch.optim.Adam([self.fov], lr=lr_pose if self.it >= ups[3] else 0.0)
         self.rng = StepRng()
         self.tv = TVLoss()
         self.grad_flats = self.opt.grad_flats()
@@ -349,12 +358,23 @@ class Trainer:
             if self._c2w_fixed is None:
                 self._c2w_fixed = pose_to_mtx(poses).detach()
             c2w_all = self._c2w_fixed
-        temp = 1.0 / (10 ** (it // 100000))                # Temp / Temp_disp_TV / Temp_static, train.py:1034-1036
-        temp_static = 1.0 / (10 ** (it / 100000.0))
+        temp = 1.0 / (10 ** (it // 100000))                # Temp (decay_iteration * 1000 = 100000), train.py:1034-1036
+        temp_disp_tv = 1.0 / (10 ** (it // 50000))         # Temp_disp_TV
+        temp_static = 1.0 / (10 ** (it / 100000.0))        # Temp_static
+        ups = c.get("upsamp_list", [0, 0, 0, 0])
+        early, late = it >= ups[0], it >= ups[3]           # gates of the mask terms (train.py:1338, 1349)
         gt_depth = -disp_t if rt == "ndc" else disp_t      # train.py:1645-1653
         to_depth = (lambda d: d) if rt == "ndc" else (lambda d: 1.0 / (d + 1e-6))
         loss_d = 0.0
         Ld = LossTerms()   # the elementwise terms of the dynamic group: one fused reduction (losses.py)
+
+        def skewed(dyn):   # train.py:1349-1358: binary entropy of dynamicness^2 (late stages only)
+            m2 = torch.clamp(dyn, min=1e-6, max=1.0 - 1e-6) ** 2
+            return torch.mean(-(m2 * torch.log(m2) + (1 - m2) * torch.log(1 - m2)))
+
+        def order_terms(outs):   # adaptive order loss, train.py:1277-1291 / 1666-1683
+            return to_depth(outs[9]), to_depth(outs[5].detach()), (1.0 - outs[12].detach())
+
         # ---- pass A
         osA, oA, outA, xyzA = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
         if capture is not None:
@@ -367,20 +387,31 @@ class Trainer:
             Ls = LossTerms().add(1.0 / 3.0, "square", outE[4], rgb_t, w=(1.0 - fg)[:, None], norm="weight")
             self.terms = (Ld, Ls)
             return Ld.total(), Ls.total()
-        Ld.add(0.1, "abs", outA[12], fg)                                                # :1341-1350
+        if early:
+            Ld.add(0.1 * temp_disp_tv, "abs", outA[12], fg)                             # mask loss, :1338-1346
+        if late:
+            loss_d = loss_d + 0.01 * skewed(outA[12])                                   # :1349-1364
+            Ld.add(0.01, "abs", outA[12])                                               # mask_L1_reg_loss, :1366
+        xo, yo, wo = order_terms(outA)
+        Ld.add(10.0, "square", xo, yo, w=wo, norm="weight")                             # order_loss, :1666-1683
         loss_d = loss_d + c["monodepth_dynamic"] * temp * frame_median_depth_loss(to_depth(outA[9]), gt_depth, view, T)
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters
-        w_dist = c["dist_dynamic"] * min(1.0, (it + 1) / c["n_iters"])
-        loss_d = loss_d + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
+        w_dist = c["dist_dynamic"] * (it / c["n_iters"])
+        if w_dist > 0:
+            loss_d = loss_d + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
         # ---- pass B (second random time)
         _, oB, outB, _ = ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
-        Ld.add(0.01, "identity", outB[12]).add(0.01, "abs", outB[9], outB[5].detach())  # :1267, 1277-1291
-        loss_d = loss_d + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
+        if late:
+            loss_d = loss_d + 0.01 * skewed(outB[12])                                   # :1248-1266
+            Ld.add(0.01, "abs", outB[12])                                               # novel_view_time_mask_loss, :1267
+        xo, yo, wo = order_terms(outB)
+        Ld.add(10.0, "square", xo, yo, w=wo, norm="weight")                             # novel_order_loss, :1277-1291
+        if w_dist > 0:
+            loss_d = loss_d + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
-        w_d = outA[11].detach()                                                         # one weight per sample
-        Ld.add(0.01, "abs", sf_f, w=w_d).add(0.01, "abs", sf_b, w=w_d)                  # :1421
-        Ld.add(0.01, "square", sf_f, sf_b, ysign=1.0, w=w_d)                            # :1627
+        Ld.add(c["small_scene_flow_weight"], "abs", sf_f).add(c["small_scene_flow_weight"], "abs", sf_b)   # :1421-1424
+        Ld.add(c["smooth_scene_flow_weight"], "abs", sf_f, sf_b, ysign=1.0)             # :1627-1628
         # ---- induced flow of the dynamic field into the neighbour frames (train.py:1373-1413)
         weights_d, pts_ref = outA[11], oA[3]
         disp_A = {}
@@ -398,20 +429,19 @@ class Trainer:
             _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, rng)
             _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
             Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
-            loss_d = loss_d + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
+            if w_dist > 0:
+                loss_d = loss_d + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
         # ---- pass E: static field with gradient, rays with gradient (pose / focal)
         oE, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
         m = (1.0 - fg)[:, None]
         Ls = LossTerms()
         loss_s = 0.0
         Ls.add(1.0 / 3.0, "square", outE[4], rgb_t, w=m, norm="weight")                  # :1828-1832
-        if not self.optimize_poses:    # stand-in for the static depth supervision of the GT-pose configs
-            Ls.add(0.04, "abs", outE[5], disp_t, w=m)
         if c["dist_static"] > 0:       # train.py:1841-1861
             loss_s = loss_s + c["dist_static"] * (it / c["n_iters"]) * eff_distloss(outE[7], oE[8].detach(), 1.0 / S)
         if self.optimize_poses:
-            loss_s = loss_s + self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static,
-                                               gt_depth, to_depth, Ls)
+            loss_s = loss_s + self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp_disp_tv,
+                                               temp_static, gt_depth, to_depth, Ls)
         loss_s = loss_s + Ls.total()
         loss_d = loss_d + Ld.total()
         self.terms = (Ld, Ls)
@@ -423,7 +453,8 @@ class Trainer:
         # while the gradients are finite; only the gradient is taken (step(): TVLoss.accumulate_grad_)
         return loss_d, loss_s
 
-    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp, temp_static, gt_depth, to_depth, Ls):
+    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp_disp_tv, temp_static, gt_depth,
+                    to_depth, Ls):
         """train.py:1895-2311 (optimize_poses): every term reaches the static field, the poses and the focal."""
         c = self.cfg
         S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
@@ -453,7 +484,7 @@ class Trainer:
                      torch.stack([col, torch.clamp(row + 1.0, max=H - 0.5)], -1)):
             rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
             _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
-            Ls.add(50.0 * temp, "square", inv_d, 1.0 / torch.clamp(outN[5], min=1e-6))  # :2293-2299
+            Ls.add(50.0 * temp_disp_tv, "square", inv_d, 1.0 / torch.clamp(outN[5], min=1e-6))  # :2293-2305
         return loss
 
     def step(self, shard=None):
@@ -470,14 +501,17 @@ class Trainer:
             self.fov.grad = None
         st, dy = self.st, self.dy
         loss_s.backward()
+        # TV_weight_density / TV_weight_app are multiplied by lr_factor every iteration BEFORE use (train.py:1734-1750;
+        # the static terms of the same iteration use the decayed value, :1872-1885)
+        tv_d, tv_a = (c["tv_density"] * self.lr_factor ** (self.it + 1), c["tv_app"] * self.lr_factor ** (self.it + 1))
         if tv:
             self.tv.accumulate_grad_(st, [(st.density_plane, st.density_line), (st.app_plane, st.app_line)],
-                                     [c["tv_density"], c["tv_app"]])
+                                     [tv_d, tv_a])
         self.opt.begin_exchange(0)           # static field: complete
         loss_d.backward()
         if tv:
             self.tv.accumulate_grad_(dy, [(dy.density_plane, dy.density_line), (dy.blending_plane, dy.blending_line),
-                                          (dy.app_plane, dy.app_line)], [c["tv_density"], c["tv_density"], c["tv_app"]])
+                                          (dy.app_plane, dy.app_line)], [tv_d, tv_d, tv_a])
         self.opt.begin_exchange(1)
         self.last = dict(loss_dynamic=loss_d.detach(), loss_static=loss_s.detach())
         return (loss_d + loss_s).detach()
@@ -487,23 +521,33 @@ class Trainer:
             if self.opt.ex.active:   # the pose / focal gradients are a [T*9 + 1] vector: one tiny all-reduce
                 import torch.distributed as dist
                 buf = torch.cat([self.poses.grad.reshape(-1), self.fov.grad.reshape(-1)])
-                dist.all_reduce(buf)
+                dist.all_reduce(buf, group=self.opt._group)
                 buf /= self.opt.world
                 self.poses.grad.copy_(buf[:-1].view_as(self.poses))
                 self.fov.grad.copy_(buf[-1:])
             self.opt_pose.step()
             self.opt_focal.step()
+            for o in (self.opt_pose, self.opt_focal):   # scheduler.step() / scheduler_focal.step(), train.py:2326-2330
+                o.param_groups[0]["lr"] *= self.pose_gamma
+                if self.it > self.cfg.get("n_iters", 100000) // 2:   # train.py:2608-2610
+                    o.param_groups[0]["lr"] = 0.0
         self.opt.step()
         self.it += 1
 
     def upsample(self, grid, n_samples=None):
-        """train.py:2582-2606: both fields to the new grid, a NEW Adam (moments dropped)."""
+        """train.py:2582-2606: both fields to the new grid, a NEW Adam (moments dropped) whose learning rates restart
+        at lr_init / lr_basis (lr_upsample_reset = 1, opt.py:73-77); the pose rate restarts at lr_pose, the focal rate
+        is switched on from upsamp_list[3]."""
         self.st.upsample_volume_grid(grid)
         self.dy.upsample_volume_grid(grid)
         self.cfg["grid"] = list(grid)
         if n_samples is not None:
             self.cfg["n_samples"] = int(n_samples)
-        self.opt.rebuild()
+        self.opt.rebuild(iteration=self.it)
+        if self.optimize_poses and self.opt.lr_upsample_reset:
+            self.opt_pose.param_groups[0]["lr"] = self.lr_pose
+            if self.it >= self.cfg.get("upsamp_list", [0, 0, 0, 0])[3]:
+                self.opt_focal.param_groups[0]["lr"] = self.lr_pose
         self.grad_flats = self.opt.grad_flats()
 
 

@@ -124,6 +124,7 @@ def kink_free_rays(O, sd_s, cfg_s, sd_d, cfg_d, rays, ts, xyz, z, valid, rt, r_s
             risk |= near0(pre)
             x = F.relu(pre)
         ok = ~risk.view(N, S).any(1)
+        kink_free_rays.sample_risk = float(risk.float().mean())   # per-SAMPLE rate (S-independent), for the guards
         for k in (0, 4, 8):       # clamp(rgb_map, 0, 1)
             v = outs[k].detach()
             # (exactly 0 / exactly 1 are not kinks for this purpose: clamp's backward is inclusive on both sides)

@@ -96,7 +96,13 @@ def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26
         r_d = O.field_forward(sd_d, cfg_d, rays, ts, xyz, z, valid, rt, dynamic=True)
         r_o = O.raw2outputs(r_s[6], r_s[7], r_d[6], r_d[7], r_d[9], r_d[2], r_d[8], rays, True, rt)
     keep = kink_free_rays(O, sd_s, cfg_s, sd_d, cfg_d, rays, ts, xyz, z, valid, rt, r_s, r_d, r_o)
-    assert float(keep.float().mean()) > 0.8, f"too many rays excluded ({float(keep.float().mean()):.2f} kept)"
+    # guard on the exclusion: a ray is dropped when ANY of its S samples sits on a kink, so the kept fraction is
+    # ~ (1 - r)^S with r the per-sample rate (measured 0.25-0.3 %: ~500 relu units x 2e-6 relative margin each).
+    # Both are bounded: r < 0.4 % whatever S, and > 80 % of the rays kept at the 70-sample reference length.
+    kept, r_s_ = float(keep.float().mean()), kink_free_rays.sample_risk
+    assert r_s_ < 4e-3, f"per-sample kink exclusion rate {r_s_:.4f}"
+    floor = 0.8 if S <= 70 else 0.9 * 0.8 ** (S / 70.0)
+    assert kept > floor, f"too many rays excluded ({kept:.2f} kept, S = {S}, floor {floor:.2f})"
     wr = keep.float()
 
     def loss(outs, sf, t, w):  # the three image terms of train.py:1323-1332,1827-1835 + extras, per-ray weighted

@@ -133,13 +133,14 @@ SMALL = {
 }
 
 
-@pytest.mark.parametrize("name", ["nvidia", "nvidia_no_poses", "davis"])
-def test_trainer_step_gradient_matches_oracle_step(name):
+@pytest.mark.parametrize("name,it", [("nvidia", 5000), ("nvidia", 30000), ("nvidia_no_poses", 5000), ("davis", 5000)])
+def test_trainer_step_gradient_matches_oracle_step(name, it):
     """ONE complete iteration of every config -- 5 dynamic + 5 static forwards (Nvidia.txt)
     or 7 + 9 with the pose / focal block (Nvidia_no_poses.txt, DAVIS.txt: contracted rays, TimeEmbedding
     static head, density_L1, per-frame depth losses) -- on a small scene: the flat gradient of both fields
     (and of the pose table and the field of view) from Trainer.step vs the oracle's re-enactment of the same
-    iteration (oracle/rodynrf_oracle_step.py) with identical batch, jitter vectors and white-background coins."""
+    iteration (oracle/rodynrf_oracle_step.py) with identical batch, jitter vectors and white-background coins.
+    (The pass structure the two share is pinned to the reference by test_pass_structure_matches_reference_fixture.)"""
     from oracle import rodynrf_oracle_step as OS
     S_ = importlib.import_module("robust-dynrf_amd.step")
     cfg = S_.scene_config(name, "stage0")
@@ -147,7 +148,7 @@ def test_trainer_step_gradient_matches_oracle_step(name):
     cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * 3.0 ** 0.5
     dev = torch.device("cuda", 0)
     tr = S_.Trainer(cfg, dev)
-    tr.it = 5000                                   # the ramped loss weights are non-zero
+    tr.it = it    # the ramped loss weights are non-zero; 5000 / 30000: before / after upsamp_list[0] and [3] (mask-term gates)
     tr.rng = OS.FixedRng(11)
     sd_s = {k: v.detach().cpu().contiguous().clone() for k, v in tr.st.state_dict().items()}
     sd_d = {k: v.detach().cpu().contiguous().clone() for k, v in tr.dy.state_dict().items()}
@@ -356,3 +357,34 @@ def test_pass_structure_matches_reference_fixture(case, dead_work):
     except AssertionError as e:
         bad.append(str(e))
     assert not bad, "\n".join(bad)
+
+
+def test_upsample_restarts_learning_rates_like_the_reference():
+    """train.py:2582-2606 with lr_upsample_reset = 1 (opt.py:73-77, every shipped config): after an upsample the new
+    Adam starts at lr_init / lr_basis again (not at the decayed rates), the moments and the step count are dropped,
+    the pose rate restarts at lr_pose and the focal rate is switched on from upsamp_list[3]; with
+    lr_upsample_reset = 0 the rates continue at lr * lr_decay_target_ratio ** (iteration / n_iters)."""
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    cfg = S_.scene_config("nvidia_no_poses", "stage0")
+    cfg.update(SMALL["nvidia_no_poses"])
+    cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * 3.0 ** 0.5
+    cfg["n_iters"] = 1000    # a visible decay per step
+    tr = S_.Trainer(cfg, torch.device("cuda", 0))
+    assert tr.opt_focal.param_groups[0]["lr"] == 0.0 and tr.opt_pose.param_groups[0]["lr"] == 3e-3
+    for _ in range(3):
+        tr.step()
+        tr.finish_step()
+    f = 0.1 ** (1.0 / 1000)
+    assert tr.opt.lr0 == pytest.approx(0.02 * f ** 3) and tr.opt.lr1 == pytest.approx(1e-3 * f ** 3) and tr.opt.t == 3
+    assert tr.opt_pose.param_groups[0]["lr"] < 3e-3
+    tr.it = cfg["upsamp_list"][3]
+    tr.upsample([20, 22, 13], 16)
+    assert tr.opt.lr0 == 0.02 and tr.opt.lr1 == 1e-3 and tr.opt.t == 0
+    assert all(float(st["m"].abs().max()) == 0.0 and float(st["v"].abs().max()) == 0.0 for st in tr.opt.state)
+    assert tr.opt_pose.param_groups[0]["lr"] == 3e-3 and tr.opt_focal.param_groups[0]["lr"] == 3e-3
+    loss = tr.step()
+    tr.finish_step()
+    assert torch.isfinite(loss)
+    tr.opt.lr_upsample_reset = False
+    tr.upsample([24, 26, 16], 18)
+    assert tr.opt.lr0 == pytest.approx(0.02 * f ** tr.it) and tr.opt.lr1 == pytest.approx(1e-3 * f ** tr.it)
