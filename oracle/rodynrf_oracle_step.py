@@ -20,14 +20,17 @@ class FixedRng:
     def __init__(self, seed=0):
         self.gen = torch.Generator().manual_seed(seed)
 
+    def _rand(self, n, device="cpu"):
+        # always the fp32 stream (the same draws when the oracle is re-run in fp64 for conditioning estimates)
+        return torch.rand(n, generator=self.gen, dtype=torch.float32).to(torch.get_default_dtype()).to(device)
+
     def coin(self):
-        return bool(torch.rand(1, generator=self.gen).item() < 0.5)
+        return bool(self._rand(1).item() < 0.5)
 
     def jitter(self, S, ray_type, device="cpu"):
         if ray_type == "ndc":
-            return torch.rand(S, generator=self.gen).to(device), None
-        return (torch.rand(S - S // 2 + 1, generator=self.gen).to(device),
-                torch.rand(S // 2 + 1, generator=self.gen).to(device))
+            return self._rand(S, device), None
+        return self._rand(S - S // 2 + 1, device), self._rand(S // 2 + 1, device)
 
 
 class ReplayRng:
@@ -97,7 +100,7 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
     focal_d = focal.detach() if torch.is_tensor(focal) else focal
     dt = 2.0 / (T - 1)
     col, row, view = O.ids2pixel(W, H, ids)
-    grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+    grid = torch.stack([col.to(poses.dtype) + 0.5, row.to(poses.dtype) + 0.5], -1)
     c2w_all = O.pose_to_mtx(poses)
     temp = 1.0 / (10 ** (it // 100000))              # train.py:1034-1036
     temp_disp_tv = 1.0 / (10 ** (it // 50000))

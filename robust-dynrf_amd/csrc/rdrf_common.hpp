@@ -335,7 +335,42 @@ RDRF_D f32x4 gather_quad(const RdrfVM& vm, int g, float x0, float x1, float x2) 
 // shared input blocks X0 (xn, t, PE10(xn)) and X1 (PE8(t)) in canonical layout
 // (models/tensorBase.py:13-19 positional_encoding: q[d*F+k] = p[d]*2^k; [sin(q), cos(q)])
 // ---------------------------------------------------------------------------------------------
-RDRF_D void fill_x0(float (&X0)[32], float xn0, float xn1, float xn2, float t, int h) {
+// sin / cos of a positional-encoding argument: two-constant Cody-Waite reduction by pi/2 (exact products inside
+// the fma, so the reduced argument carries one rounding for |a| <= 1e5: n <= 6.4e4 and n * (pi/2 - C1 - C2) < 4e-10),
+// then the Cephes single-precision minimax polynomials on [-pi/4, pi/4].  Max abs error 9.2e-8 over the encodings'
+// argument range (libm: 7e-8; tests/test_abi_cpu.py::test_sincos_pe_formula restates and bounds it) in ~24 VALU
+// instructions; OCML's sincosf costs ~40 plus a large-argument branch, and the encodings were 28 % of
+// k_dyn_density's vector instructions.  Callers route |a| > 1e5 (wild feature-mode coordinates) to OCML.
+#define RDRF_PE_FAST_MAX 1.0e5f
+RDRF_D void sincos_pe(float a, float& s, float& c) {
+  const float n = rintf(a * 0.63661977236758134f);
+  float r = fmaf(n, -1.57079625129699707031e+00f, a);
+  r = fmaf(n, -7.54978941586159635335e-08f, r);
+  const int q = (int)n;
+  const float r2 = r * r;
+  float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = fmaf(sp, r2, -1.6666654611e-1f);
+  const float sr = fmaf(sp * r2, r, r);
+  float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = fmaf(cp, r2, 4.166664568298827e-2f);
+  const float cr = fmaf(cp * r2, r2, fmaf(r2, -0.5f, 1.0f));
+  const bool sw = (q & 1) != 0;
+  const float S = sw ? cr : sr, C = sw ? sr : cr;
+  s = __int_as_float(__float_as_int(S) ^ ((q & 2) << 30));
+  c = __int_as_float(__float_as_int(C) ^ (((q + 1) & 2) << 30));
+}
+template <bool FAST>
+RDRF_D void sincos_sel(float a, float& s, float& c) {
+#ifdef RDRF_ABL_OCML_SINCOS
+  sincosf(a, &s, &c);
+#else
+  if constexpr (FAST) sincos_pe(a, s, c);
+  else sincosf(a, &s, &c);
+#endif
+}
+
+template <bool FAST>
+RDRF_D void fill_x0_impl(float (&X0)[32], float xn0, float xn1, float xn2, float t, int h) {
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     if (o == 0 && h == 0) {
@@ -348,28 +383,34 @@ RDRF_D void fill_x0(float (&X0)[32], float xn0, float xn1, float xn2, float t, i
         const int d = j / 10, f = j - d * 10;
         const float x = d == 0 ? xn0 : (d == 1 ? xn1 : xn2);
         float sv, cv;
-#ifdef RDRF_ABL_FASTSIN
-        __sincosf(ldexpf(x, f), &sv, &cv);
-#else
-        sincosf(ldexpf(x, f), &sv, &cv);
-#endif
+        sincos_sel<FAST>(ldexpf(x, f), sv, cv);
         X0[o * 4 + 2 * p] = sv;
         X0[o * 4 + 2 * p + 1] = cv;
       }
     }
   }
 }
-RDRF_D void fill_x1(float (&X1)[8], float t, int h) {
+RDRF_D void fill_x0(float (&X0)[32], float xn0, float xn1, float xn2, float t, int h) {
+  const bool wild = !(fmaxf(fmaxf(fabsf(xn0), fabsf(xn1)), fabsf(xn2)) * 512.0f <= RDRF_PE_FAST_MAX);
+  if (__builtin_expect(__any(wild), 0)) fill_x0_impl<false>(X0, xn0, xn1, xn2, t, h);
+  else fill_x0_impl<true>(X0, xn0, xn1, xn2, t, h);
+}
+template <bool FAST>
+RDRF_D void fill_x1_impl(float (&X1)[8], float t, int h) {
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int f = 4 * o + 2 * h + p;
       float sv, cv;
-      sincosf(ldexpf(t, f), &sv, &cv);
+      sincos_sel<FAST>(ldexpf(t, f), sv, cv);
       X1[o * 4 + 2 * p] = sv;
       X1[o * 4 + 2 * p + 1] = cv;
     }
+}
+RDRF_D void fill_x1(float (&X1)[8], float t, int h) {
+  if (__builtin_expect(__any(!(fabsf(t) * 128.0f <= RDRF_PE_FAST_MAX)), 0)) fill_x1_impl<false>(X1, t, h);
+  else fill_x1_impl<true>(X1, t, h);
 }
 
 // raw2alpha's per-sample factor 1 - alpha + 1e-10 (models/tensorBase.py:28, renderer.py:220)

@@ -132,12 +132,27 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, Stat
       continue;
     }
     float P[64];
+    {
+      float fmax_ = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float s1, c1, s2, c2;
-      sincosf(F[r], &s1, &c1);
-      sincosf(F[r] * 2.0f, &s2, &c2);
-      P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+      for (int r = 0; r < 16; ++r) fmax_ = fmaxf(fmax_, fabsf(F[r]));
+      if (__builtin_expect(__any(!(fmax_ * 2.0f <= RDRF_PE_FAST_MAX)), 0)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s1, c1, s2, c2;
+          sincosf(F[r], &s1, &c1);
+          sincosf(F[r] * 2.0f, &s2, &c2);
+          P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s1, c1, s2, c2;
+          sincos_sel<true>(F[r], s1, c1);
+          sincos_sel<true>(F[r] * 2.0f, s2, c2);
+          P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+        }
+      }
     }
     if (HEAD == RDRF_HEAD_MLP_FEA) {  // viewdirs ride in the pad slots 27..29 of the feature block
       if (h == 0) F[15] = vx;
@@ -468,7 +483,9 @@ RDRF_D void fill_sf_x(float (&X)[20], float xn0, float xn1, float xn2, float t, 
         if (pr < 16) {
           const int d = pr >> 2, f = pr & 3;
           const float x = pr < 12 ? (d == 0 ? xn0 : (d == 1 ? xn1 : xn2)) : t;
-          sincosf(ldexpf(x, f), &sv, &cv);
+          const float a_ = ldexpf(x, f);
+          if (__builtin_expect(!(fabsf(a_) <= RDRF_PE_FAST_MAX), 0)) sincosf(a_, &sv, &cv);
+          else sincos_sel<true>(a_, sv, cv);
         }
         X[o * 4 + 2 * p] = sv;
         X[o * 4 + 2 * p + 1] = cv;

@@ -156,8 +156,32 @@ def test_trainer_step_gradient_matches_oracle_step(name, it):
     poses = tr.pose_table().detach().cpu()
     foc = tr.fov.detach().cpu() if tr.optimize_poses else float(tr.data.focal)
     loss_ref, gref = OS.step_gradients(dict(cfg), sd_s, sd_d, batch, poses, foc, tr.it, OS.FixedRng(11))
+    # conditioning: the same iteration in fp64 (identical draws: the jitter / coin stream is fp32 either way) measures how
+    # far the fp32 REFERENCE arithmetic is from exact for each gradient entry (the order loss is 10 x a squared depth
+    # difference: cancelling sums; a relu unit whose pre-activation rounds to the other side): the kernels are held to
+    # tolerance + twice that distance, element by element, the allowance capped at the tolerance itself (no kink-free
+    # ray selection here -- the trainer draws its own batch; the pass structure is pinned at 1e-4 by the reference fixture)
+    torch.set_default_dtype(torch.float64)
+    try:
+        cv = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+        _, g64 = OS.step_gradients(dict(cfg), {k: cv(v.detach()) for k, v in sd_s.items()},
+                                   {k: cv(v.detach()) for k, v in sd_d.items()}, {k: cv(v) for k, v in batch.items()},
+                                   cv(poses), cv(foc), tr.it, OS.FixedRng(11))
+    finally:
+        torch.set_default_dtype(torch.float32)
     loss = tr.step()
     assert abs(float(loss) - float(loss_ref)) <= 2e-4 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+
+    def check(name, got, ref, ref64, rtol):
+        a, b = got.detach().cpu().double(), ref.double()
+        cond = (2.0 * (b - ref64.double()).abs()).clamp(max=rtol * float(b.abs().max()))
+        err = (a - b).abs()
+        tol = rtol * float(b.abs().max()) + cond
+        if not bool((err <= tol).all()):
+            i = int((err - tol).argmax())
+            bad.append(f"{name}: |err| {float(err.flatten()[i]):.3e} > {rtol:.0e} * max|ref| ({float(b.abs().max()):.3e}) + "
+                       f"conditioning {float(cond.flatten()[i]):.3e}")
+
     bad, n = [], 0
     for mod, pre in ((tr.st, "s."), (tr.dy, "d.")):
         for k, p in mod.named_parameters():
@@ -166,16 +190,10 @@ def test_trainer_step_gradient_matches_oracle_step(name, it):
                 assert float(p.grad.abs().max()) == 0.0, f"{pre}{k}: expected no gradient"
                 continue
             n += 1
-            try:
-                assert_close(p.grad, ref, pre + k, rtol=5e-4)
-            except AssertionError as e:
-                bad.append(str(e))
+            check(pre + k, p.grad, ref, g64[pre + k], 5e-4)
     if tr.optimize_poses:
         for nm, ten in (("poses", tr.poses), ("fov", tr.fov)):
-            try:
-                assert_close(ten.grad, gref[nm], nm, rtol=1e-3)
-            except AssertionError as e:
-                bad.append(str(e))
+            check(nm, ten.grad, gref[nm], g64[nm], 1e-3)
     assert n > 60 and not bad, "\n".join(bad)
     # and the optimiser step applies: parameters move, stay finite
     before = tr.st.flatten_params_().clone()
