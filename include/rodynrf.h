@@ -340,7 +340,7 @@ int rdrf_dynamic_pack(const RdrfDynamicParams* P, int backward, float* image, rd
  * bwd: out as written by fwd; g_loss[0] (device) = d L / d out[0].  Deterministic (no float atomics). */
 enum { RDRF_LOSS_SQUARE = 0, RDRF_LOSS_ABS = 1, RDRF_LOSS_IDENTITY = 2 };
 enum { RDRF_LOSS_NORM_MEAN = 0, RDRF_LOSS_NORM_WEIGHT = 1 };
-#define RDRF_MAX_LOSS_TERMS 24
+#define RDRF_MAX_LOSS_TERMS 32
 typedef struct {
   const float* x;
   const float* y;
@@ -358,6 +358,25 @@ size_t rdrf_loss_terms_workspace_floats(int n);
 int rdrf_loss_terms_fwd(const RdrfLossTerm* terms, int n, float* partial, float* out, rdrf_stream_t stream);
 int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float* out, const float* g_loss,
                         rdrf_stream_t stream);
+
+/* ---- per-frame median-normalised monocular depth loss: train.py:797-807 compute_depth_loss summed over the
+ * frames of the batch and divided by the number of rays used (train.py:1636-1664 dynamic, 2097-2121 static):
+ *   for each frame k with more than one (unmasked) ray:  t = median(p), s = mean|p - t|, u = (p - t) / (s + 1e-10),
+ *   likewise v from gt;  L_k = sum (u - v)^2;      loss = coef * sum_k L_k / sum_k n_k.
+ * The reference loops over the frames on the host (one sync each); here one workgroup per frame selects its
+ * rays (in ray order), bitonic-sorts them in LDS for the median (torch.median: the lower middle element) and
+ * writes the loss AND its gradient wrt pred in the same pass: g_raw[j] = d(sum_k L_k)/d pred[j], with the
+ * median's gradient spread evenly over the elements equal to it (ATen's evenly_distribute_backward).
+ * pred, gt [N]; frame [N] int64 in [0, T); mask [N] uint8 or NULL (NULL: every ray is used).
+ * out[0] = loss, out[1] = coef / sum_k n_k (the factor g_raw is to be multiplied with), out[2] = sum_k n_k.
+ * ws: rdrf_frame_depth_loss_workspace_bytes(N, T).  N <= 16384. */
+size_t rdrf_frame_depth_loss_workspace_bytes(int N, int T);
+int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, const int64_t* frame, const uint8_t* mask,
+                              int N, int T, float coef, float* out, float* g_raw, void* ws, size_t ws_bytes,
+                              rdrf_stream_t stream);
+/* g_pred[j] = g_loss[0] * out[1] * g_raw[j] */
+int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float* g_pred,
+                              rdrf_stream_t stream);
 
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
  * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].

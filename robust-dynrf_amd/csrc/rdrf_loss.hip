@@ -122,3 +122,178 @@ extern "C" int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float
   RDRF_LAUNCH("loss_terms_bwd", k_loss_bwd, dim3(LOSS_BLOCKS, n), dim3(256), stream, T, out, g_loss);
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-frame median-normalised depth loss (train.py:797-807, 1636-1664, 2097-2121): one workgroup per frame
+// ------------------------------------------------------------------------------------------------------------------
+#define FDL_THREADS 1024
+#define FDL_MAXN 16384
+
+RDRF_D float block_sum(float v, float* red /*[16]*/) {   // deterministic tree; every thread gets the total
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < FDL_THREADS / 64; ++i) t += red[i];
+  return t;
+}
+
+// bitonic sort of buf[0..np2) (np2 a power of two, padding = +inf) by the whole block
+RDRF_D void bitonic_sort_lds(float* buf, int np2) {
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float a = buf[i], b = buf[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+struct FdlStats { float med, inv; };   // median, 1 / (mean|x - med| + 1e-10)
+
+// median (lower middle element of the sorted values) and mean absolute deviation of x[ids[0..n)]
+RDRF_D FdlStats fdl_stats(const float* __restrict__ x, const int* ids, int n, float* sortbuf, float* red) {
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) sortbuf[i] = i < n ? x[ids[i]] : INFINITY;
+  bitonic_sort_lds(sortbuf, np2);
+  const float med = sortbuf[(n - 1) >> 1];
+  float dev = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dev += fabsf(x[ids[i]] - med);
+  const float s = block_sum(dev, red) / (float)n;
+  FdlStats r;
+  r.med = med;
+  r.inv = 1.0f / (s + 1e-10f);
+  return r;
+}
+
+__global__ __launch_bounds__(FDL_THREADS) void k_frame_depth_loss(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                                   const int64_t* __restrict__ frame,
+                                                                   const uint8_t* __restrict__ mask, int N,
+                                                                   float* __restrict__ g_raw, float* __restrict__ part /*[T][2]*/) {
+  extern __shared__ float fdl_lds[];
+  float* sortbuf = fdl_lds;                       // [pow2(N)]
+  int* ids = (int*)(fdl_lds + FDL_MAXN);          // [N]
+  __shared__ float red[FDL_THREADS / 64];
+  __shared__ int wcount[FDL_THREADS / 64];
+  __shared__ int base_s;
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- select this frame's rays, in ray order (ballot compaction: deterministic)
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < N; i0 += FDL_THREADS) {
+    const int i = i0 + threadIdx.x;
+    const bool sel = i < N && frame[i] == (int64_t)k && (mask == nullptr || mask[i] != 0);
+    const unsigned long long b = __ballot(sel);
+    if (lane == 0) wcount[wave] = __popcll(b);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (sel) ids[off + __popcll(b & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < FDL_THREADS / 64; ++w) t += wcount[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  const int n = base_s;
+  if (n <= 1) {   // train.py:1641 / 2103: frames with fewer than two rays are skipped
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g_raw[ids[i]] = 0.f;
+    if (threadIdx.x == 0) { part[2 * k] = 0.f; part[2 * k + 1] = 0.f; }
+    return;
+  }
+  const FdlStats sp = fdl_stats(pred, ids, n, sortbuf, red);
+  const FdlStats sg = fdl_stats(gt, ids, n, sortbuf, red);
+  // ---- loss and the three sums of the gradient:  A = sum a, B = sum a (p - m), Sg = sum sgn(p - m), c = #(p == m)
+  float Ls = 0.f, A = 0.f, B = 0.f, Sg = 0.f, cnt = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int j = ids[i];
+    const float dp = pred[j] - sp.med;
+    const float r = dp * sp.inv - (gt[j] - sg.med) * sg.inv;
+    const float a = 2.0f * r;
+    Ls += r * r;
+    A += a;
+    B += a * dp;
+    Sg += dp > 0.f ? 1.0f : (dp < 0.f ? -1.0f : 0.f);
+    cnt += dp == 0.f ? 1.0f : 0.f;
+  }
+  Ls = block_sum(Ls, red); A = block_sum(A, red); B = block_sum(B, red); Sg = block_sum(Sg, red); cnt = block_sum(cnt, red);
+  // d u_i / d p_j = (delta_ij - e_j) inv - (p_i - m) inv^2 ds/dp_j,   ds/dp_j = (sgn(p_j - m) - e_j Sg) / n,   e_j = [p_j == m] / c
+  const float kB = B * sp.inv * sp.inv / (float)n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int j = ids[i];
+    const float dp = pred[j] - sp.med;
+    const float r = dp * sp.inv - (gt[j] - sg.med) * sg.inv;
+    const float e = dp == 0.f ? 1.0f / cnt : 0.f;
+    const float sgn = dp > 0.f ? 1.0f : (dp < 0.f ? -1.0f : 0.f);
+    g_raw[j] = 2.0f * r * sp.inv - e * A * sp.inv - kB * (sgn - e * Sg);
+  }
+  if (threadIdx.x == 0) { part[2 * k] = Ls; part[2 * k + 1] = (float)n; }
+}
+
+// rays no frame selected (masked out) get a zero gradient; loss = coef * sum L_k / sum n_k
+__global__ __launch_bounds__(256) void k_frame_depth_finish(const float* __restrict__ part, int T, float coef,
+                                                            const uint8_t* __restrict__ mask, int N,
+                                                            float* __restrict__ g_raw, float* __restrict__ out) {
+  if (mask != nullptr)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+      if (mask[i] == 0) g_raw[i] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float L = 0.f, c = 0.f;
+    for (int k = 0; k < T; ++k) { L += part[2 * k]; c += part[2 * k + 1]; }   // frame order, like the reference's loop
+    out[0] = coef * L / c;
+    out[1] = coef / c;
+    out[2] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frame_depth_bwd(const float* __restrict__ g_raw, const float* __restrict__ out,
+                                                         const float* __restrict__ g_loss, int N, float* __restrict__ g_pred) {
+  const float s = g_loss[0] * out[1];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) g_pred[i] = s * g_raw[i];
+}
+
+extern "C" size_t rdrf_frame_depth_loss_workspace_bytes(int N, int T) { return (size_t)(2 * (T > 0 ? T : 1)) * sizeof(float) + 256; }
+
+extern "C" int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, const int64_t* frame, const uint8_t* mask,
+                                         int N, int T, float coef, float* out, float* g_raw, void* ws, size_t ws_bytes,
+                                         rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(pred && gt && frame && out && g_raw && ws, -1, "frame_depth_loss: null argument");
+  RDRF_CHECK(N >= 1 && N <= FDL_MAXN && T >= 1, -1, "frame_depth_loss: N must be in 1..%d (got %d), T >= 1 (got %d)", FDL_MAXN, N, T);
+  RDRF_CHECK(ws_bytes >= rdrf_frame_depth_loss_workspace_bytes(N, T), -2, "frame_depth_loss: workspace too small");
+  float* part = (float*)ws;
+  const size_t lds = (size_t)FDL_MAXN * 4 + (size_t)N * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RDRF_HIP(hipFuncSetAttribute((const void*)k_frame_depth_loss, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FDL_MAXN * 4));
+    attr_set = true;
+  }
+  rdrf_prof_begin("frame_depth_loss", stream);
+  hipLaunchKernelGGL(k_frame_depth_loss, dim3(T), dim3(FDL_THREADS), lds, stream, pred, gt, frame, mask, N, g_raw, part);
+  hipLaunchKernelGGL(k_frame_depth_finish, dim3(mask ? (N + 255) / 256 : 1), dim3(256), 0, stream, (const float*)part, T, coef,
+                     mask, N, g_raw, out);
+  rdrf_prof_end("frame_depth_loss", stream);
+  RDRF_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float* g_pred,
+                                         rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(g_raw && out && g_loss && g_pred && N >= 1, -1, "frame_depth_loss_bwd: bad arguments");
+  RDRF_LAUNCH("frame_depth_loss_bwd", k_frame_depth_bwd, dim3((N + 255) / 256), dim3(256), stream, g_raw, out, g_loss, N, g_pred);
+  return 0;
+}

@@ -59,6 +59,49 @@ class _LossTermsFn(torch.autograd.Function):
         return (None, *grads)
 
 
+class _FrameDepthLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, frame, mask, T, coef):
+        L.require_device(pred, gt, frame, mask)
+        pred, gt = L.f32c(pred).reshape(-1), L.f32c(gt).reshape(-1)
+        frame = frame.contiguous()
+        if frame.dtype != torch.int64:
+            frame = frame.long()
+        if mask is not None:
+            mask = mask.contiguous()
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else (mask != 0).view(torch.uint8)
+        N = pred.numel()
+        out = torch.empty(3, device=pred.device)
+        g_raw = torch.empty(N, device=pred.device)
+        nb = int(L.lib.rdrf_frame_depth_loss_workspace_bytes(N, int(T)))
+        ws = L.workspace(pred.device, nb)
+        L.check(L.lib.rdrf_frame_depth_loss_fwd(L.ptr(pred), L.ptr(gt), L.ptr(frame), L.ptr(mask), N, int(T), float(coef),
+                                                L.ptr(out), L.ptr(g_raw), L.ptr(ws), C.c_size_t(nb), L.stream_of(pred)),
+                "rdrf_frame_depth_loss_fwd")
+        ctx.save_for_backward(g_raw, out)
+        ctx.shape = pred.shape
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        g_raw, out = ctx.saved_tensors
+        g_pred = torch.empty_like(g_raw)
+        L.check(L.lib.rdrf_frame_depth_loss_bwd(L.ptr(g_raw), L.ptr(out), L.ptr(L.f32c(g_loss.reshape(1))), g_raw.numel(),
+                                                L.ptr(g_pred), L.stream_of(g_raw)), "rdrf_frame_depth_loss_bwd")
+        return g_pred, None, None, None, None, None
+
+
+def frame_depth_loss(pred, gt, frame, T, mask=None, coef=1.0):
+    """coef * (train.py:797-807 compute_depth_loss summed over the frames of the batch with more than one ray) / (number
+    of rays used): the per-frame median-normalised monocular depth loss of train.py:1636-1664 (dynamic) and
+    2097-2121 (static, mask = background rays).  pred, gt [N]; frame [N] in [0, T).  One workgroup per frame
+    (selection, LDS bitonic sort for the median, loss and gradient in the same pass): 2 launches instead of the ~40
+    small sort / scatter / gather launches of a torch formulation, no host synchronisation."""
+    if pred.shape != gt.shape or pred.numel() != frame.numel():
+        raise L.RdrfError("frame_depth_loss: pred, gt, frame must have one entry per ray")
+    return _FrameDepthLossFn.apply(pred, gt, frame, mask, T, coef)
+
+
 class LossTerms:
     """terms = LossTerms(); terms.add(3.0, "square", rgb_map, rgb_gt); ...; loss = terms.total()"""
 
@@ -76,6 +119,8 @@ class LossTerms:
         if len(self._meta) >= L.MAX_LOSS_TERMS:
             raise L.RdrfError(f"LossTerms: more than {L.MAX_LOSS_TERMS} terms in one group")
         L.require_device(x, y, w)
+        if x.dim() == 0:   # a scalar term (another fused loss' value): coef * x
+            x = x.reshape(1)
         if y is not None and y.shape != x.shape:
             raise L.RdrfError(f"LossTerms: x {tuple(x.shape)} and y {tuple(y.shape)} differ")
         rows = x.numel() if w is None else w.numel()

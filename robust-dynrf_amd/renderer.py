@@ -331,6 +331,12 @@ class _DistLossFn(torch.autograd.Function):
         return g_w, None, None
 
 
+def distloss_rays(w, m, interval):
+    """the per-ray values of eff_distloss [N] (their mean is the loss): lets the trainer fold the mean and the loss
+    weight into its fused loss reduction instead of three scalar launches per call"""
+    return _DistLossFn.apply(w, m, interval)
+
+
 def eff_distloss(w, m, interval):
     """torch_efficient_distloss.eff_distloss: w, m [N,S] (m ascending along a ray), interval a scalar
     or [N,S]; mean over rays of  sum_ij w_i w_j |m_i - m_j| + (1/3) sum_i interval w_i^2."""

@@ -37,8 +37,8 @@ from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
 from .optim import FlatAdam
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
-from .losses import LossTerms
-from .renderer import eff_distloss, induce_flow, raw2outputs, sampleXYZ
+from .losses import LossTerms, frame_depth_loss
+from .renderer import distloss_rays, induce_flow, raw2outputs, sampleXYZ
 
 NDC_AABB = [[-1.5, -1.67, -1.0], [1.5, 1.67, 1.0]]
 
@@ -174,6 +174,10 @@ class SyntheticScene:
         self.grid_table = torch.stack([col.float() + 0.5, row.float() + 0.5], -1).to(device)
         self.view_table = view.to(device)
         self.ts_table = (view.float() * (2.0 / (T - 1)) - 1.0).to(device)
+        # packed copies for make_batch: one gather per SHAPE class instead of one per tensor (11 launches -> 5);
+        # row k of a packed gather is a contiguous tensor
+        self._scalars = torch.stack([self.ts_table, self.disp, self.fgmask, self.flow_mask_f[:, 0], self.flow_mask_b[:, 0]])
+        self._vec2 = torch.stack([self.flow_f, self.flow_b, self.grid_table])
 
     def batch(self, it, bs, which=0):
         off = ((it * 3 + which) * bs) % (self.total - bs)
@@ -189,10 +193,9 @@ class SyntheticScene:
             r, w = shard
             lo, hi = r * bs // w, (r + 1) * bs // w
             ids, ids2 = ids[lo:hi], ids2[lo:hi]
-        return dict(ids=ids, ts=self.ts_of(ids), ts_rand=self.ts_of(ids2), grid=self.grid_table[ids],
-                    view=self.view_table[ids], rgb=self.rgb[ids], disp=self.disp[ids],
-                    fg=self.fgmask[ids], flow_f=self.flow_f[ids], flow_b=self.flow_b[ids],
-                    mask_f=self.flow_mask_f[ids], mask_b=self.flow_mask_b[ids])
+        sc, v2 = self._scalars[:, ids], self._vec2[:, ids]
+        return dict(ids=ids, ts=sc[0], ts_rand=self.ts_of(ids2), grid=v2[2], view=self.view_table[ids], rgb=self.rgb[ids],
+                    disp=sc[1], fg=sc[2], flow_f=v2[0], flow_b=v2[1], mask_f=sc[3][:, None], mask_b=sc[4][:, None])
 
 
 SyntheticBalloon = SyntheticScene   # round-1 name
@@ -205,43 +208,25 @@ class StepRng:
 
     def __init__(self, seed=7):
         self.gen = torch.Generator().manual_seed(seed)
+        self._pool, self._cur = None, 0
 
     def coin(self):
         return bool(torch.rand(1, generator=self.gen).item() < 0.5)
 
+    def _take(self, n, device):
+        """n uniform [0,1) floats from a device pool refilled by ONE rand launch per ~16 passes (a pass draws one
+        or two small vectors: a launch each otherwise); 64-float aligned slices, contiguous"""
+        n_al = (n + 63) // 64 * 64
+        if self._pool is None or self._pool.device != torch.device(device) or self._cur + n_al > self._pool.numel():
+            self._pool, self._cur = torch.rand(max(16 * n_al, 8192), device=device), 0
+        v = self._pool[self._cur: self._cur + n]
+        self._cur += n_al
+        return v
+
     def jitter(self, S, ray_type, device):
         if ray_type == "ndc":
-            return torch.rand(S, device=device), None
-        return torch.rand(S - S // 2 + 1, device=device), torch.rand(S // 2 + 1, device=device)
-
-
-def frame_median_depth_loss(pred, gt, frame, T, mask=None):
-    """train.py:797-807 compute_depth_loss summed over the frames of the batch and divided by the number of
-    rays used (train.py:1636-1664, 2097-2121): per frame k with more than one ray,
-    sum(((p - med p) / (mean|p - med p| + 1e-10) - (g - med g) / (mean|g - med g| + 1e-10))^2).
-    The reference loops over the frames on the host with a sync per frame; here the per-frame medians
-    come from one segmented sort on the device (torch.median = the lower middle element)."""
-    N = pred.shape[0]
-    dev = pred.device
-    seg = frame if mask is None else torch.where(mask, frame, torch.full_like(frame, T))
-    nseg = T + 1
-    ones = torch.ones(N, device=dev)
-    counts = torch.zeros(nseg, device=dev).scatter_add_(0, seg, ones)
-    starts = torch.cumsum(counts, 0) - counts
-    pos = (starts + torch.div((counts - 1).clamp(min=0), 2, rounding_mode="floor")).long().clamp(max=N - 1)
-
-    def normalise(x):
-        i1 = torch.argsort(x.detach())
-        i2 = torch.argsort(seg[i1], stable=True)
-        order = i1[i2]                      # sorted by (segment, value)
-        med = x[order][pos]                 # [nseg]; gradient goes to the median element, as torch.median
-        dev_ = x - med[seg]
-        s = torch.zeros(nseg, device=dev).scatter_add(0, seg, dev_.abs()) / counts.clamp(min=1)
-        return dev_ / (s[seg] + 1e-10)
-
-    use = ((counts[seg] > 1) & (seg < T)).float()
-    sq = (normalise(pred) - normalise(gt)) ** 2
-    return (sq * use).sum() / use.sum()
+            return self._take(S, device), None
+        return self._take(S - S // 2 + 1, device), self._take(S // 2 + 1, device)
 
 
 def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_grad=False, dynamic=True):
@@ -365,8 +350,10 @@ class Trainer:
         early, late = it >= ups[0], it >= ups[3]           # gates of the mask terms (train.py:1338, 1349)
         gt_depth = -disp_t if rt == "ndc" else disp_t      # train.py:1645-1653
         to_depth = (lambda d: d) if rt == "ndc" else (lambda d: 1.0 / (d + 1e-6))
-        loss_d = 0.0
-        Ld = LossTerms()   # the elementwise terms of the dynamic group: one fused reduction (losses.py)
+        # every term of a group goes through ONE fused reduction (losses.LossTerms): the per-element terms directly, the
+        # other fused losses (per-frame depth loss, distortion loss, density L1) as their weighted values -- no scalar
+        # torch arithmetic (each `loss = loss + w * x` on 0-dim tensors is 2 launches forward and 2 backward)
+        Ld = LossTerms()
 
         def skewed(dyn):   # train.py:1349-1358: binary entropy of dynamicness^2 (late stages only)
             m2 = torch.clamp(dyn, min=1e-6, max=1.0 - 1e-6) ** 2
@@ -390,24 +377,24 @@ class Trainer:
         if early:
             Ld.add(0.1 * temp_disp_tv, "abs", outA[12], fg)                             # mask loss, :1338-1346
         if late:
-            loss_d = loss_d + 0.01 * skewed(outA[12])                                   # :1349-1364
+            Ld.add(0.01, "identity", skewed(outA[12]))                                  # :1349-1364
             Ld.add(0.01, "abs", outA[12])                                               # mask_L1_reg_loss, :1366
         xo, yo, wo = order_terms(outA)
         Ld.add(10.0, "square", xo, yo, w=wo, norm="weight")                             # order_loss, :1666-1683
-        loss_d = loss_d + c["monodepth_dynamic"] * temp * frame_median_depth_loss(to_depth(outA[9]), gt_depth, view, T)
+        Ld.add(1.0, "identity", frame_depth_loss(to_depth(outA[9]), gt_depth, view, T, coef=c["monodepth_dynamic"] * temp))
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters
         w_dist = c["dist_dynamic"] * (it / c["n_iters"])
-        if w_dist > 0:
-            loss_d = loss_d + w_dist * eff_distloss(outA[11], oA[8].detach(), 1.0 / S)
+        if w_dist > 0:   # mean over the rays of the per-ray loss (eff_distloss), weighted
+            Ld.add(w_dist, "identity", distloss_rays(outA[11], oA[8].detach(), 1.0 / S))
         # ---- pass B (second random time)
         _, oB, outB, _ = ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
         if late:
-            loss_d = loss_d + 0.01 * skewed(outB[12])                                   # :1248-1266
+            Ld.add(0.01, "identity", skewed(outB[12]))                                  # :1248-1266
             Ld.add(0.01, "abs", outB[12])                                               # novel_view_time_mask_loss, :1267
         xo, yo, wo = order_terms(outB)
         Ld.add(10.0, "square", xo, yo, w=wo, norm="weight")                             # novel_order_loss, :1277-1291
         if w_dist > 0:
-            loss_d = loss_d + w_dist * eff_distloss(outB[11], oB[8].detach(), 1.0 / S)
+            Ld.add(w_dist, "identity", distloss_rays(outB[11], oB[8].detach(), 1.0 / S))
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
         Ld.add(c["small_scene_flow_weight"], "abs", sf_f).add(c["small_scene_flow_weight"], "abs", sf_b)   # :1421-1424
@@ -430,25 +417,23 @@ class Trainer:
             _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
             Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
             if w_dist > 0:
-                loss_d = loss_d + w_dist * eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
+                Ld.add(w_dist, "identity", distloss_rays(outN[11], oN[8].detach(), 1.0 / S))
         # ---- pass E: static field with gradient, rays with gradient (pose / focal)
         oE, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
         m = (1.0 - fg)[:, None]
         Ls = LossTerms()
-        loss_s = 0.0
         Ls.add(1.0 / 3.0, "square", outE[4], rgb_t, w=m, norm="weight")                  # :1828-1832
-        if c["dist_static"] > 0:       # train.py:1841-1861
-            loss_s = loss_s + c["dist_static"] * (it / c["n_iters"]) * eff_distloss(outE[7], oE[8].detach(), 1.0 / S)
+        if c["dist_static"] > 0 and it > 0:       # train.py:1841-1861
+            Ls.add(c["dist_static"] * (it / c["n_iters"]), "identity", distloss_rays(outE[7], oE[8].detach(), 1.0 / S))
         if self.optimize_poses:
-            loss_s = loss_s + self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp_disp_tv,
-                                               temp_static, gt_depth, to_depth, Ls)
-        loss_s = loss_s + Ls.total()
-        loss_d = loss_d + Ld.total()
-        self.terms = (Ld, Ls)
+            self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp_disp_tv, temp_static, gt_depth,
+                             to_depth, Ls)
         # ---- factor-space regularisers (train.py:1718-1754, 1863-1885)
         if c["l1_weight"] > 0:
-            loss_d = loss_d + c["l1_weight"] * self.dy.density_L1()
-            loss_s = loss_s + c["l1_weight"] * self.st.density_L1()
+            Ld.add(c["l1_weight"], "identity", self.dy.density_L1())
+            Ls.add(c["l1_weight"], "identity", self.st.density_L1())
+        loss_s, loss_d = Ls.total(), Ld.total()
+        self.terms = (Ld, Ls)
         # TV (train.py:1735-1754, 1872-1885): the VALUE is NaN in the reference (line tensors have count_w = 0)
         # while the gradients are finite; only the gradient is taken (step(): TVLoss.accumulate_grad_)
         return loss_d, loss_s
@@ -460,7 +445,6 @@ class Trainer:
         S, rt, T, H, W = c["n_samples"], c["ray_type"], c["T"], c["H"], c["W"]
         ids, ts, fg = b["ids"], b["ts"], b["fg"]
         rng = self.rng
-        loss = 0.0
         weights_s, pts_ref_s, depth_s = outE[7], oE[3], outE[5]
         for sgn, flow_t, mask_t in ((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"])):
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]                       # live: allposes_refine_f / _b
@@ -475,8 +459,8 @@ class Trainer:
             _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, ray_type=rt)
             Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
-        loss = loss + c["monodepth_static"] * temp_static * frame_median_depth_loss(to_depth(depth_s), gt_depth, view, T,
-                                                                                    mask=fg < 0.5)
+        Ls.add(1.0, "identity", frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5,
+                                                 coef=c["monodepth_static"] * temp_static))
         # P3 / P4: disparity smoothness against the x+1 / y+1 pixel neighbours (train.py:2123-2311)
         col, row = grid[:, 0], grid[:, 1]
         inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)
@@ -485,7 +469,6 @@ class Trainer:
             rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
             _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
             Ls.add(50.0 * temp_disp_tv, "square", inv_d, 1.0 / torch.clamp(outN[5], min=1e-6))  # :2293-2305
-        return loss
 
     def step(self, shard=None):
         """One iteration on this rank's shard of the batch: forward of every pass, two-phase backward (static

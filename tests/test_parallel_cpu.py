@@ -140,28 +140,3 @@ def test_flat_exchange_zero1_equals_allreduce_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
-
-
-def test_frame_median_depth_loss_matches_reference_loop():
-    """step.frame_median_depth_loss (one segmented sort, no host sync) vs the reference's per-frame host
-    loop (train.py:797-807, 1636-1664, restated in the oracle): values and gradients, with empty frames,
-    single-ray frames (skipped), even / odd counts (lower median) and a mask."""
-    sys.path.insert(0, ROOT)
-    import importlib
-    S_ = importlib.import_module("robust-dynrf_amd.step")
-    from oracle import rodynrf_oracle as O
-    g = torch.Generator().manual_seed(3)
-    T, N = 12, 257
-    frame = torch.randint(0, T - 2, (N,), generator=g)          # frames T-2, T-1 stay empty
-    frame[:1] = T - 2                                           # one frame with a single ray: skipped
-    pred0 = torch.randn(N, generator=g) * 3
-    gt = torch.rand(N, generator=g)
-    for mask in (None, torch.rand(N, generator=g) < 0.6):
-        p1 = pred0.clone().requires_grad_(True)
-        p2 = pred0.clone().requires_grad_(True)
-        a = S_.frame_median_depth_loss(p1, gt, frame, T, mask=mask)
-        b = O.frame_depth_loss(p2, gt, frame, T, mask=mask)
-        assert torch.allclose(a, b, rtol=1e-5), (float(a), float(b))
-        a.backward()
-        b.backward()
-        assert torch.allclose(p1.grad, p2.grad, rtol=1e-4, atol=1e-7)
