@@ -69,6 +69,13 @@ static_assert(K1H_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE
 // argument block of the backward kernels
 // ------------------------------------------------------------------------------------------------
 
+// sample-major d(feature) record of the sorted scatter: per factor set 72 floats ordered
+// [XY: level 0 (16) | level 1 (16) | level 2 (16)] [XZ: 3 x 4] [YZ: 3 x 4]  (each XY level block is one 64-byte line)
+#define DFS_FLOATS 144
+RDRF_HD constexpr int dfs_off(int Q) {   // feature quad Q = 6 level + w  (w < 4: XY quad w, 4: XZ, 5: YZ)
+  return (Q % 6) < 4 ? (Q / 6) * 16 + 4 * (Q % 6) : ((Q % 6) == 4 ? 48 + 4 * (Q / 6) : 60 + 4 * (Q / 6));
+}
+
 struct BwdArgs {
   const float* rays;
   const float* ts;
@@ -90,6 +97,8 @@ struct BwdArgs {
   float* dxw_app;  // [N*S*3] coordinate grads arriving from the appearance phase
   float* dxn_app;  // [N*S*3]
   float* dtout;    // [N*32]
+  float* dfs;      // sorted scatter: d(features) of the density / blending heads SAMPLE-major, [N*S][2][72] in the
+                   // order [XY quads of level 0, 1, 2 | XZ quads | YZ quads] (nullptr: row layout for the ray-tile scatter)
   // outputs
   float* g_xyz;
   float* g_rays;   // [N][6] (+=): through dists (ray norm) and the static head's view directions
@@ -1185,6 +1194,138 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SORTED scatter of the density / blending gradients (dynamic field, ray path).
+//
+// With the reference initialiser the warp MLP moves the warped point by about a texel between consecutive samples of
+// a ray, so the ray-tile scatter above finds runs of 1-2 samples and pays ~13 M memory-side atomic requests per launch
+//  for gradient planes of a few MB.  Here the live samples are first grouped by the plane CELL they fall
+// into (one stable device-wide radix sort of (plane | level-0 cell) keys, rdrf_sort.hip), once per plane, and each
+// plane is scattered in that order by the SAME per-quad device functions: consecutive lanes now hold samples of the
+// same or the neighbouring cell (~20-40 samples per level-0 cell at the benchmark shapes), so the in-register run
+// reduction collapses them and a run of lanes issues one request per tap.  Per plane: XY = 16 samples x 4 quads per
+// wave step (gather_xy4_bwd), XZ / YZ = 32 samples, the half-waves taking the two bilinear columns (gather_zquad_bwd).
+// d(features) come from the sample-major records the heads kernel writes (BwdArgs::dfs); coordinate gradients are
+// accumulated into dxw by the three launches in turn (a sample is owned by one lane per launch: no atomics).
+// ------------------------------------------------------------------------------------------------
+struct SortKeyArgs {
+  const float* xw;
+  const uint8_t* valid;
+  const float* grows1;   // K1G_SM rows 3 / 4 hold g_fd / g_fb: a sample with both zero scatters nothing
+  int N, S;
+  int W[3], H[3];        // level-0 plane sizes
+  int kb;                // bits of the cell part of the key
+  unsigned* keys;        // [3][N*S]
+  int* counts;           // [3] live entries per plane
+};
+
+RDRF_D int cell_axis(float c, int L, bool& any) {
+  // level-0 tap index clamped to [-2, L]; `any`: some stride level has an in-range tap on this axis
+  const Tap1 t0 = tap1d(c, L), t1 = tap1d(c, (L + 1) >> 1), t2 = tap1d(c, (L + 3) >> 2);
+  any = t0.ok0 || t0.ok1 || t1.ok0 || t1.ok1 || t2.ok0 || t2.ok1;
+  return min(max(t0.i0, -2), L) + 2;
+}
+
+__global__ __launch_bounds__(256) void k_sort_keys(SortKeyArgs a) {
+  const int NS = a.N * a.S, tpr = (a.S + 31) >> 5;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NS; idx += gridDim.x * blockDim.x) {
+    bool live = false;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    {
+      const int n = idx / a.S, j = idx - n * a.S;
+      const float* sm = a.grows1 + ((size_t)(n * tpr + (j >> 5)) * sv::K1G_ROWS + sv::K1G_SM) * 32 + (j & 31);
+      live = a.valid[idx] != 0 && (sm[3 * 32] != 0.f || sm[4 * 32] != 0.f);
+      x0 = a.xw[(size_t)idx * 3 + 0]; x1 = a.xw[(size_t)idx * 3 + 1]; x2 = a.xw[(size_t)idx * 3 + 2];
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const float cx = p == 2 ? x1 : x0, cy = p == 0 ? x1 : x2;
+      bool ax, ay;
+      const int ix = cell_axis(cx, a.W[p], ax), iy = cell_axis(cy, a.H[p], ay);
+      const bool in = live && ax && ay;
+      const unsigned cell = in ? (unsigned)(iy * (a.W[p] + 3) + ix) : ((1u << a.kb) - 1u);
+      a.keys[(size_t)p * NS + idx] = ((unsigned)p << a.kb) | cell;
+    }
+  }
+}
+
+// live entries per plane = position of the first dropped key of the plane in the sorted array (a per-wave atomic
+// counter in k_sort_keys serialised 66 k same-address atomics: 240 us)
+__global__ void k_sort_counts(const unsigned* __restrict__ keys_sorted, int NS, int kb, int* __restrict__ counts) {
+  const int p = threadIdx.x;
+  if (p >= 3) return;
+  const unsigned drop = ((unsigned)p << kb) | ((1u << kb) - 1u);
+  const unsigned* k = keys_sorted + (size_t)p * NS;
+  int lo = 0, hi = NS;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (k[mid] < drop) lo = mid + 1; else hi = mid;
+  }
+  counts[p] = lo;
+}
+
+struct SortedScatterArgs {
+  RdrfVM vm[2], gvm[2];
+  int set_mask;            // bit k: set k has a gradient
+  const unsigned* order;   // [NS] sorted positions of THIS plane (value = plane * NS + sample index)
+  const int* count;        // live entries of this plane
+  unsigned base;           // plane * NS
+  const float* dfs;
+  const float* xw;
+  float* dxw;              // += coordinate gradients
+  int lds_bytes;
+};
+
+template <int PLANE>
+__global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) {
+  extern __shared__ float lacc[];
+  const int nl0 = lines_floats(a.vm[0]), nl1 = lines_floats(a.vm[1]);
+  const bool use_lacc = a.lds_bytes > 0;
+  if (use_lacc)
+    for (int i = threadIdx.x; i < nl0 + nl1; i += blockDim.x) lacc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31, q = lane >> 4, s16 = lane & 15;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = *a.count;
+  constexpr int SPT = PLANE == 0 ? 16 : 32;   // samples per wave step
+  const int ntiles = (count + SPT - 1) / SPT;
+  for (int t = blockIdx.x * nwaves + wave; t < ntiles; t += gridDim.x * nwaves) {
+    const int pos = t * SPT + (PLANE == 0 ? s16 : s);
+    const bool live = pos < count;
+    const int idx = live ? (int)(a.order[pos] - a.base) : 0;
+    const float x0 = a.xw[(size_t)idx * 3 + 0], x1 = a.xw[(size_t)idx * 3 + 1], x2 = a.xw[(size_t)idx * 3 + 2];
+    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+#pragma unroll 1
+    for (int set = 0; set < 2; ++set) {
+      if (!((a.set_mask >> set) & 1)) continue;
+      const LdsLines ll = make_lds_lines(use_lacc ? lacc + (set ? nl0 : 0) : nullptr, a.vm[set]);
+      const float* rec = a.dfs + (size_t)idx * DFS_FLOATS + set * 72;
+#pragma unroll 1
+      for (int lv = 0; lv < 3; ++lv) {
+        if constexpr (PLANE == 0) {
+          const f32x4 dq = live ? ld4(rec + lv * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+          gather_xy4_bwd<4, 1>(a.vm[set], a.gvm[set], lv, q, x0, x1, x2, dq, live, q == 0, dw0, dw1, dw2, ll);
+        } else {
+          const f32x4 dq = live ? ld4(rec + 48 + (PLANE - 1) * 12 + lv * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          gather_zquad_bwd<4, 1>(a.vm[set], a.gvm[set], lv * 6 + 4 + (PLANE - 1), h, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+        }
+      }
+    }
+    if constexpr (PLANE != 0) {   // both halves computed half of every coordinate gradient
+      dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
+    }
+    if (live && (PLANE == 0 ? q == 0 : h == 0)) {
+      float* d = a.dxw + (size_t)idx * 3;
+      d[0] += dw0; d[1] += dw1; d[2] += dw2;
+    }
+  }
+  if (use_lacc) {
+    __syncthreads();
+    flush_lds_lines(lacc, a.vm[0], a.gvm[0]);
+    flush_lds_lines(lacc + nl0, a.vm[1], a.gvm[1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dynamic field, density / blending / warp backward-data: wave per ray, 32-sample tiles, in two
 // phases around the scatter kernel:
 //   PHASE 0 (heads): weight/sigma/blending backward, density + blending head backward ->
@@ -1303,7 +1444,20 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
           mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_X0 : pkb::K1H_BLE1T_X0), lane);
           float dFh[48];
           acc_copy<3>(dFh, accF);
-          save_rows<48>(gb, head == 0 ? sv::K1G_DFD : sv::K1G_DFB, dFh, s, h);
+          if (!FEAT && a.dfs != nullptr) {
+            // sample-major record for the sorted scatter: this lane half holds the feature quads Q = 2 m + h
+            // (slots 4m..4m+3), Q = 6 level + {0..3: XY quad, 4: XZ, 5: YZ}; one 16-byte store per quad
+            if (act) {
+              float* rec = a.dfs + (size_t)idx * DFS_FLOATS + head * 72;
+#pragma unroll
+              for (int m = 0; m < 9; ++m) {
+                const int off = h ? dfs_off(2 * m + 1) : dfs_off(2 * m);
+                *reinterpret_cast<f32x4*>(rec + off) = f32x4{dFh[4 * m], dFh[4 * m + 1], dFh[4 * m + 2], dFh[4 * m + 3]};
+              }
+            }
+          } else {
+            save_rows<48>(gb, head == 0 ? sv::K1G_DFD : sv::K1G_DFB, dFh, s, h);
+          }
         }
         float dXh[32];
         acc_copy<2>(dXh, accX);
@@ -2090,12 +2244,19 @@ extern "C" size_t rdrf_workspace_bytes(int N, int S) {
   // backward: pack area + dz rows of both phases + coordinate-gradient buffers + d(tout)
   size_t bwd = (size_t)PACK_AREA_FLOATS * 4 + t1 * sv::K1G_ROWS * 32 * 4 + t3 * sv::K3G_ROWS * 32 * 4 +
                ns * 3 * 4 * 2 + (size_t)N * 32 * 4 + (1 << 14);
+  // sorted scatter: sample-major d(feature) records, keys in / out, sorted positions, counters, radix-sort scratch
+  bwd += ns * DFS_FLOATS * 4 + 3 * ns * 4 * 3 + 1024 + rdrf_sort_temp_bytes((unsigned)(3 * ns), 32) + (1 << 12);
   size_t sf = (size_t)PACK_AREA_FLOATS * 4 + t3 * sv::SFG_ROWS * 32 * 4 + (1 << 12);
   size_t m = fwd > bwd ? fwd : bwd;
   return m > sf ? m : sf;
 }
 
 struct BwdWs {
+  float* dfs;            // sorted scatter (dynamic field)
+  unsigned *keys_in, *keys_out, *order;
+  int* counts;
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
   float* pk;
   float* gf;       // static field: d(density feature) per sample, [N][ceil(S/32)*32]
   float* grows1;
@@ -2114,6 +2275,16 @@ static int carve_bwd(BwdWs& b, void* ws, size_t ws_bytes, int N, int S, int dyna
   b.dxn = dynamic ? c.take<float>(ns * 3) : nullptr;
   b.dtout = dynamic ? c.take<float>((size_t)N * 32) : nullptr;
   b.gf = dynamic ? nullptr : c.take<float>(t1 * 32);
+  b.dfs = nullptr;
+  if (dynamic) {
+    b.dfs = c.take<float>(ns * DFS_FLOATS);
+    b.keys_in = c.take<unsigned>(3 * ns);
+    b.keys_out = c.take<unsigned>(3 * ns);
+    b.order = c.take<unsigned>(3 * ns);
+    b.counts = c.take<int>(64);
+    b.sort_tmp_bytes = rdrf_sort_temp_bytes((unsigned)(3 * ns), 32);
+    b.sort_tmp = c.take<char>(b.sort_tmp_bytes);
+  }
   RDRF_CHECK(c.ok(), -3, "backward workspace too small: need %zu have %zu", c.off, ws_bytes);
   return 0;
 }
@@ -2156,6 +2327,85 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(threads), (size_t)sa.lds_bytes, stream, sa);
   rdrf_prof_end(name, stream);
   RDRF_HIP(hipGetLastError());
+  return 0;
+}
+
+// RDRF_SCATTER = ray (default) | sorted: how the density / blending gradients of the dynamic field's ray path reach the
+// factor planes -- the ray-tile kernel (k_scatter), or samples grouped by plane cell first (k_scatter_sorted: ~10x fewer
+// memory-side atomic requests).  Measured on MI355X at the Balloon1 stage-0 shape: sorted = 14 us keys +
+// 150 us radix sort + 340 / 140 / 140 us for the three planes = 816 us per launch against 695 us for the ray-tile kernel;
+// with its global atomics compiled out the sorted passes take 370 us, with the LDS line atomics out as well 174 us -- the
+// slow part is ds_add_f32 (~150 cycles per wave instruction), which grouping by plane cell scatters over random line
+// entries.  Kept as an option: it is the only path whose request count does not depend on the warp field's smoothness.
+static int scatter_mode() {
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("RDRF_SCATTER");
+    m = (e && !strcmp(e, "sorted")) ? 1 : 0;
+  }
+  return m;
+}
+
+template <int PLANE>
+static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStream_t stream) {
+  const long bytes = 4L * (lines_floats_host(sa.vm[0]) + lines_floats_host(sa.vm[1]));
+  sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
+  if (sa.lds_bytes > 48 * 1024)
+    RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_sorted<PLANE>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
+  const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;
+  const int wpb = threads / 64;
+  const long ntiles = (max_samples + (PLANE == 0 ? 15 : 31)) / (PLANE == 0 ? 16 : 32);
+  long g = (ntiles + wpb - 1) / wpb;
+  const long cap = threads == 512 ? 256 : 768;
+  g = g < 1 ? 1 : (g > cap ? cap : g);
+  static const char* names[3] = {"scatter_sorted_xy", "scatter_sorted_xz", "scatter_sorted_yz"};
+  rdrf_prof_begin(names[PLANE], stream);
+  hipLaunchKernelGGL(k_scatter_sorted<PLANE>, dim3((unsigned)g), dim3(threads), (size_t)sa.lds_bytes, stream, sa);
+  rdrf_prof_end(names[PLANE], stream);
+  RDRF_HIP(hipGetLastError());
+  return 0;
+}
+
+// density / blending scatter of the dynamic field's ray path, samples grouped by plane cell (see k_scatter_sorted)
+static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDynamicParams* P, const RdrfDynamicParams* G,
+                                      int set_mask, hipStream_t stream) {
+  const size_t ns = (size_t)a.N * a.S;
+  SortKeyArgs ka;
+  ka.xw = a.sp.xw; ka.valid = a.valid; ka.grows1 = b.grows1; ka.N = a.N; ka.S = a.S;
+  long maxcells = 0;
+  for (int p = 0; p < 3; ++p) {
+    ka.W[p] = P->density.W[p]; ka.H[p] = P->density.H[p];
+    RDRF_CHECK(P->blending.W[p] == ka.W[p] && P->blending.H[p] == ka.H[p], -1, "sorted scatter: density and blending planes differ in size");
+    const long c = (long)(ka.W[p] + 3) * (ka.H[p] + 3);
+    maxcells = c > maxcells ? c : maxcells;
+  }
+  int kb = 1;
+  while (((1L << kb) - 1) < maxcells) ++kb;
+  RDRF_CHECK(kb <= 29, -1, "sorted scatter: plane too large for 32-bit keys");
+  ka.kb = kb; ka.keys = b.keys_in; ka.counts = b.counts;
+  rdrf_prof_begin("scatter_sort", stream);
+  {
+    long g = ((long)ns + 255) / 256;
+    g = g > 2048 ? 2048 : g;
+    rdrf_prof_begin("sort_keys", stream);
+    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)g), dim3(256), 0, stream, ka);
+    rdrf_prof_end("sort_keys", stream);
+  }
+  int rc = rdrf_sort_positions(b.keys_in, b.keys_out, b.order, (unsigned)(3 * ns), kb + 2, b.sort_tmp, b.sort_tmp_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sort_counts, dim3(1), dim3(64), 0, stream, (const unsigned*)b.keys_out, (int)ns, kb, b.counts);
+  rdrf_prof_end("scatter_sort", stream);
+  RDRF_HIP(hipGetLastError());
+  SortedScatterArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;
+  sa.set_mask = set_mask; sa.dfs = b.dfs; sa.xw = a.sp.xw; sa.dxw = b.dxw;
+  for (int p = 0; p < 3; ++p) {
+    sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
+    rc = p == 0 ? launch_scatter_sorted<0>(sa, (long)ns, stream)
+                : (p == 1 ? launch_scatter_sorted<1>(sa, (long)ns, stream) : launch_scatter_sorted<2>(sa, (long)ns, stream));
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -2351,8 +2601,18 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   }
   {
     const Geo g = geo_for_units(N);
+    const int smode = scatter_mode();
+    a.dfs = smode != 0 ? b.dfs : nullptr;
     RDRF_LAUNCH("dyn_heads_bwd", (k_dyn_density_bwd<0, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
-    {
+    if (smode != 0) {
+      const int set_mask = ((g_sigma != nullptr || g_weight != nullptr) ? 1 : 0) | (g_blending != nullptr ? 2 : 0);
+      if (set_mask != 0) {
+        rdrf_prof_begin("scatter_dyn_density", stream);
+        rc = scatter_dyn_density_sorted(a, b, P, G, set_mask, stream);
+        rdrf_prof_end("scatter_dyn_density", stream);
+        if (rc) return rc;
+      }
+    } else {
       ScatterArgs sa;
       fill_scatter_common(sa, a);
       sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;

@@ -67,6 +67,11 @@ static inline bool vm_ok(const RdrfVM& v, int c0, int c1) {
   return v.C[0] == c0 && v.C[1] == c1 && v.C[2] == c1;
 }
 
+// device-wide stable key sort (rdrf_sort.hip)
+size_t rdrf_sort_temp_bytes(unsigned n, int bits);
+int rdrf_sort_positions(const unsigned* keys_in, unsigned* keys_out, unsigned* vals_out, unsigned n, int bits, void* temp,
+                        size_t temp_bytes, hipStream_t stream);
+
 // pack-job builders (rdrf_pack.hip)
 void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int mode,
               int nb, int kk, int dst);

@@ -26,6 +26,7 @@ extern "C" int rdrf_abi_version(void) { return RDRF_ABI_VERSION; }
 struct ProfRec {
   std::string name;
   hipEvent_t a, b;
+  bool closed;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -37,15 +38,23 @@ void rdrf_prof_begin(const char* name, hipStream_t s) {
   r.name = name;
   hipEventCreate(&r.a);
   hipEventCreate(&r.b);
-  hipEventRecord(r.a, s);
+  r.closed = false;
+  (void)hipEventRecord(r.a, s);
   g_prof.push_back(r);
 }
 void rdrf_prof_end(const char* name, hipStream_t s) {
   if (!g_prof_on) return;
-  hipEventRecord(g_prof.back().b, s);
+  // the innermost open record of this name (ranges may nest: a launch sequence and the kernels inside it)
+  for (size_t i = g_prof.size(); i-- > 0;)
+    if (!g_prof[i].closed && g_prof[i].name == name) {
+      (void)hipEventRecord(g_prof[i].b, s);
+      g_prof[i].closed = true;
+      return;
+    }
 }
 static void prof_drain() {
   for (auto& r : g_prof) {
+    if (!r.closed) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); continue; }
     hipEventSynchronize(r.b);
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
