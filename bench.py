@@ -308,6 +308,9 @@ def main():
     ap.add_argument("--rays-per-gpu", type=int, default=0, help="default: the config's batch size (4096; DAVIS 8192)")
     ap.add_argument("--dp", default="zero1", choices=["zero1", "allreduce"],
                     help="N > 1: reduce-scatter -> sharded Adam -> all-gather, or all-reduce + replicated Adam")
+    ap.add_argument("--dp-per-shard-stats", action="store_true",
+                    help="N > 1: normalise the masked-mean / per-frame depth losses by each rank's own batch statistics "
+                         "instead of all-reducing them (default: exact single-process statistics, SURVEY 8e)")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -341,7 +344,8 @@ def main():
     cfg = S_.scene_config(args.config, args.stage)
     rpg = args.rays_per_gpu or cfg["batch_size"]
     cfg["batch_size"] = rpg * world   # weak scaling: fixed rays per GPU
-    trainer = S_.Trainer(cfg, dev, weights=args.weights, dead_work=not args.exploit_liveness, dp_mode=args.dp)
+    trainer = S_.Trainer(cfg, dev, weights=args.weights, dead_work=not args.exploit_liveness, dp_mode=args.dp,
+                         dp_exact_stats=not args.dp_per_shard_stats)
     shard = (rank, world)
 
     dt, loss = timed_steps(trainer, shard, args.steps, args.warmup, world, dev)
@@ -367,6 +371,8 @@ def main():
                    "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if trainer.opt.ex.active else ""),
                    "ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                    "exchange_bytes_per_step": trainer.opt.nbytes_exchanged() if trainer.opt.ex.active else 0,
+                   "loss_statistics": ("whole batch (all-reduced mask sums, gathered per-frame depth statistics)"
+                                       if trainer._dp() is not None else "single process"),
                    "final_loss": loss_val,
                    "dead_dynamic_forwards": "skipped (dead work, SURVEY 3.1)" if args.exploit_liveness
                    else "executed (dead work the reference also computes)"},

@@ -356,6 +356,14 @@ typedef struct {
 } RdrfLossTerm;
 size_t rdrf_loss_terms_workspace_floats(int n);
 int rdrf_loss_terms_fwd(const RdrfLossTerm* terms, int n, float* partial, float* out, rdrf_stream_t stream);
+/* The same in two stages, for data-parallel runs that want the single-process normalisers (the reference's
+ * masked means divide by the mask sum of the WHOLE batch, train.py:1391-1394): stats[2k], stats[2k+1] = this rank's
+ * (sum_rows w rho, sum_rows w) of term k; the caller sums `stats` over the ranks (all-reduce) and passes both to finish,
+ * which normalises a masked mean by (sum over ranks of sum w) / world + 1e-8, so that the MEAN over ranks of the per-rank
+ * losses / gradients is exactly the single-process value.  rdrf_loss_terms_fwd == stats + finish(local, local, 1). */
+int rdrf_loss_terms_stats(const RdrfLossTerm* terms, int n, float* partial, float* stats, rdrf_stream_t stream);
+int rdrf_loss_terms_finish(const RdrfLossTerm* terms, int n, const float* stats_local, const float* stats_global, int world,
+                           float* out, rdrf_stream_t stream);
 int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float* out, const float* g_loss,
                         rdrf_stream_t stream);
 
@@ -369,13 +377,14 @@ int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float* out, cons
  * median's gradient spread evenly over the elements equal to it (ATen's evenly_distribute_backward).
  * pred, gt [N]; frame [N] int64 in [0, T); mask [N] uint8 or NULL (NULL: every ray is used).
  * out[0] = loss, out[1] = coef / sum_k n_k (the factor g_raw is to be multiplied with), out[2] = sum_k n_k.
- * ws: rdrf_frame_depth_loss_workspace_bytes(N, T).  N <= 16384. */
+ * ws: rdrf_frame_depth_loss_workspace_bytes(N, T).  N <= 32768 (the gathered batch of a data-parallel run included). */
 size_t rdrf_frame_depth_loss_workspace_bytes(int N, int T);
 int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, const int64_t* frame, const uint8_t* mask,
                               int N, int T, float coef, float* out, float* g_raw, void* ws, size_t ws_bytes,
                               rdrf_stream_t stream);
-/* g_pred[j] = g_loss[0] * out[1] * g_raw[j] */
-int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float* g_pred,
+/* g_pred[j] = g_loss[0] * out[1] * gscale * g_raw[j]   (gscale: world size when the batch was gathered over a
+ * data-parallel group whose exchange averages the per-rank gradients; 1 otherwise) */
+int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float gscale, float* g_pred,
                               rdrf_stream_t stream);
 
 /* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):

@@ -77,6 +77,7 @@ def _load():
     lib.rdrf_frame_depth_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_frame_depth_loss_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.rdrf_frame_depth_loss_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
     lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -100,6 +101,7 @@ SYMBOLS = [
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
     "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
     "rdrf_dense_l1_bwd", "rdrf_pack_floats", "rdrf_static_pack", "rdrf_dynamic_pack", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
+    "rdrf_loss_terms_stats", "rdrf_loss_terms_finish",
     "rdrf_frame_depth_loss_workspace_bytes", "rdrf_frame_depth_loss_fwd", "rdrf_frame_depth_loss_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",

@@ -44,17 +44,30 @@ __global__ __launch_bounds__(256) void k_loss_fwd(LossTermsK T, float* __restric
   }
 }
 
-// out[0] = total loss; out[1 + k] = coef_k / Z_k (the backward's per-term factor); out[1 + n + k] = term k's value
-__global__ __launch_bounds__(64) void k_loss_finish(LossTermsK T, const float* __restrict__ partial, float* __restrict__ out) {
+// stats[k] = (sum_rows w rho, sum_rows w) of term k on this rank: the numerators / denominators a data-parallel run
+// all-reduces when exact single-GPU loss normalisation is wanted (train.py:1391-1394)
+__global__ __launch_bounds__(64) void k_loss_stats(LossTermsK T, const float* __restrict__ partial, float* __restrict__ stats) {
+  const int k = threadIdx.x;
+  if (k >= T.n) return;
+  float s = 0.f, ws = 0.f;
+  for (int b = 0; b < LOSS_BLOCKS; ++b) { s += partial[((size_t)k * LOSS_BLOCKS + b) * 2]; ws += partial[((size_t)k * LOSS_BLOCKS + b) * 2 + 1]; }
+  stats[2 * k] = s;
+  stats[2 * k + 1] = ws;
+}
+
+// out[0] = total loss; out[1 + k] = coef_k / Z_k (the backward's per-term factor); out[1 + n + k] = term k's value.
+// local: this rank's (sum, weight sum) per term;  global: the same summed over `world` ranks (== local at world 1).
+// A masked mean is normalised by the GLOBAL weight sum: Z = (sum_ranks ws) / world + 1e-8, so that the mean over ranks of
+// the per-rank losses (the exchange's convention, optim.FlatAdam) is exactly the single-process masked mean.
+__global__ __launch_bounds__(64) void k_loss_finish(LossTermsK T, const float* __restrict__ local, const float* __restrict__ global,
+                                                    float world, float* __restrict__ out) {
   const int k = threadIdx.x;
   float val = 0.f;
   if (k < T.n) {
-    float s = 0.f, ws = 0.f;
-    for (int b = 0; b < LOSS_BLOCKS; ++b) { s += partial[((size_t)k * LOSS_BLOCKS + b) * 2]; ws += partial[((size_t)k * LOSS_BLOCKS + b) * 2 + 1]; }
     const RdrfLossTerm& t = T.t[k];
-    const float z = t.norm == RDRF_LOSS_NORM_WEIGHT ? ws + 1e-8f : (float)(t.rows * t.cols);
+    const float z = t.norm == RDRF_LOSS_NORM_WEIGHT ? global[2 * k + 1] / world + 1e-8f : (float)(t.rows * t.cols);
     const float scale = t.coef / z;
-    val = s * scale;
+    val = local[2 * k] * scale;
     out[1 + k] = scale;
     out[1 + T.n + k] = val;
   }
@@ -99,17 +112,36 @@ static int loss_pack(LossTermsK& T, const RdrfLossTerm* terms, int n) {
   return 0;
 }
 
-extern "C" size_t rdrf_loss_terms_workspace_floats(int n) { return (size_t)n * LOSS_BLOCKS * 2; }
+extern "C" size_t rdrf_loss_terms_workspace_floats(int n) { return (size_t)n * LOSS_BLOCKS * 2 + 2 * RDRF_MAX_LOSS_TERMS; }
 
-extern "C" int rdrf_loss_terms_fwd(const RdrfLossTerm* terms, int n, float* partial, float* out, rdrf_stream_t stream_) {
+extern "C" int rdrf_loss_terms_stats(const RdrfLossTerm* terms, int n, float* partial, float* stats, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   LossTermsK T;
   int rc = loss_pack(T, terms, n);
   if (rc) return rc;
-  RDRF_CHECK(partial && out, -1, "loss_terms_fwd: null workspace / output");
+  RDRF_CHECK(partial && stats, -1, "loss_terms_stats: null workspace / output");
   RDRF_LAUNCH("loss_terms", k_loss_fwd, dim3(LOSS_BLOCKS, n), dim3(256), stream, T, partial);
-  RDRF_LAUNCH("loss_terms", k_loss_finish, dim3(1), dim3(64), stream, T, (const float*)partial, out);
+  RDRF_LAUNCH("loss_terms", k_loss_stats, dim3(1), dim3(64), stream, T, (const float*)partial, stats);
   return 0;
+}
+
+extern "C" int rdrf_loss_terms_finish(const RdrfLossTerm* terms, int n, const float* stats_local, const float* stats_global,
+                                      int world, float* out, rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  LossTermsK T;
+  int rc = loss_pack(T, terms, n);
+  if (rc) return rc;
+  RDRF_CHECK(stats_local && stats_global && out && world >= 1, -1, "loss_terms_finish: bad arguments");
+  RDRF_LAUNCH("loss_terms", k_loss_finish, dim3(1), dim3(64), stream, T, stats_local, stats_global, (float)world, out);
+  return 0;
+}
+
+extern "C" int rdrf_loss_terms_fwd(const RdrfLossTerm* terms, int n, float* partial, float* out, rdrf_stream_t stream_) {
+  RDRF_CHECK(partial && out, -1, "loss_terms_fwd: null workspace / output");
+  float* stats = partial + (size_t)n * LOSS_BLOCKS * 2;   // tail of the workspace
+  int rc = rdrf_loss_terms_stats(terms, n, partial, stats, stream_);
+  if (rc) return rc;
+  return rdrf_loss_terms_finish(terms, n, stats, stats, 1, out, stream_);
 }
 
 extern "C" int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float* out, const float* g_loss,
@@ -128,7 +160,7 @@ extern "C" int rdrf_loss_terms_bwd(const RdrfLossTerm* terms, int n, const float
 // per-frame median-normalised depth loss (train.py:797-807, 1636-1664, 2097-2121): one workgroup per frame
 // ------------------------------------------------------------------------------------------------------------------
 #define FDL_THREADS 1024
-#define FDL_MAXN 16384
+#define FDL_MAXN 32768
 
 RDRF_D float block_sum(float v, float* red /*[16]*/) {   // deterministic tree; every thread gets the total
   v = wave_sum(v);
@@ -160,15 +192,23 @@ RDRF_D void bitonic_sort_lds(float* buf, int np2) {
 
 struct FdlStats { float med, inv; };   // median, 1 / (mean|x - med| + 1e-10)
 
-// median (lower middle element of the sorted values) and mean absolute deviation of x[ids[0..n)]
-RDRF_D FdlStats fdl_stats(const float* __restrict__ x, const int* ids, int n, float* sortbuf, float* red) {
+RDRF_D bool fdl_sel(const int64_t* __restrict__ frame, const uint8_t* __restrict__ mask, int i, int N, int k) {
+  return i < N && frame[i] == (int64_t)k && (mask == nullptr || mask[i] != 0);
+}
+
+// median (lower middle element of the sorted values) and mean absolute deviation of the n values x[i], i selected,
+// which the caller has compacted into sortbuf[0..n) (any order)
+RDRF_D FdlStats fdl_stats(const float* __restrict__ x, const int64_t* __restrict__ frame, const uint8_t* __restrict__ mask,
+                          int N, int k, int n, float* sortbuf, float* red) {
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) sortbuf[i] = i < n ? x[ids[i]] : INFINITY;
+  for (int i = n + threadIdx.x; i < np2; i += blockDim.x) sortbuf[i] = INFINITY;
   bitonic_sort_lds(sortbuf, np2);
   const float med = sortbuf[(n - 1) >> 1];
+  __syncthreads();
   float dev = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dev += fabsf(x[ids[i]] - med);
+  for (int i = threadIdx.x; i < N; i += blockDim.x)
+    if (fdl_sel(frame, mask, i, N, k)) dev += fabsf(x[i] - med);
   const float s = block_sum(dev, red) / (float)n;
   FdlStats r;
   r.med = med;
@@ -176,50 +216,57 @@ RDRF_D FdlStats fdl_stats(const float* __restrict__ x, const int* ids, int n, fl
   return r;
 }
 
+// compaction of the selected values of x into sortbuf, in ray order (ballot ranks: deterministic); returns the count
+RDRF_D int fdl_compact(const float* __restrict__ x, const int64_t* __restrict__ frame, const uint8_t* __restrict__ mask, int N,
+                       int k, float* sortbuf, int* wcount, int* base_s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) *base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < N; i0 += FDL_THREADS) {
+    const int i = i0 + threadIdx.x;
+    const bool sel = fdl_sel(frame, mask, i, N, k);
+    const unsigned long long b = __ballot(sel);
+    if (lane == 0) wcount[wave] = __popcll(b);
+    __syncthreads();
+    int off = *base_s;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (sel) sortbuf[off + __popcll(b & ((1ull << lane) - 1ull))] = x[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < FDL_THREADS / 64; ++w) t += wcount[w];
+      *base_s += t;
+    }
+    __syncthreads();
+  }
+  return *base_s;
+}
+
 __global__ __launch_bounds__(FDL_THREADS) void k_frame_depth_loss(const float* __restrict__ pred, const float* __restrict__ gt,
                                                                    const int64_t* __restrict__ frame,
                                                                    const uint8_t* __restrict__ mask, int N,
                                                                    float* __restrict__ g_raw, float* __restrict__ part /*[T][2]*/) {
   extern __shared__ float fdl_lds[];
-  float* sortbuf = fdl_lds;                       // [pow2(N)]
-  int* ids = (int*)(fdl_lds + FDL_MAXN);          // [N]
+  float* sortbuf = fdl_lds;                       // [pow2(n)]
   __shared__ float red[FDL_THREADS / 64];
   __shared__ int wcount[FDL_THREADS / 64];
   __shared__ int base_s;
   const int k = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // ---- select this frame's rays, in ray order (ballot compaction: deterministic)
-  if (threadIdx.x == 0) base_s = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < N; i0 += FDL_THREADS) {
-    const int i = i0 + threadIdx.x;
-    const bool sel = i < N && frame[i] == (int64_t)k && (mask == nullptr || mask[i] != 0);
-    const unsigned long long b = __ballot(sel);
-    if (lane == 0) wcount[wave] = __popcll(b);
-    __syncthreads();
-    int off = base_s;
-    for (int w = 0; w < wave; ++w) off += wcount[w];
-    if (sel) ids[off + __popcll(b & ((1ull << lane) - 1ull))] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int t = 0;
-      for (int w = 0; w < FDL_THREADS / 64; ++w) t += wcount[w];
-      base_s += t;
-    }
-    __syncthreads();
-  }
-  const int n = base_s;
+  const int n = fdl_compact(pred, frame, mask, N, k, sortbuf, wcount, &base_s);
   if (n <= 1) {   // train.py:1641 / 2103: frames with fewer than two rays are skipped
-    for (int i = threadIdx.x; i < n; i += blockDim.x) g_raw[ids[i]] = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+      if (fdl_sel(frame, mask, i, N, k)) g_raw[i] = 0.f;
     if (threadIdx.x == 0) { part[2 * k] = 0.f; part[2 * k + 1] = 0.f; }
     return;
   }
-  const FdlStats sp = fdl_stats(pred, ids, n, sortbuf, red);
-  const FdlStats sg = fdl_stats(gt, ids, n, sortbuf, red);
+  const FdlStats sp = fdl_stats(pred, frame, mask, N, k, n, sortbuf, red);
+  __syncthreads();
+  fdl_compact(gt, frame, mask, N, k, sortbuf, wcount, &base_s);
+  const FdlStats sg = fdl_stats(gt, frame, mask, N, k, n, sortbuf, red);
   // ---- loss and the three sums of the gradient:  A = sum a, B = sum a (p - m), Sg = sum sgn(p - m), c = #(p == m)
   float Ls = 0.f, A = 0.f, B = 0.f, Sg = 0.f, cnt = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int j = ids[i];
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    if (!fdl_sel(frame, mask, j, N, k)) continue;
     const float dp = pred[j] - sp.med;
     const float r = dp * sp.inv - (gt[j] - sg.med) * sg.inv;
     const float a = 2.0f * r;
@@ -232,8 +279,8 @@ __global__ __launch_bounds__(FDL_THREADS) void k_frame_depth_loss(const float* _
   Ls = block_sum(Ls, red); A = block_sum(A, red); B = block_sum(B, red); Sg = block_sum(Sg, red); cnt = block_sum(cnt, red);
   // d u_i / d p_j = (delta_ij - e_j) inv - (p_i - m) inv^2 ds/dp_j,   ds/dp_j = (sgn(p_j - m) - e_j Sg) / n,   e_j = [p_j == m] / c
   const float kB = B * sp.inv * sp.inv / (float)n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int j = ids[i];
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    if (!fdl_sel(frame, mask, j, N, k)) continue;
     const float dp = pred[j] - sp.med;
     const float r = dp * sp.inv - (gt[j] - sg.med) * sg.inv;
     const float e = dp == 0.f ? 1.0f / cnt : 0.f;
@@ -260,8 +307,9 @@ __global__ __launch_bounds__(256) void k_frame_depth_finish(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void k_frame_depth_bwd(const float* __restrict__ g_raw, const float* __restrict__ out,
-                                                         const float* __restrict__ g_loss, int N, float* __restrict__ g_pred) {
-  const float s = g_loss[0] * out[1];
+                                                         const float* __restrict__ g_loss, int N, float gscale,
+                                                         float* __restrict__ g_pred) {
+  const float s = g_loss[0] * out[1] * gscale;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) g_pred[i] = s * g_raw[i];
 }
 
@@ -275,10 +323,12 @@ extern "C" int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, con
   RDRF_CHECK(N >= 1 && N <= FDL_MAXN && T >= 1, -1, "frame_depth_loss: N must be in 1..%d (got %d), T >= 1 (got %d)", FDL_MAXN, N, T);
   RDRF_CHECK(ws_bytes >= rdrf_frame_depth_loss_workspace_bytes(N, T), -2, "frame_depth_loss: workspace too small");
   float* part = (float*)ws;
-  const size_t lds = (size_t)FDL_MAXN * 4 + (size_t)N * 4;
+  size_t np2 = 1;
+  while (np2 < (size_t)N) np2 <<= 1;
+  const size_t lds = np2 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    RDRF_HIP(hipFuncSetAttribute((const void*)k_frame_depth_loss, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FDL_MAXN * 4));
+    RDRF_HIP(hipFuncSetAttribute((const void*)k_frame_depth_loss, hipFuncAttributeMaxDynamicSharedMemorySize, FDL_MAXN * 4));
     attr_set = true;
   }
   rdrf_prof_begin("frame_depth_loss", stream);
@@ -290,10 +340,10 @@ extern "C" int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, con
   return 0;
 }
 
-extern "C" int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float* g_pred,
-                                         rdrf_stream_t stream_) {
+extern "C" int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float gscale,
+                                         float* g_pred, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RDRF_CHECK(g_raw && out && g_loss && g_pred && N >= 1, -1, "frame_depth_loss_bwd: bad arguments");
-  RDRF_LAUNCH("frame_depth_loss_bwd", k_frame_depth_bwd, dim3((N + 255) / 256), dim3(256), stream, g_raw, out, g_loss, N, g_pred);
+  RDRF_LAUNCH("frame_depth_loss_bwd", k_frame_depth_bwd, dim3((N + 255) / 256), dim3(256), stream, g_raw, out, g_loss, N, gscale, g_pred);
   return 0;
 }

@@ -14,7 +14,7 @@ _KINDS = {"square": SQUARE, "abs": ABS, "identity": IDENTITY}
 
 class _LossTermsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, meta, *tensors):
+    def forward(ctx, meta, reducer, *tensors):
         n = len(meta)
         dev = tensors[0].device
         arr = (L.RdrfLossTerm * n)()
@@ -31,7 +31,14 @@ class _LossTermsFn(torch.autograd.Function):
             t.rows, t.cols, t.kind, t.norm, t.ysign, t.coef = rows, cols, kind, norm, ysign, coef
         partial = torch.empty(int(L.lib.rdrf_loss_terms_workspace_floats(n)), device=dev)
         out = torch.empty(1 + 2 * n, device=dev)
-        L.check(L.lib.rdrf_loss_terms_fwd(arr, n, L.ptr(partial), L.ptr(out), L.stream_of(out)), "rdrf_loss_terms_fwd")
+        if reducer is None:
+            L.check(L.lib.rdrf_loss_terms_fwd(arr, n, L.ptr(partial), L.ptr(out), L.stream_of(out)), "rdrf_loss_terms_fwd")
+        else:   # data parallel, exact normalisers: all-reduce the per-term (sum, weight sum) pairs between the two stages
+            stats = torch.empty(2 * n, device=dev)
+            L.check(L.lib.rdrf_loss_terms_stats(arr, n, L.ptr(partial), L.ptr(stats), L.stream_of(out)), "rdrf_loss_terms_stats")
+            glob, world = reducer(stats)
+            L.check(L.lib.rdrf_loss_terms_finish(arr, n, L.ptr(stats), L.ptr(glob), int(world), L.ptr(out), L.stream_of(out)),
+                    "rdrf_loss_terms_finish")
         ctx.meta, ctx.held, ctx.out = meta, held, out
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
@@ -44,8 +51,8 @@ class _LossTermsFn(torch.autograd.Function):
         grads = []
         for k, (kind, norm, ysign, coef, rows, cols) in enumerate(meta):
             x, y, w = held[3 * k: 3 * k + 3]
-            need_x, need_y = ctx.needs_input_grad[1 + 3 * k], ctx.needs_input_grad[2 + 3 * k]
-            if ctx.needs_input_grad[3 + 3 * k]:
+            need_x, need_y = ctx.needs_input_grad[2 + 3 * k], ctx.needs_input_grad[3 + 3 * k]
+            if ctx.needs_input_grad[4 + 3 * k]:
                 raise L.RdrfError("LossTerms: the row weights are constants of the term (detach them)")
             gx = torch.empty_like(x) if need_x else None
             gy = torch.empty_like(y) if (need_y and y is not None) else None
@@ -56,12 +63,12 @@ class _LossTermsFn(torch.autograd.Function):
             grads += [gx, gy, None]
         g = L.f32c(g_loss.reshape(1))
         L.check(L.lib.rdrf_loss_terms_bwd(arr, n, L.ptr(out), L.ptr(g), L.stream_of(out)), "rdrf_loss_terms_bwd")
-        return (None, *grads)
+        return (None, None, *grads)
 
 
 class _FrameDepthLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, gt, frame, mask, T, coef):
+    def forward(ctx, pred, gt, frame, mask, T, coef, gscale):
         L.require_device(pred, gt, frame, mask)
         pred, gt = L.f32c(pred).reshape(-1), L.f32c(gt).reshape(-1)
         frame = frame.contiguous()
@@ -79,7 +86,7 @@ class _FrameDepthLossFn(torch.autograd.Function):
                                                 L.ptr(out), L.ptr(g_raw), L.ptr(ws), C.c_size_t(nb), L.stream_of(pred)),
                 "rdrf_frame_depth_loss_fwd")
         ctx.save_for_backward(g_raw, out)
-        ctx.shape = pred.shape
+        ctx.gscale = float(gscale)
         return out[0].clone()
 
     @staticmethod
@@ -87,11 +94,45 @@ class _FrameDepthLossFn(torch.autograd.Function):
         g_raw, out = ctx.saved_tensors
         g_pred = torch.empty_like(g_raw)
         L.check(L.lib.rdrf_frame_depth_loss_bwd(L.ptr(g_raw), L.ptr(out), L.ptr(L.f32c(g_loss.reshape(1))), g_raw.numel(),
-                                                L.ptr(g_pred), L.stream_of(g_raw)), "rdrf_frame_depth_loss_bwd")
-        return g_pred, None, None, None, None, None
+                                                C.c_float(ctx.gscale), L.ptr(g_pred), L.stream_of(g_raw)),
+                "rdrf_frame_depth_loss_bwd")
+        return g_pred, None, None, None, None, None, None
 
 
-def frame_depth_loss(pred, gt, frame, T, mask=None, coef=1.0):
+class _GatherRaysFn(torch.autograd.Function):
+    """all-gather of a per-ray tensor over the data-parallel group; backward keeps this rank's slice of the gradient
+    (every rank computes the same global loss from the gathered batch, so the other slices' gradients belong to the
+    other ranks)."""
+
+    @staticmethod
+    def forward(ctx, x, group, rank, world):
+        import torch.distributed as dist
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        ctx.rank, ctx.n = rank, x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.n: (ctx.rank + 1) * ctx.n].contiguous(), None, None, None
+
+
+def frame_depth_loss(pred, gt, frame, T, mask=None, coef=1.0, dp=None):
+    """dp = (group, rank, world): the statistics (per-frame medians, deviations, ray count) are those of the WHOLE
+    data-parallel batch -- pred / gt / frame / mask are all-gathered (a few KB), every rank evaluates the loss of the
+    gathered batch and keeps the gradient of its own rays, scaled by world for the exchange's mean-over-ranks."""
+    if dp is not None:
+        group, rank, world = dp
+        pred = _GatherRaysFn.apply(pred, group, rank, world)
+        gt = _GatherRaysFn.apply(gt, group, rank, world)
+        frame = _GatherRaysFn.apply(frame, group, rank, world)
+        mask = None if mask is None else _GatherRaysFn.apply(mask.to(torch.uint8), group, rank, world)
+        return _frame_depth_loss(pred, gt, frame, T, mask, coef, gscale=float(world))
+    return _frame_depth_loss(pred, gt, frame, T, mask, coef)
+
+
+def _frame_depth_loss(pred, gt, frame, T, mask=None, coef=1.0, gscale=1.0):
     """coef * (train.py:797-807 compute_depth_loss summed over the frames of the batch with more than one ray) / (number
     of rays used): the per-frame median-normalised monocular depth loss of train.py:1636-1664 (dynamic) and
     2097-2121 (static, mask = background rays).  pred, gt [N]; frame [N] in [0, T).  One workgroup per frame
@@ -99,13 +140,16 @@ def frame_depth_loss(pred, gt, frame, T, mask=None, coef=1.0):
     small sort / scatter / gather launches of a torch formulation, no host synchronisation."""
     if pred.shape != gt.shape or pred.numel() != frame.numel():
         raise L.RdrfError("frame_depth_loss: pred, gt, frame must have one entry per ray")
-    return _FrameDepthLossFn.apply(pred, gt, frame, mask, T, coef)
+    return _FrameDepthLossFn.apply(pred, gt, frame, mask, T, coef, gscale)
 
 
 class LossTerms:
     """terms = LossTerms(); terms.add(3.0, "square", rgb_map, rgb_gt); ...; loss = terms.total()"""
 
-    def __init__(self):
+    def __init__(self, reducer=None):
+        """reducer (data-parallel runs with exact loss statistics): callable(stats [2n] device tensor) -> (the same summed
+        over the ranks, world size); None = this process' own statistics (the single-process arithmetic)."""
+        self._reducer = reducer
         self._meta, self._tensors = [], []
         self.values = None   # after total(): per-term values (device tensor [n]), for logging
 
@@ -133,7 +177,7 @@ class LossTerms:
         return self
 
     def total(self):
-        loss, out = _LossTermsFn.apply(tuple(self._meta), *self._tensors)
+        loss, out = _LossTermsFn.apply(tuple(self._meta), self._reducer, *self._tensors)
         n = len(self._meta)
         self.values = out[1 + n:]
         return loss

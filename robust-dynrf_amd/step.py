@@ -263,10 +263,16 @@ def masked_mean(x, m):
 
 class Trainer:
     def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False,
-                 dp_mode="allreduce", lr_pose=3e-3):
+                 dp_mode="allreduce", lr_pose=3e-3, dp_exact_stats=False):
         """dead_work: also run the dynamic-field forward of passes E / P3 / P4, which the reference computes
-        although nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical."""
+        although nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical.
+        dp_exact_stats (data-parallel runs): the batch statistics of the losses -- the mask sums of the masked means
+        (train.py:1391-1394, 1522-1524, 1828-1832, 1277-1291) and the per-frame medians / deviations / ray counts of
+        the monocular depth losses (train.py:797-807) -- are those of the WHOLE batch (one all-reduce of ~30 pairs of
+        floats per loss group, one all-gather of the per-ray depths), so that an N-rank run optimises exactly the
+        single-process objective; off: per-shard statistics."""
         self.dead_work = dead_work
+        self.dp_exact_stats = bool(dp_exact_stats)
         self.cfg = cfg
         self.device = device
         self.st, self.dy = build_fields(cfg, device)
@@ -294,6 +300,24 @@ class Trainer:
         self.grad_flats = self.opt.grad_flats()
         self.last = {}
         self._c2w_fixed = None
+
+    # ---- data-parallel loss statistics ---------------------------------------------------------------
+    def _dp(self):
+        """(group, rank, world) when the exact-statistics exchange is on, else None"""
+        ex = self.opt.ex
+        return (self.opt._group, ex.rank, ex.world) if (self.dp_exact_stats and ex.active) else None
+
+    def _loss_terms(self):
+        dp = self._dp()
+        if dp is None:
+            return LossTerms()
+        import torch.distributed as dist
+
+        def reducer(stats):
+            g = stats.clone()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=dp[0])
+            return g, dp[2]
+        return LossTerms(reducer)
 
     # ---- geometry ----------------------------------------------------------------------------------
     def focal(self):
@@ -353,7 +377,7 @@ class Trainer:
         # every term of a group goes through ONE fused reduction (losses.LossTerms): the per-element terms directly, the
         # other fused losses (per-frame depth loss, distortion loss, density L1) as their weighted values -- no scalar
         # torch arithmetic (each `loss = loss + w * x` on 0-dim tensors is 2 launches forward and 2 backward)
-        Ld = LossTerms()
+        Ld = self._loss_terms()
 
         def skewed(dyn):   # train.py:1349-1358: binary entropy of dynamicness^2 (late stages only)
             m2 = torch.clamp(dyn, min=1e-6, max=1.0 - 1e-6) ** 2
@@ -371,7 +395,7 @@ class Trainer:
             oE, oEd, outE, xyzE = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
             if capture is not None:
                 capture["E"] = (oE, oEd, outE, xyzE)
-            Ls = LossTerms().add(1.0 / 3.0, "square", outE[4], rgb_t, w=(1.0 - fg)[:, None], norm="weight")
+            Ls = self._loss_terms().add(1.0 / 3.0, "square", outE[4], rgb_t, w=(1.0 - fg)[:, None], norm="weight")
             self.terms = (Ld, Ls)
             return Ld.total(), Ls.total()
         if early:
@@ -381,7 +405,8 @@ class Trainer:
             Ld.add(0.01, "abs", outA[12])                                               # mask_L1_reg_loss, :1366
         xo, yo, wo = order_terms(outA)
         Ld.add(10.0, "square", xo, yo, w=wo, norm="weight")                             # order_loss, :1666-1683
-        Ld.add(1.0, "identity", frame_depth_loss(to_depth(outA[9]), gt_depth, view, T, coef=c["monodepth_dynamic"] * temp))
+        Ld.add(1.0, "identity", frame_depth_loss(to_depth(outA[9]), gt_depth, view, T, coef=c["monodepth_dynamic"] * temp,
+                                                 dp=self._dp()))
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters
         w_dist = c["dist_dynamic"] * (it / c["n_iters"])
         if w_dist > 0:   # mean over the rays of the per-ray loss (eff_distloss), weighted
@@ -421,7 +446,7 @@ class Trainer:
         # ---- pass E: static field with gradient, rays with gradient (pose / focal)
         oE, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
         m = (1.0 - fg)[:, None]
-        Ls = LossTerms()
+        Ls = self._loss_terms()
         Ls.add(1.0 / 3.0, "square", outE[4], rgb_t, w=m, norm="weight")                  # :1828-1832
         if c["dist_static"] > 0 and it > 0:       # train.py:1841-1861
             Ls.add(c["dist_static"] * (it / c["n_iters"]), "identity", distloss_rays(outE[7], oE[8].detach(), 1.0 / S))
@@ -460,7 +485,7 @@ class Trainer:
             Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
         Ls.add(1.0, "identity", frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5,
-                                                 coef=c["monodepth_static"] * temp_static))
+                                                 coef=c["monodepth_static"] * temp_static, dp=self._dp()))
         # P3 / P4: disparity smoothness against the x+1 / y+1 pixel neighbours (train.py:2123-2311)
         col, row = grid[:, 0], grid[:, 1]
         inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)

@@ -101,7 +101,7 @@ def test_loss_terms_errors_are_loud():
         T.add(1.0, "abs", x)
 
 
-@pytest.mark.parametrize("N,T", [(257, 12), (4096, 12), (8192, 50)])
+@pytest.mark.parametrize("N,T", [(257, 12), (4096, 12), (8192, 50), (32768, 12)])
 def test_frame_depth_loss_matches_reference_loop(N, T):
     """rdrf_frame_depth_loss_fwd/bwd (one workgroup per frame: selection, LDS bitonic sort, loss + gradient in one pass)
     vs the reference's per-frame host loop (train.py:797-807, 1636-1664, 2097-2121, restated in the oracle with torch's
@@ -136,5 +136,5 @@ def test_frame_depth_loss_matches_reference_loop(N, T):
     c2 = LS.frame_depth_loss(p3, gt.cuda(), frame.cuda(), T)
     assert torch.equal(c1, c2)
     with pytest.raises(Exception):
-        LS.frame_depth_loss(torch.zeros(20000, device="cuda"), torch.zeros(20000, device="cuda"),
-                            torch.zeros(20000, dtype=torch.long, device="cuda"), T)
+        LS.frame_depth_loss(torch.zeros(40000, device="cuda"), torch.zeros(40000, device="cuda"),
+                            torch.zeros(40000, dtype=torch.long, device="cuda"), T)    # N <= 32768

@@ -32,30 +32,43 @@ def test_short_training_run_reduces_loss():
     assert last < 0.9 * first, (first, last)
 
 
-def test_trainer_sharded_step_matches_unsharded_gradients():
-    """rank-sharded steps (shard = (r, 2)) add up to the unsharded gradient of the per-ray losses:
-    the data-parallel exchange is a plain sum / mean of per-rank flat buffers."""
-    S_ = importlib.import_module("robust-dynrf_amd.step")
+def dp_check_cfg(S_):
     cfg = S_.balloon1_config("stage0")
     cfg.update(grid=[24, 26, 16], n_samples=40, batch_size=256, H=27, W=48, T=6)
     cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * 3.0 ** 0.5
-    cfg["monodepth_dynamic"] = 0.0   # the per-frame median normalisation is a statistic of the rank's own rays
-    dev = torch.device("cuda", 0)
+    return cfg
 
-    def grads(shard):
-        tr = S_.Trainer(cfg, dev)
-        tr.step(shard)
-        return [f.clone() for f in tr.grad_flats]
 
-    full = grads(None)
-    parts = [grads((r, 2)) for r in range(2)]
-    for k in range(2):
-        mean = 0.5 * (parts[0][k] + parts[1][k])
-        # every loss term is a mean over the rank's rays (equal shard sizes) or a rank-independent
-        # regulariser, so the mean over ranks is the full-batch gradient up to the mask-normalised
-        # terms (flow / disparity masks), which are per-shard statistics: compare loosely
-        rel = float((mean - full[k]).norm() / full[k].norm())
-        assert rel < 0.15, rel
+@pytest.mark.parametrize("mode", ["allreduce", "zero1"])
+def test_two_rank_step_with_exact_statistics_matches_single_process(mode, tmp_path):
+    """SURVEY 8e / train.py:1391-1394, 797-807: a 2-rank data-parallel step (ray-sharded, gloo, both ranks on this GPU)
+    with dp_exact_stats -- mask sums of the masked means all-reduced, per-frame depth statistics from the gathered batch
+    -- produces, after the exchange, the gradient of the SINGLE-process step on the whole batch (1e-3 relative L2 per
+    flat buffer: atomics order and the split reductions are the only differences); with per-shard statistics (the
+    default) the two differ visibly, which is what the option exists for."""
+    import os
+    import subprocess
+    import sys
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dp_check_cfg(S_)
+    torch.manual_seed(0)
+    tr = S_.Trainer(cfg, torch.device("cuda", 0))
+    tr.it = 9000
+    tr.step()
+    full = [f.detach().cpu().clone() for f in tr.grad_flats]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    rels = {}
+    for exact in ("1", "0"):
+        out = str(tmp_path / f"g{exact}.pt")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29711 + int(exact)), os.path.join(root, "tools", "dp_check.py"), out, exact, mode]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        got = torch.load(out)
+        rels[exact] = [float((a - b).norm() / b.norm()) for a, b in zip(got, full)]
+    assert max(rels["1"]) < 1e-3, rels
+    assert max(rels["0"]) > 3.0 * max(rels["1"]), rels    # per-shard statistics: a different objective
 
 
 @pytest.mark.parametrize("dp", ["zero1", "allreduce"])
