@@ -2330,20 +2330,22 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   return 0;
 }
 
-// RDRF_SCATTER = ray (default) | sorted: how the density / blending gradients of the dynamic field's ray path reach the
+// RDRF_SCATTER = auto (default) | ray | sorted: how the density / blending gradients of the dynamic field's ray path reach the
 // factor planes -- the ray-tile kernel (k_scatter), or samples grouped by plane cell first (k_scatter_sorted: ~10x fewer
 // memory-side atomic requests).  Measured on MI355X at the Balloon1 stage-0 shape: sorted = 14 us keys +
 // 150 us radix sort + 340 / 140 / 140 us for the three planes = 816 us per launch against 695 us for the ray-tile kernel;
 // with its global atomics compiled out the sorted passes take 370 us, with the LDS line atomics out as well 174 us -- the
 // slow part is ds_add_f32 (~150 cycles per wave instruction), which grouping by plane cell scatters over random line
 // entries.  Kept as an option: it is the only path whose request count does not depend on the warp field's smoothness.
-static int scatter_mode() {
-  static int m = -1;
+static int scatter_mode(size_t ns) {
+  static int m = -1;   // -1 unset, 0 ray, 1 sorted, 2 auto
   if (m < 0) {
     const char* e = getenv("RDRF_SCATTER");
-    m = (e && !strcmp(e, "sorted")) ? 1 : 0;
+    m = !e ? 2 : (!strcmp(e, "sorted") ? 1 : (!strcmp(e, "ray") ? 0 : 2));
   }
-  return m;
+  // auto: the sort is a fixed ~170 us per launch, the saving grows with the batch: measured break-even between the
+  // Balloon1 stage-0 shape (4096 x 115 samples: sorted 816 us vs ray 695 us) and the final shape (4096 x 270: 1562 vs 1802)
+  return m == 2 ? (ns >= (size_t)800000 ? 1 : 0) : m;
 }
 
 template <int PLANE>
@@ -2601,7 +2603,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   }
   {
     const Geo g = geo_for_units(N);
-    const int smode = scatter_mode();
+    const int smode = scatter_mode(ns);
     a.dfs = smode != 0 ? b.dfs : nullptr;
     RDRF_LAUNCH("dyn_heads_bwd", (k_dyn_density_bwd<0, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     if (smode != 0) {
