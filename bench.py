@@ -42,12 +42,13 @@ F_STAT_APP = 72752                         # basis + MLP_Fea head
 F_SCENE_FLOW = 21760
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak (~6.3 TB/s achievable)
+PEAK_L2_GBS = 34500.0                      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 L2_ATOMIC_REQ_PER_S = 20.8e9               # tools/ubench/atomics.hip: fp32 atomic requests the L2 retires
-PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r02")
+PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r03")
 
 
 def _profile_csv(name):
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         fn = os.path.join(ROOT, "profiles", f"{tag}_{name}.csv")
         if os.path.exists(fn):
             return fn, tag
@@ -104,7 +105,7 @@ def cpu_baseline(trainer, n_rays, repeats, dead_work=True):
 
     O.USE_GRID_SAMPLE = True   # the reference's own gather formulation (validated against the index-based one
     try:                       # in tests/test_oracle_golden.py): a fair CPU timing
-        one(max(32, n_rays // 4))
+        one(max(32, n_rays // (4 if repeats > 1 else 8)))
         times = sorted(one(n_rays) for _ in range(repeats))
     finally:
         O.USE_GRID_SAMPLE = False
@@ -112,8 +113,7 @@ def cpu_baseline(trainer, n_rays, repeats, dead_work=True):
     return dict(value=n_rays / med, unit="rays/s", cores=torch.get_num_threads(), kind="port", batch_rays=n_rays,
                 sample=f"oracle/rodynrf_oracle_step.py (torch-CPU restatement of the reference, grid_sample gathers): the "
                        f"same {cfg['name']} step on {n_rays} rays x {cfg['n_samples']} samples, median of {repeats} after "
-                       f"1 warm-up, {med:.1f} s per step; throughput grows with the batch (bench.py --cpu-rays 4096 "
-                       f"--cpu-repeats 5 for the configs[0] size)")
+                       f"1 warm-up, {med:.1f} s per step (the CPU throughput grows with the batch)")
 
 
 def self_spawn(args):
@@ -215,6 +215,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
             "bound": "hbm", "achieved": dw_b / (dw_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": dw_b / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": tr,
             "hbm_real": None if tr is None else tr / (dw_ms / dw_launch * 1e-3) / 1e9,
+            "source": {"traffic / hbm_real": f"profiles/{_profile_csv('pmc_fetch')[1]}_pmc_*.csv (committed, not re-measured here)"},
             "kernel": "k_dw2", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
             "launches_per_step": dw_launch, "algorithmic_bytes_per_launch": dw_b / dw_launch,
             "mfma": {"achieved_tflops": dw_f / (dw_ms * 1e-3) / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
@@ -240,9 +241,16 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         "l2_atomic_frac": None if (atom is None or not den_us) else atom / (den_us * 1e-6) / L2_ATOMIC_REQ_PER_S,
         "kernel": "k_scatter", "ms_per_step": sc_ms, "kernel_avg_us": sc_ms / sc_launch * 1e3,
         "launches_per_step": sc_launch, "algorithmic_bytes_per_launch": sc_b / sc_launch,
-        "limiter": "L2 fp32-atomic request rate (~20.8 G requests/s, tools/ubench/atomics.hip): `frac` is nominal "
-                   "(the bytes are cache resident); hbm_real = PMC bytes / time and l2_atomic_frac = atomic requests / "
-                   "time / 20.8 G/s of the density/blending launch are the physical figures"}
+        "bound_physical": "memory-side fp32 atomic requests + LDS line atomics (not HBM: the gathered bytes are cache resident)",
+        "frac_l2": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_L2_GBS,
+        "source": {"achieved / ms_per_step / kernel_avg_us": "HIP events, this run",
+                   "traffic / hbm_real / l2_atomic_frac": f"profiles/{_profile_csv('pmc_fetch')[1]}_*.csv (committed rocprofv3 PMC "
+                                                          "summaries of the same command, not re-measured in this run)"},
+        "limiter": "memory-side fp32-atomic request rate (~20.8 G requests/s, tools/ubench/atomics.hip) and ds_add_f32 "
+                   "(~150 cycles per wave instruction): `frac` is NOMINAL (algorithmic bytes / time against the HBM peak; "
+                   "the contract offers hbm | mfma); hbm_real = PMC bytes / time, l2_atomic_frac = atomic requests / "
+                   "time / 20.8 G/s of the density/blending launch and frac_l2 (against the 34.5 TB/s L2) are the "
+                   "physical figures"}
     dom_e, oth_e = (sc_entry, dw_entry) if (not dw_keys or sc_ms >= dw_ms) else (dw_entry, sc_entry)
     out = dict(dom_e)
     out.update({
@@ -317,6 +325,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-final-stage", action="store_true")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the W-sparse (app mask ~0.10) training / render leg")
+    ap.add_argument("--no-cpu-4096", action="store_true", help="skip the single 4096-ray CPU step (about one minute)")
     ap.add_argument("--render-chunk", type=int, default=0, help="rays per render call (default: a whole frame)")
     ap.add_argument("--exploit-liveness", action="store_true",
                     help="skip the dynamic-field forward of passes E / P3 / P4, dead work the reference computes "
@@ -412,8 +422,24 @@ def main():
             fin["render"] = render_leg(R, tr_f, cfg_f, dev, cfg_f["H"] * cfg_f["W"], frames=3)
         out["final_stage"] = fin
         del tr_f
+    if rank == 0 and world == 1 and not args.no_sparse and args.weights == "dense":
+        # SURVEY 8d W-sparse: the same step / render with trained-scene-like occupancy (app mask ~0.10 in both fields)
+        tr_s = S_.Trainer(dict(cfg), dev, weights="sparse", dead_work=not args.exploit_liveness)
+        dts, _ = timed_steps(tr_s, shard, max(10, args.steps // 5), 3, 1, dev)
+        sp = {"weights": "sparse", "value": rpg / dts, "unit": "rays/s", "ms_per_step": dts * 1e3, "steps": max(10, args.steps // 5)}
+        if not args.no_roofline:
+            rf = roofline(L, S_, tr_s, cfg, shard, rpg, dts * 1e3)
+            sp["fractions"] = rf["fractions"]
+            sp["kernel_ms_per_step"] = rf["kernel_ms_per_step"]
+        if not args.no_render:
+            sp["render"] = render_leg(R, tr_s, cfg, dev, cfg["H"] * cfg["W"], frames=3)
+        out["sparse_weights"] = sp
+        del tr_s
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, args.cpu_repeats, dead_work=not args.exploit_liveness)
+        if args.cpu_rays < 4096 and not args.no_cpu_4096:   # BASELINE.json configs[0]: "4k rays/iter, PyTorch-CPU": one timed step
+            out["cpu_baseline_4096"] = cpu_baseline(trainer, 4096, 1, dead_work=not args.exploit_liveness)
+            out["cpu_baseline_4096"]["note"] = "the configs[0] batch size; one timed step after a 512-ray warm-up"
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():

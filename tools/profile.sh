@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 RAW=/tmp/rawprof
 rm -rf $OUT $RAW; mkdir -p $OUT $RAW
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline $BENCH_EXTRA"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-sparse $BENCH_EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- python $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/fetch -o fetch -- python $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $RAW/write -o write -- python $ARGS > $OUT/write.log 2>&1

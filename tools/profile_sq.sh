@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/sq
 RAW=/tmp/rawsq
 rm -rf $OUT $RAW; mkdir -p $OUT $RAW
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-render $BENCH_EXTRA"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-render --no-sparse $BENCH_EXTRA"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
