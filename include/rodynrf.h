@@ -396,6 +396,17 @@ int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
                     const float* ts, int N, int S, float near, float far, float* rgb_map,
                     float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
 
+/* ---- deterministic debugging build (librodynrf_det.so = the same sources with -DRDRF_DETERMINISTIC) ----------------
+ * Every addition into a BOUND flat gradient buffer (scatter of the VM factors, line flushes, dW / bias sums, time
+ * branch) goes to a 64-bit fixed-point shadow of that buffer (value * 2^40, integer atomics: order-independent) and
+ * rdrf_det_finish adds the shadow into the fp32 gradients and clears it; the compaction lists of the appearance
+ * phases are sorted, LDS line accumulators are bypassed.  Result: bit-identical parameter gradients run after run,
+ * within fp32 rounding of the product build's.  rdrf_deterministic() = 1 in that build, 0 in the product build
+ * (where bind / finish fail).  slot 0 = static field, 1 = dynamic field; shadow: n 64-bit words, zero-initialised. */
+int rdrf_deterministic(void);
+int rdrf_det_bind(int slot, float* grad_base, size_t n, void* shadow_i64, rdrf_stream_t stream);
+int rdrf_det_finish(int slot, rdrf_stream_t stream);
+
 /* ---- kernel self-tests (used by tests/ only): run the MFMA layer chain on a synthetic input
  * and return it for comparison with a numpy matmul. x[M][K] -> y[M][OUT] = relu(x W^T + b). */
 int rdrf_selftest_mlp(const float* x, const float* w, const float* b, int M, int K, int OUT,

@@ -9,7 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf.so"))  # RDRF_LIB: A/B builds
+# RDRF_DETERMINISTIC=1: the debugging twin (fixed-point gradient accumulation, bit-reproducible gradients; csrc/Makefile)
+DETERMINISTIC = os.environ.get("RDRF_DETERMINISTIC", "0") == "1"
+LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf_det.so" if DETERMINISTIC else "librodynrf.so"))  # RDRF_LIB: A/B builds
 
 ABI_VERSION = 3   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
 
@@ -81,6 +83,10 @@ def _load():
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
     lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.rdrf_det_bind.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.rdrf_det_finish.argtypes = [C.c_int, C.c_void_p]
+    if DETERMINISTIC and not lib.rdrf_deterministic():
+        raise ImportError(f"RDRF_DETERMINISTIC=1 but {LIB_PATH} is the product build")
     if lib.rdrf_abi_version() != ABI_VERSION:
         raise ImportError("librodynrf.so ABI version mismatch")
     return lib
@@ -101,7 +107,7 @@ SYMBOLS = [
     "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
     "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
     "rdrf_dense_l1_bwd", "rdrf_pack_floats", "rdrf_static_pack", "rdrf_dynamic_pack", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
-    "rdrf_loss_terms_stats", "rdrf_loss_terms_finish",
+    "rdrf_loss_terms_stats", "rdrf_loss_terms_finish", "rdrf_deterministic", "rdrf_det_bind", "rdrf_det_finish",
     "rdrf_frame_depth_loss_workspace_bytes", "rdrf_frame_depth_loss_fwd", "rdrf_frame_depth_loss_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",

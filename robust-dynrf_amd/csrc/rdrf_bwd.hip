@@ -17,7 +17,7 @@
 #ifdef RDRF_NO_BIAS_ATOMICS
 #define BIAS_ATOMIC(p, v) ((void)0)
 #else
-#define BIAS_ATOMIC(p, v) atomicAdd(p, v)
+#define BIAS_ATOMIC(p, v) grad_add(p, v)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -154,7 +154,7 @@ RDRF_D void atomic_quad_k(float* base, unsigned off, float val, int c) {
   constexpr int QP = K * 0x55;  // quad_perm:[K,K,K,K]
   const unsigned o = (unsigned)dppi<QP>((int)off);
   if (__ballot(o != 0xffffffffu) == 0ull) return;
-  if (o != 0xffffffffu) atomicAdd(base + (size_t)o + c, val);
+  if (o != 0xffffffffu) grad_add(base + (size_t)o + c, val);
 }
 RDRF_D void atomic_add4(float* p_base, size_t p_off, f32x4 v, bool ok) {
 #if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOGLOBAL)
@@ -289,7 +289,7 @@ RDRF_D void flush_lds_lines(const float* acc, const RdrfVM& vm, const RdrfVM& gv
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const int l = i / C, c = i - l * C;
       const float v = acc[base + l * st + c];
-      if (v != 0.f) atomicAdd(gvm.line[li] + i, v);
+      if (v != 0.f) grad_add(gvm.line[li] + i, v);
     }
     base += vm.L[li] * st;
   }
@@ -1619,23 +1619,23 @@ __global__ __launch_bounds__(128) void k_time_branch_bwd(const float* __restrict
     const int o = e / 64, k = e - o * 64;
     float a = 0.f;
     for (int rr = 0; rr < TB_RPB; ++rr) a = fmaf(s_dz2[rr][o], s_h[rr][k], a);
-    atomicAdd(g_l2w + e, a);
+    grad_add(g_l2w + e, a);
   }
   for (int e = tid; e < 64 * 17; e += 128) {
     const int k = e / 17, i = e - k * 17;
     float a = 0.f;
     for (int rr = 0; rr < TB_RPB; ++rr) a = fmaf(s_dz1[rr][k], s_tin[rr][i], a);
-    atomicAdd(g_l1w + e, a);
+    grad_add(g_l1w + e, a);
   }
   if (tid < 30) {
     float a = 0.f;
     for (int rr = 0; rr < TB_RPB; ++rr) a += s_dz2[rr][tid];
-    atomicAdd(g_l2b + tid, a);
+    grad_add(g_l2b + tid, a);
   }
   if (tid < 64) {
     float a = 0.f;
     for (int rr = 0; rr < TB_RPB; ++rr) a += s_dz1[rr][tid];
-    atomicAdd(g_l1b + tid, a);
+    grad_add(g_l1b + tid, a);
   }
 }
 
@@ -1855,14 +1855,14 @@ __global__ __launch_bounds__(256, 2) void k_dw(DwJobs jobs) {
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int orow = bo * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h - J.out_row0;
-        if (col >= 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.dW + (size_t)orow * J.ld + col, acc[b][rr]);
+        if (col >= 0 && orow >= 0 && orow < J.out_dim) grad_add(J.dW + (size_t)orow * J.ld + col, acc[b][rr]);
       }
     }
   }
   if (grp == 0 && J.db != nullptr) {
     bsum += __shfl_xor(bsum, 32, 64);
     const int orow = bo * 32 + li - J.out_row0;
-    if (h == 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.db + orow, bsum);
+    if (h == 0 && orow >= 0 && orow < J.out_dim) grad_add(J.db + orow, bsum);
   }
 }
 
@@ -2045,12 +2045,12 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int orow = pr.bo * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h - J.out_row0;
-        if (col >= 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.dW + (size_t)orow * J.ld + col, acc[p][rr]);
+        if (col >= 0 && orow >= 0 && orow < J.out_dim) grad_add(J.dW + (size_t)orow * J.ld + col, acc[p][rr]);
       }
       if (pr.bias && J.db != nullptr) {
         const float b = bsum[p] + __shfl_xor(bsum[p], 32, 64);
         const int orow = pr.bo * 32 + li - J.out_row0;
-        if (h == 0 && orow >= 0 && orow < J.out_dim) atomicAdd(J.db + orow, b);
+        if (h == 0 && orow >= 0 && orow < J.out_dim) grad_add(J.db + orow, b);
       }
     }
   }
@@ -2315,6 +2315,9 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
     return rc ? rc : launch_scatter(name, kern, s1, ntiles, stream);
   }
   sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
+#ifdef RDRF_DETERMINISTIC
+  sa.lds_bytes = 0;   // the fp32 LDS accumulators add in wave-arrival order: the line gradients go straight to the shadow
+#endif
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
   const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;   // one big workgroup per CU vs. two or three
@@ -2352,6 +2355,9 @@ template <int PLANE>
 static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStream_t stream) {
   const long bytes = 4L * (lines_floats_host(sa.vm[0]) + lines_floats_host(sa.vm[1]));
   sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
+#ifdef RDRF_DETERMINISTIC
+  sa.lds_bytes = 0;
+#endif
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_sorted<PLANE>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
   const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;
@@ -2969,4 +2975,62 @@ extern "C" int rdrf_dynamic_pack(const RdrfDynamicParams* P, int backward, float
   PackJobs J;
   if (backward) dyn_pack_jobs_bwd(J, P); else dyn_pack_jobs_fwd(J, P);
   return pack_launch(J, image, (hipStream_t)stream_);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// deterministic build: bind a field's flat gradient buffer to its fixed-point shadow, fold it back
+// ------------------------------------------------------------------------------------------------
+#ifdef RDRF_DETERMINISTIC
+int det_bind_optim(int slot, const float* base, size_t n, unsigned long long* shadow, hipStream_t stream);   // rdrf_optim.hip
+static DetMap g_det_host[2];
+__global__ void k_det_finish(float* __restrict__ g, unsigned long long* __restrict__ shadow, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const long long v = (long long)shadow[i];
+    if (v != 0) {
+      g[i] += (float)((double)v * (1.0 / (double)RDRF_DET_SCALE));
+      shadow[i] = 0ull;
+    }
+  }
+}
+#endif
+
+extern "C" int rdrf_deterministic(void) {
+#ifdef RDRF_DETERMINISTIC
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+extern "C" int rdrf_det_bind(int slot, float* grad_base, size_t n, void* shadow_i64, rdrf_stream_t stream_) {
+#ifdef RDRF_DETERMINISTIC
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK(slot == 0 || slot == 1, -1, "det_bind: slot 0 (static field) or 1 (dynamic field)");
+  g_det_host[slot].base = grad_base;
+  g_det_host[slot].n = n;
+  g_det_host[slot].shadow = (unsigned long long*)shadow_i64;
+  RDRF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_det), &g_det_host[slot], sizeof(DetMap), slot * sizeof(DetMap),
+                                  hipMemcpyHostToDevice, stream));
+  return det_bind_optim(slot, grad_base, n, (unsigned long long*)shadow_i64, stream);
+#else
+  (void)slot; (void)grad_base; (void)n; (void)shadow_i64; (void)stream_;
+  rdrf_set_error("det_bind: this library is the product build (fp32 atomics); load librodynrf_det.so (RDRF_DETERMINISTIC=1)");
+  return -1;
+#endif
+}
+
+extern "C" int rdrf_det_finish(int slot, rdrf_stream_t stream_) {
+#ifdef RDRF_DETERMINISTIC
+  hipStream_t stream = (hipStream_t)stream_;
+  RDRF_CHECK((slot == 0 || slot == 1) && g_det_host[slot].shadow != nullptr, -1, "det_finish: slot %d is not bound", slot);
+  const size_t n = g_det_host[slot].n;
+  RDRF_LAUNCH("det_finish", k_det_finish, dim3((unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024)), dim3(256), stream,
+              (float*)g_det_host[slot].base, g_det_host[slot].shadow, n);
+  return 0;
+#else
+  (void)slot; (void)stream_;
+  rdrf_set_error("det_finish: product build");
+  return -1;
+#endif
 }

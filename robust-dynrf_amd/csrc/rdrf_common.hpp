@@ -30,6 +30,42 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RDRF_D __device__ __forceinline__
 
 // ---------------------------------------------------------------------------------------------
+// gradient accumulation.  Product build: hardware fp32 atomics (the order of the additions, and with it the last
+// bits of every gradient, varies from run to run).  Deterministic build (-DRDRF_DETERMINISTIC -> librodynrf_det.so,
+// selected with RDRF_DETERMINISTIC=1): every addition into a field's flat gradient buffer goes to a 64-bit FIXED-POINT
+// shadow of that buffer (value * 2^40 rounded to an integer; integer addition is associative, so the sum does not
+// depend on the order) and rdrf_det_finish folds the shadow into the fp32 gradients once: bit-reproducible gradients
+// to diff a suspected race against (SURVEY.md 5 / 7 hard part 1).  Additions outside the bound buffers (pose / ray
+// gradients) stay fp32 atomics.
+// ---------------------------------------------------------------------------------------------
+#ifdef RDRF_DETERMINISTIC
+struct DetMap {
+  const float* base;
+  unsigned long long n;
+  unsigned long long* shadow;
+};
+// one copy per translation unit, written only from the host (rdrf_det_bind): `volatile` keeps the optimiser from
+// treating the never-stored-to internal global as a zero constant and folding every lookup away
+static __device__ volatile DetMap g_det[2];
+#define RDRF_DET_SCALE 1099511627776.0f   // 2^40: quantum 9.1e-13, range +-8.4e6
+RDRF_D void grad_add(float* p, float v) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float* base = g_det[k].base;
+    unsigned long long* shadow = g_det[k].shadow;
+    const unsigned long long n = g_det[k].n;
+    if (shadow != nullptr && p >= base && (unsigned long long)(p - base) < n) {
+      atomicAdd(shadow + (p - base), (unsigned long long)__float2ll_rn(v * RDRF_DET_SCALE));
+      return;
+    }
+  }
+  atomicAdd(p, v);
+}
+#else
+RDRF_D void grad_add(float* p, float v) { atomicAdd(p, v); }
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // canonical layout
 // ---------------------------------------------------------------------------------------------
 RDRF_HD int elem_of(int kk, int h) { return ((kk >> 2) << 3) + (h << 2) + (kk & 3); }

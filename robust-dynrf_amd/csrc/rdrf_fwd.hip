@@ -703,7 +703,13 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   }
   RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
   RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
+#ifdef RDRF_DETERMINISTIC
+  RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
+#endif
   RDRF_LAUNCH("static_density", k_static_density<false>, dim3(N), dim3(64), stream, a, w);
+#ifdef RDRF_DETERMINISTIC
+  { int rc_ = rdrf_sort_ints_inplace(a.list, (unsigned)((size_t)N * S), stream); if (rc_) return rc_; }   // append order depends on wave timing
+#endif
   const Geo g = geo_for_tiles(N, S);
   if (cfg->static_head == RDRF_HEAD_MLP_FEA)
     RDRF_LAUNCH("static_app", (k_static_app<RDRF_HEAD_MLP_FEA, false>), dim3(g.grid), dim3(g.block), stream,
@@ -745,7 +751,13 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
   RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout);
   const Geo g1 = geo_for_units(N), g3 = geo_for_tiles(N, S);
+#ifdef RDRF_DETERMINISTIC
+  RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
+#endif
   RDRF_LAUNCH("dyn_density", k_dyn_density<false>, dim3(g1.grid), dim3(g1.block), stream, a, w);
+#ifdef RDRF_DETERMINISTIC
+  { int rc_ = rdrf_sort_ints_inplace(a.list, (unsigned)((size_t)N * S), stream); if (rc_) return rc_; }
+#endif
   RDRF_LAUNCH("dyn_app", k_dyn_app<false>, dim3(g3.grid), dim3(g3.block), stream, a, w);
   return 0;
 }

@@ -72,6 +72,8 @@ size_t rdrf_sort_temp_bytes(unsigned n, int bits);
 int rdrf_sort_positions(const unsigned* keys_in, unsigned* keys_out, unsigned* vals_out, unsigned n, int bits, void* temp,
                         size_t temp_bytes, hipStream_t stream);
 
+int rdrf_sort_ints_inplace(int* data, unsigned n, hipStream_t stream);   // deterministic build only
+
 // pack-job builders (rdrf_pack.hip)
 void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int mode,
               int nb, int kk, int dst);

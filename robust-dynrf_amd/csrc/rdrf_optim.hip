@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_dense_l1(L1Args a) {
       float r = gl_a[c];
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) r += __shfl_xor(r, d, 32);
-      if ((threadIdx.x & 31) == 0 && v < V) atomicAdd(a.gvm.line[1] + (size_t)v * 4 + c, r);
+      if ((threadIdx.x & 31) == 0 && v < V) grad_add(a.gvm.line[1] + (size_t)v * 4 + c, r);
     }
     __shared__ float cols[8][32][4];
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_dense_l1(L1Args a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) r += cols[k][uu][c];
       const int ug = blockIdx.x * 32 + uu;
-      if (ug < U) atomicAdd(a.gvm.line[2] + (size_t)ug * 4 + c, r);
+      if (ug < U) grad_add(a.gvm.line[2] + (size_t)ug * 4 + c, r);
     }
   } else if (SWEEP == 1) {
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_dense_l1(L1Args a) {
       float r = gl_a[c];
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) r += __shfl_xor(r, d, 32);
-      if ((threadIdx.x & 31) == 0 && v < V) atomicAdd(a.gvm.line[0] + (size_t)v * 16 + c, r);
+      if ((threadIdx.x & 31) == 0 && v < V) grad_add(a.gvm.line[0] + (size_t)v * 16 + c, r);
     }
   }
 }
@@ -321,3 +321,13 @@ extern "C" int rdrf_dense_l1_bwd(const RdrfVM* vm, const RdrfVM* gvm, int act, f
   RDRF_LAUNCH("dense_l1_bwd", (k_dense_l1<2, 1>), dim3((Y + 31) / 32, (Z + 7) / 8), dim3(256), stream, a);
   return 0;
 }
+
+
+#ifdef RDRF_DETERMINISTIC
+int det_bind_optim(int slot, const float* base, size_t n, unsigned long long* shadow, hipStream_t stream) {
+  static DetMap host[2];
+  host[slot].base = base; host[slot].n = n; host[slot].shadow = shadow;
+  RDRF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_det), &host[slot], sizeof(DetMap), slot * sizeof(DetMap), hipMemcpyHostToDevice, stream));
+  return 0;
+}
+#endif

@@ -31,3 +31,24 @@ int rdrf_sort_positions(const unsigned* keys_in, unsigned* keys_out, unsigned* v
   RDRF_HIP(rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, vin, vals_out, n, 0, (unsigned)bits, stream));
   return 0;
 }
+
+
+// deterministic build: ascending in-place sort of an int list (the app-mask compaction lists, whose append order depends on
+// wave timing).  Scratch is a lazily grown device allocation owned by this debugging build.
+int rdrf_sort_ints_inplace(int* data, unsigned n, hipStream_t stream) {
+  static void* scratch = nullptr;
+  static size_t scratch_bytes = 0;
+  size_t need = 0;
+  RDRF_HIP(rocprim::radix_sort_keys(nullptr, need, (const unsigned*)nullptr, (unsigned*)nullptr, n, 0, 32, stream));
+  const size_t total = need + (size_t)n * 4 + 512;
+  if (total > scratch_bytes) {
+    if (scratch) RDRF_HIP(hipFree(scratch));
+    RDRF_HIP(hipMalloc(&scratch, total));
+    scratch_bytes = total;
+  }
+  unsigned* out = (unsigned*)scratch;
+  void* tmp = (char*)scratch + (((size_t)n * 4 + 255) & ~(size_t)255);
+  RDRF_HIP(rocprim::radix_sort_keys(tmp, need, (const unsigned*)data, out, n, 0, 32, stream));
+  RDRF_HIP(hipMemcpyAsync(data, out, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  return 0;
+}

@@ -256,6 +256,7 @@ class _StaticFn(torch.autograd.Function):
         N, S = z.shape
         dev = z.device
         fused = ctx.field.fused_grad
+        ctx.field._det_bind()
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G = _static_struct(grads)
         P = _static_struct(params)
@@ -317,6 +318,7 @@ class _DynamicFn(torch.autograd.Function):
         N, S = z.shape
         dev = z.device
         fused = ctx.field.fused_grad
+        ctx.field._det_bind()
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G = _dynamic_struct(grads)
         P = _dynamic_struct(params)
@@ -369,6 +371,7 @@ class _SceneFlowFn(torch.autograd.Function):
             raise L.RdrfError("get_forward_backward_scene_flow: backward called twice (retain_graph is not supported)")
         N, S, _ = pts.shape
         fused = ctx.field.fused_grad
+        ctx.field._det_bind()
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G = _dynamic_struct(grads)
         P = _dynamic_struct(params)
@@ -430,6 +433,7 @@ class _StaticFeatFn(torch.autograd.Function):
             raise L.RdrfError("compute_*: backward called twice (the saved activations were released)")
         M, dev = xn.shape[0], xn.device
         fused = ctx.field.fused_grad
+        ctx.field._det_bind()
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         if g_dens is None and g_app is None:
             return (None,) * (4 + len(params))
@@ -487,6 +491,7 @@ class _DynFeatFn(torch.autograd.Function):
             raise L.RdrfError("compute_*: backward called twice (the saved activations were released)")
         M, dev = x.shape[0], x.device
         fused = ctx.field.fused_grad
+        ctx.field._det_bind()
         grads = ctx.field.fused_grads() if fused else [torch.zeros_like(p) for p in params]
         G, P = _dynamic_struct(grads), _dynamic_struct(params)
         _attach_packed(ctx.field, P, params, True, True)
@@ -716,7 +721,28 @@ class TensorBase(nn.Module):
                         v.copy_(p.grad)
                     p.grad = v
             self._gflat, self._gviews = flat, views
+            self._det_shadow = torch.zeros(total, dtype=torch.int64, device=flat.device) if L.DETERMINISTIC else None
         return views
+
+    # ---- deterministic debugging build (RDRF_DETERMINISTIC=1, librodynrf_det.so) -----------------------------------------
+    def _det_bind(self):
+        """bind this field's flat gradient buffer to its fixed-point shadow for the backward about to run"""
+        if not L.DETERMINISTIC:
+            return
+        if not self.fused_grad:
+            raise L.RdrfError("RDRF_DETERMINISTIC=1 needs the fused gradient buffers (field.fused_grad = True): only additions "
+                              "into a bound flat buffer are order-independent")
+        self.fused_grads()
+        L.check(L.lib.rdrf_det_bind(1 if isinstance(self, TensorVMSplit_TimeEmbedding) else 0, L.ptr(self._gflat),
+                                    C.c_size_t(self._gflat.numel()), L.ptr(self._det_shadow), L.stream_of(self._gflat)),
+                "rdrf_det_bind")
+
+    def det_fold_(self):
+        """fold the fixed-point shadow into the fp32 gradients (call before anything reads .grad); no-op otherwise"""
+        if L.DETERMINISTIC and getattr(self, "_det_shadow", None) is not None:
+            self._det_bind()
+            L.check(L.lib.rdrf_det_finish(1 if isinstance(self, TensorVMSplit_TimeEmbedding) else 0,
+                                          L.stream_of(self._gflat)), "rdrf_det_finish")
 
     def flatten_params_(self):
         """Make every parameter a view of ONE flat fp32 buffer (same layout as the fused gradient buffer):
@@ -742,6 +768,8 @@ class TensorBase(nn.Module):
         """one memset for every gradient of this field (replaces optimizer.zero_grad())"""
         self.fused_grads()
         self._gflat.zero_()
+        if getattr(self, "_det_shadow", None) is not None:
+            self._det_shadow.zero_()
         return self._gflat
 
     def _check_layout(self):

@@ -87,6 +87,8 @@ class FlatAdam:
         # that an N-rank run optimises a slightly different objective from the 1-rank run.
         scale = 1.0 / self.world
         gathers = []
+        for f in self.fields:
+            f.det_fold_()
         for i, (f, st) in enumerate(zip(self.fields, self.state)):
             if f.flatten_params_().data_ptr() != st["p"].data_ptr():
                 raise L.RdrfError("a field's parameters left the flat buffer FlatAdam updates (Module.to / .cuda / "

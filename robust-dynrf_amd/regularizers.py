@@ -186,6 +186,7 @@ class _DenseL1Fn(torch.autograd.Function):
         xs = ctx.saved_tensors
         field = ctx.field
         fused = field.fused_grad
+        field._det_bind()
         if fused:
             views = {p.data_ptr(): v for p, v in zip(field._param_list(), field.fused_grads())}
             grads = [views[x.data_ptr()] for x in xs]

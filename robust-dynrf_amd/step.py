@@ -509,6 +509,7 @@ class Trainer:
             self.fov.grad = None
         st, dy = self.st, self.dy
         loss_s.backward()
+        st.det_fold_()   # RDRF_DETERMINISTIC=1: fixed-point shadow -> fp32 gradients (no-op in the product build)
         # TV_weight_density / TV_weight_app are multiplied by lr_factor every iteration BEFORE use (train.py:1734-1750;
         # the static terms of the same iteration use the decayed value, :1872-1885)
         tv_d, tv_a = (c["tv_density"] * self.lr_factor ** (self.it + 1), c["tv_app"] * self.lr_factor ** (self.it + 1))
@@ -517,6 +518,7 @@ class Trainer:
                                      [tv_d, tv_a])
         self.opt.begin_exchange(0)           # static field: complete
         loss_d.backward()
+        dy.det_fold_()
         if tv:
             self.tv.accumulate_grad_(dy, [(dy.density_plane, dy.density_line), (dy.blending_plane, dy.blending_line),
                                           (dy.app_plane, dy.app_line)], [tv_d, tv_d, tv_a])

@@ -1,0 +1,48 @@
+"""RDRF_DETERMINISTIC=1 (librodynrf_det.so: 64-bit fixed-point gradient accumulation, sorted compaction lists, no LDS
+line accumulators): the parameter gradients of a complete training step are bit-identical run after run, and equal
+the product build's (hardware fp32 atomics, run-to-run noise) within fp32 accumulation noise -- the reproducible
+reference a suspected race is diffed against (SURVEY.md 5 'race detection', 7 hard part 1)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, tag, det, size, name="nvidia"):
+    out = str(tmp_path / f"{tag}.pt")
+    env = dict(os.environ, RDRF_DETERMINISTIC="1" if det else "0")
+    env.pop("RDRF_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "det_check.py"), out, size, name], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(out)
+
+
+@pytest.mark.parametrize("size,name", [("small", "nvidia"), ("small", "davis"), ("bench", "nvidia")])
+def test_deterministic_build_is_bit_reproducible_and_matches_the_atomic_build(tmp_path, size, name):
+    a = _run(tmp_path, "det_a", True, size, name)
+    b = _run(tmp_path, "det_b", True, size, name)
+    c = _run(tmp_path, "atomic", False, size, name)
+    for x, y in zip(a["flats"], b["flats"]):
+        assert torch.equal(x, y), "the deterministic build is not bit-reproducible"
+    assert float(a["loss"]) == float(b["loss"])
+    for x, z in zip(a["flats"], c["flats"]):
+        scale = float(x.abs().max())
+        assert scale > 0
+        err = float((x - z).abs().max())
+        assert err <= 2e-5 * scale, (err, scale)   # the atomic build's own order noise (fp32 sums of up to ~1e5 terms)
+        assert float((x - z).norm() / x.norm()) < 2e-6
+
+
+def test_product_build_refuses_the_deterministic_entry_points():
+    import importlib
+    L = importlib.import_module("robust-dynrf_amd._lib")
+    if L.DETERMINISTIC:
+        pytest.skip("running under the deterministic build")
+    assert L.lib.rdrf_deterministic() == 0
+    assert L.lib.rdrf_det_finish(0, None) < 0 and b"product build" in L.lib.rdrf_last_error()
