@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
 // directly by walking the ray LAST tile first (transmittance carries of each tile start come from a
 // forward pre-pass); total - prefix would cancel catastrophically when p -> 1e-10.
 __global__ __launch_bounds__(64) void k_static_density_bwd(BwdArgs a, StaticW w, float* __restrict__ gf_rows) {
-  __shared__ float carr[32];
+  __shared__ float carr[64];   // transmittance carries at each 64-sample step (S <= 4096)
   const int lane = threadIdx.x;
   const int n = blockIdx.x;
   if (n >= a.N) return;
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
 template <int PHASE, bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[PHASE == 0 ? pkb::K1H_SIZE : pkb::K1W_SIZE];
-  __shared__ float carr[8][32];  // per-wave transmittance carries at tile starts (S <= 1024)
+  __shared__ float carr[8][128];  // per-wave transmittance carries at tile starts (S <= 4096)
   lds_fill(lds, a.pk + (PHASE == 0 ? pkb::REG_K1H : pkb::REG_K1W), PHASE == 0 ? pkb::K1H_SIZE : pkb::K1W_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -2460,7 +2460,7 @@ extern "C" int rdrf_static_bwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
                                rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
-  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 2048, -1, "static_bwd: bad arguments (S <= 2048)");
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 4096, -1, "static_bwd: bad arguments (S <= 4096)");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "static_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   // z_vals never depends on a trainable quantity in the reference (linspace + jitter)
   BwdArgs a;
@@ -2548,7 +2548,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
                                 size_t ws_bytes, rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
-  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 1024, -1, "dynamic_bwd: bad arguments (S <= 1024)");
+  RDRF_CHECK(P && cfg && G && saved && N > 0 && S > 0 && S <= 4096, -1, "dynamic_bwd: bad arguments (S <= 4096)");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "dynamic_bwd: N * S * 3 must stay below 2^31 (32-bit sample indices)");
   BwdArgs a;
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);

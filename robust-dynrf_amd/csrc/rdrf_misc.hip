@@ -371,7 +371,7 @@ RDRF_D float wave_suffix_excl(float v, int lane, float& total) {
 }
 
 __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
-  __shared__ float carr[3][32];  // transmittance carries at each 64-sample tile start (S <= 2048)
+  __shared__ float carr[3][64];  // transmittance carries at each 64-sample tile start (S <= 4096)
   const int lane = threadIdx.x;
   const int n = blockIdx.x;
   if (n >= a.N) return;
@@ -501,7 +501,7 @@ extern "C" int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, cons
                                   float* const g_in8[8], rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
-  RDRF_CHECK(N > 0 && S > 0 && S <= 2048 && g_out13 && g_in8, -1, "composite_bwd: bad arguments (S <= 2048)");
+  RDRF_CHECK(N > 0 && S > 0 && S <= 4096 && g_out13 && g_in8, -1, "composite_bwd: bad arguments (S <= 4096)");
   CompBArgs a;
   a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
   a.dists = dists; a.blending = blending; a.z = z; a.rays = rays;

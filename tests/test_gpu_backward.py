@@ -375,3 +375,21 @@ def test_z_vals_gradient_matches_oracle(rt):
     gg, = torch.autograd.grad(Lg, zg)
     assert float(gref.abs().max()) > 0
     assert_close(gg, gref, "d loss / d z_vals", rtol=1e-4)
+
+
+def test_sorted_scatter_passes_the_same_parity_tests():
+    """RDRF_SCATTER=sorted (samples grouped by plane cell by one stable radix sort, csrc/rdrf_bwd.hip k_scatter_sorted; the
+    automatic choice from 800 k samples per launch) is read once per process: the golden-gradient and mid-size oracle
+    gradient tests are re-run in a child process with the sorted path forced at their small sizes."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RDRF_SCATTER") == "sorted":
+        pytest.skip("already the child process")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RDRF_SCATTER="sorted")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_backward.py"), "-m", "gpu", "-q", "-x",
+                        "--no-header", "-k", "golden_gradients or midsize or pruned or fused_grad"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout

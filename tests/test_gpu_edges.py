@@ -1,5 +1,5 @@
 """Edge cases of the call surface through the C ABI: empty and single-element batches, rays with no valid
-sample, nothing / everything passing the appearance mask, the longest supported ray (S = 1024), S = 1.
+sample, nothing / everything passing the appearance mask, the longest supported ray (S = 4096), S = 1.
 The oracle (or the torch behaviour of the reference on the same input) is the checker."""
 import pytest
 import torch
@@ -85,7 +85,7 @@ def test_empty_batch_is_a_no_op(rt):
     assert rgb.shape == (0, 3) and depth.shape == (0,)
 
 
-@pytest.mark.parametrize("rt,N,S", [("ndc", 1, 1), ("ndc", 1, 33), ("contract", 1, 2), ("ndc", 3, 1024), ("contract", 2, 1024)])
+@pytest.mark.parametrize("rt,N,S", [("ndc", 1, 1), ("ndc", 1, 33), ("contract", 1, 2), ("ndc", 3, 1024), ("contract", 2, 1024), ("ndc", 2, 4096)])
 def test_single_ray_and_extreme_sample_counts(rt, N, S):
     """one ray; one sample per ray; the longest ray the dynamic field supports (S = 1024: 32 tiles, the
     transmittance carries of all of them)"""
