@@ -387,14 +387,28 @@ int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, const int64_t*
 int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float* g_loss, int N, float gscale, float* g_pred,
                               rdrf_stream_t stream);
 
-/* ---- one-launch-sequence no-grad render of a ray chunk (renderer.py:740-812 loop body):
- * sample -> static fwd -> dynamic fwd -> composite; writes rgb_map_full[N][3], depth_map_full[N].
- * scratch for the per-sample tensors comes out of ws (rdrf_render_workspace_bytes). */
+/* ---- no-grad render of a ray chunk (renderer.py:740-812 loop body): sample -> static -> dynamic -> composite;
+ * writes rgb_map_full[N][3], depth_map_full[N]; scratch for the per-sample tensors comes out of ws
+ * (rdrf_render_workspace_bytes).
+ *   rdrf_render_fused_fwd     ONE cooperative launch: persistent workgroups walk the sampler, both density phases, both
+ *                             appearance phases and the compositor, separated by grid-wide barriers (the LDS is re-filled
+ *                             with each phase's weight image).  Same device code as the per-phase kernels: identical bits.
+ *   rdrf_render_sequence_fwd  the per-phase kernels as a launch sequence (11 stream operations).
+ *   rdrf_render_fwd           the launch sequence (measured faster at every size on MI355X: 274 vs 378 us per 512-ray
+ *                             chunk, equal on whole frames; csrc/rdrf_render.hip); RDRF_RENDER=fused selects the single launch. */
 size_t rdrf_render_workspace_bytes(int N, int S);
 int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
                     const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
                     const float* ts, int N, int S, float near, float far, float* rgb_map,
                     float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+int rdrf_render_fused_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
+                          const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
+                          const float* ts, int N, int S, float near, float far, float* rgb_map,
+                          float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
+                             const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
+                             const float* ts, int N, int S, float near, float far, float* rgb_map,
+                             float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
 
 /* ---- deterministic debugging build (librodynrf_det.so = the same sources with -DRDRF_DETERMINISTIC) ----------------
  * Every addition into a BOUND flat gradient buffer (scatter of the VM factors, line flushes, dW / bias sums, time

@@ -108,6 +108,7 @@ SYMBOLS = [
     "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
     "rdrf_dense_l1_bwd", "rdrf_pack_floats", "rdrf_static_pack", "rdrf_dynamic_pack", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
     "rdrf_loss_terms_stats", "rdrf_loss_terms_finish", "rdrf_deterministic", "rdrf_det_bind", "rdrf_det_finish",
+    "rdrf_render_fused_fwd", "rdrf_render_sequence_fwd",
     "rdrf_frame_depth_loss_workspace_bytes", "rdrf_frame_depth_loss_fwd", "rdrf_frame_depth_loss_bwd",
     "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",

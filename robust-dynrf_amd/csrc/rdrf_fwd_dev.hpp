@@ -1,0 +1,476 @@
+// rdrf_fwd_dev.hpp -- device bodies of the forward field kernels (TensorBase.forward, /root/reference/models/
+// tensorBase.py:704-850), shared by the per-phase kernels of rdrf_fwd.hip and the single-launch fused render of
+// rdrf_render.hip.  A body sees its position in the launch through GridCtx (workgroup id / count, thread id / count)
+// and gets its LDS weight image as a pointer, so the same code runs as its own kernel or as one phase of a larger one.
+#pragma once
+#include "rdrf_kernels.hpp"
+
+struct GridCtx {
+  int bid, nblk, tid, nthr;
+};
+RDRF_D GridCtx grid_ctx() { return GridCtx{(int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, (int)blockDim.x}; }
+// a body that IS the kernel (FUSED = false) reads the launch geometry from the hardware registers, exactly as the
+// kernels did before they were split into bodies (same code generation); as a phase of the fused render it reads gc
+#define GC_BID (FUSED ? gc.bid : (int)blockIdx.x)
+#define GC_NBLK (FUSED ? gc.nblk : (int)gridDim.x)
+#define GC_TID (FUSED ? gc.tid : (int)threadIdx.x)
+#define GC_NTHR (FUSED ? gc.nthr : (int)blockDim.x)
+
+template <bool FEAT, bool FUSED = false>
+RDRF_D void static_density_body(const FieldArgs a, const StaticW w, const GridCtx gc) {
+  const int lane = GC_TID & 63;
+  const int wave_ = GC_TID >> 6, nwaves_ = GC_NTHR >> 6;
+  for (int n = GC_BID * nwaves_ + wave_; n < a.N; n += GC_NBLK * nwaves_) {
+  float vx, vy, vz;
+  float nrm = 1.0f;
+  if constexpr (!FEAT) nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float carry = 1.0f;
+  for (int j0 = 0; j0 < a.S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
+    const int idx = n * a.S + (act ? j : 0);
+    const bool vld = act && (FEAT || a.valid[idx] != 0);
+    float f = 0.0f;
+    if (vld) {
+      float x0, x1, x2;
+      if (FEAT && a.in_norm) {
+        x0 = a.xyz[idx * 3 + 0]; x1 = a.xyz[idx * 3 + 1]; x2 = a.xyz[idx * 3 + 2];
+      } else {
+        x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+        x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+        x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+      }
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) {  // quads 0..3 plane 0, 4 plane 1, 5 plane 2
+        float sp = 0.f;
+#pragma unroll
+        for (int g = (pi == 0 ? 0 : 3 + pi); g < (pi == 0 ? 4 : 4 + pi); ++g) {
+          f32x4 v = gather_quad<4, 1>(w.density, g, x0, x1, x2);
+          sp += v.x + v.y + v.z + v.w;
+        }
+        f += sp;
+      }
+    }
+    if (a.raw != nullptr && act) a.raw[idx] = f;
+    if constexpr (FEAT) {  // compute_densityfeature: the raw feature (models/tensoRF.py:118-154)
+      if (act && a.sigma != nullptr) a.sigma[idx] = f;
+    } else {
+      const float sigma = vld ? density_act(f, a.act, a.density_shift) : 0.0f;
+      const float zj = act ? a.z[idx] : 0.f;
+      const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+      const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+      const float alpha = 1.0f - expf(-sigma * ds);
+      const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+      const float incl = scan_mul64(p, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.0f;
+      const float T = carry * excl;
+      const float wt = alpha * T;
+      carry *= __shfl(incl, 63, 64);
+      const bool m = act && wt > a.weight_thres;
+      if (act) {
+        a.sigma[idx] = sigma;
+        a.weight[idx] = wt;
+        a.dists[idx] = ds;
+      }
+      const unsigned long long bal = __ballot(m);
+      if (bal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
+      }
+    }
+  }
+  }  // ray loop
+}
+
+template <int HEAD, bool FEAT, bool SAVE = true, bool FUSED = false>
+RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused, const GridCtx gc) {
+  float* lds;
+  if constexpr (FUSED) lds = lds_fused;
+  else {   // the standalone kernel owns its image as a named LDS array (constant addresses in every ds_read)
+    __shared__ __attribute__((aligned(16))) float lds_own[pk::S3_SIZE];
+    lds = lds_own;
+  }
+  lds_fill(lds, a.pk + pk::REG_S3, pk::S3_SIZE);
+  const int lane = GC_TID & 63, h = lane >> 5, s = lane & 31;
+  const int wave = GC_TID >> 6, nwaves = GC_NTHR >> 6;
+  const int count = FEAT ? a.M : *a.counter;
+  const int ntiles = (count + 31) >> 5;
+  const float* pkw = lds;
+  for (int tile = GC_BID * nwaves + wave; tile < ntiles; tile += GC_NBLK * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < count;
+    const int idx = act ? (FEAT ? li : a.list[li]) : 0;
+    const int n = idx / a.S;
+    float* svb = (SAVE && a.act3) ? a.act3 + (size_t)tile * sv::S3_ROWS * 32 : nullptr;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if constexpr (!FEAT) ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    float x0, x1, x2;
+    if (FEAT && a.in_norm) {
+      x0 = a.xyz[idx * 3 + 0]; x1 = a.xyz[idx * 3 + 1]; x2 = a.xyz[idx * 3 + 2];
+    } else {
+      x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    }
+    float G[36];
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, x0, x1, x2);
+      G[o * 4 + 0] = v.x; G[o * 4 + 1] = v.y; G[o * 4 + 2] = v.z; G[o * 4 + 3] = v.w;
+    }
+    f32x16 accF[1];
+    acc_bias<1>(accF, nullptr, h);
+    mfma_seg<1, 36>(accF, G, pkw + pk::S3_BASIS, lane);
+    float F[16];
+    acc_copy<1>(F, accF);
+    if constexpr (FEAT) {  // compute_appfeature: basis_mat output (models/tensoRF.py:156-196)
+      save_rows<36>(svb, sv::S3_G, G, s, h);
+      if (act) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+          if (elem_of(kk, h) < 27) a.feat[(size_t)idx * 27 + elem_of(kk, h)] = F[kk];
+      }
+      continue;
+    }
+    float P[64];
+    {
+      float fmax_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fmax_ = fmaxf(fmax_, fabsf(F[r]));
+      if (__builtin_expect(__any(!(fmax_ * 2.0f <= RDRF_PE_FAST_MAX)), 0)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s1, c1, s2, c2;
+          sincosf(F[r], &s1, &c1);
+          sincosf(F[r] * 2.0f, &s2, &c2);
+          P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s1, c1, s2, c2;
+          sincos_sel<true>(F[r], s1, c1);
+          sincos_sel<true>(F[r] * 2.0f, s2, c2);
+          P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+        }
+      }
+    }
+    if (HEAD == RDRF_HEAD_MLP_FEA) {  // viewdirs ride in the pad slots 27..29 of the feature block
+      if (h == 0) F[15] = vx;
+      else { F[12] = vy; F[13] = vz; }
+    }
+    if (svb != nullptr && h == 0) {
+      svb[(size_t)(sv::S3_VD + 0) * 32 + s] = vx; svb[(size_t)(sv::S3_VD + 1) * 32 + s] = vy;
+      svb[(size_t)(sv::S3_VD + 2) * 32 + s] = vz;
+    }
+    save_rows<36>(svb, sv::S3_G, G, s, h);
+    save_rows<16>(svb, sv::S3_F, F, s, h);
+    save_rows<64>(svb, sv::S3_P, P, s, h);
+    f32x16 acc[4];
+    acc_bias<4>(acc, pkw + pk::S3_B1, h);
+    mfma_seg<4, 16>(acc, F, pkw + pk::S3_W1_F, lane);
+    mfma_seg<4, 64>(acc, P, pkw + pk::S3_W1_P, lane);
+    float H1[64];
+    acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::S3_H1, H1, s, h);
+    acc_bias<4>(acc, pkw + pk::S3_B2, h);
+    mfma_seg<4, 64>(acc, H1, pkw + pk::S3_W2, lane);
+    acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::S3_H2, H1, s, h);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small<64>(H1, pkw + pk::S3_W3 + o * 128, h) + w.b3[o];
+      if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING)
+        v += w.w3[o * 131 + 128] * vx + w.w3[o * 131 + 129] * vy + w.w3[o * 131 + 130] * vz;
+      if (act && h == 0) a.rgb[(size_t)idx * 3 + o] = sigmoidf_(v);
+    }
+  }
+}
+
+template <bool FEAT, bool SAVE = true, bool FUSED = false>
+RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, const GridCtx gc) {
+  float* lds;
+  if constexpr (FUSED) lds = lds_fused;
+  else {   // the standalone kernel owns its image as a named LDS array (constant addresses in every ds_read)
+    __shared__ __attribute__((aligned(16))) float lds_own[pk::K1_SIZE];
+    lds = lds_own;
+  }
+  lds_fill(lds, a.pk + pk::REG_K1, pk::K1_SIZE);
+  const int lane = GC_TID & 63, h = lane >> 5, s = lane & 31;
+  const int wave = GC_TID >> 6, nwaves = GC_NTHR >> 6;
+  const float* pkw = lds;
+  for (int n = GC_BID * nwaves + wave; n < a.N; n += GC_NBLK * nwaves) {
+  float t = 0.f, nrm = 1.0f;
+  float T[16];
+  float X1[8];
+  if constexpr (!FEAT) {   // time is per ray: tout / PE8(t) are per-ray constants
+    t = a.ts[n];
+    float vx, vy, vz;
+    nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = ld4(a.tout + n * 32 + 8 * q + 4 * h);
+      T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
+    }
+    fill_x1(X1, t, h);
+  }
+  float carry = 1.0f;
+  for (int j0 = 0; j0 < a.S; j0 += 32) {
+    const int j = j0 + s;
+    const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
+    const int idx = n * a.S + (act ? j : 0);
+    const bool vld = act && (FEAT || a.valid[idx] != 0);
+    if constexpr (FEAT) {  // time is per point
+      t = a.ts[idx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = ld4(a.tout + (size_t)idx * 32 + 8 * q + 4 * h);
+        T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
+      }
+      fill_x1(X1, t, h);
+    }
+    const float px = a.xyz[idx * 3 + 0], py = a.xyz[idx * 3 + 1], pz = a.xyz[idx * 3 + 2];
+    const bool raw_in = FEAT && a.in_norm;   // compute_*: the caller hands normalised coordinates
+    const float xn0 = raw_in ? px : norm_c(px, a.box.lo[0], a.box.inv[0]);
+    const float xn1 = raw_in ? py : norm_c(py, a.box.lo[1], a.box.inv[1]);
+    const float xn2 = raw_in ? pz : norm_c(pz, a.box.lo[2], a.box.inv[2]);
+    float X0[32];
+    fill_x0(X0, xn0, xn1, xn2, t, h);
+    float* svb = (SAVE && a.act1) ? a.act1 + ((size_t)n * ((a.S + 31) >> 5) + (j0 >> 5)) * sv::K1_ROWS * 32 : nullptr;
+    save_rows<32>(svb, sv::K1_X0, X0, s, h);
+    save_rows<8>(svb, sv::K1_X1, X1, s, h);
+    save_rows<16>(svb, sv::K1_T, T, s, h);
+    // ---- warp MLP: [xn, PE10(xn), tout] -> 64 -> 64 -> 3  (models/tensoRF.py:521-541)
+    float d0, d1, d2;
+    {
+      f32x16 acc[2];
+      acc_bias<2>(acc, pkw + pk::K1_B3, h);
+      mfma_seg<2, 32>(acc, X0, pkw + pk::K1_W3_X0, lane);
+      mfma_seg<2, 16>(acc, T, pkw + pk::K1_W3_T, lane);
+      float H3[32];
+      acc_relu<2>(H3, acc);
+      save_rows<32>(svb, sv::K1_H3, H3, s, h);
+      acc_bias<2>(acc, pkw + pk::K1_B4, h);
+      mfma_seg<2, 32>(acc, H3, pkw + pk::K1_W4, lane);
+      acc_relu<2>(H3, acc);
+      save_rows<32>(svb, sv::K1_H4, H3, s, h);
+      d0 = dot_small<32>(H3, pkw + pk::K1_W5 + 0 * 64, h) + w.l5b[0];
+      d1 = dot_small<32>(H3, pkw + pk::K1_W5 + 1 * 64, h) + w.l5b[1];
+      d2 = dot_small<32>(H3, pkw + pk::K1_W5 + 2 * 64, h) + w.l5b[2];
+    }
+    // compute_* warp the un-normalised round trip of xn (models/tensoRF.py:647-649)
+    const float xw0 = norm_c(unnorm_c(xn0, a.box.lo[0], a.box.inv[0]) + d0, a.box.lo[0], a.box.inv[0]);
+    const float xw1 = norm_c(unnorm_c(xn1, a.box.lo[1], a.box.inv[1]) + d1, a.box.lo[1], a.box.inv[1]);
+    const float xw2 = norm_c(unnorm_c(xn2, a.box.lo[2], a.box.inv[2]) + d2, a.box.lo[2], a.box.inv[2]);
+    if (act && h == 0) {
+      if (!FEAT || a.xyz_prime != nullptr) {
+        a.xyz_prime[(size_t)idx * 3 + 0] = (raw_in ? unnorm_c(xn0, a.box.lo[0], a.box.inv[0]) : px) + d0;
+        a.xyz_prime[(size_t)idx * 3 + 1] = (raw_in ? unnorm_c(xn1, a.box.lo[1], a.box.inv[1]) : py) + d1;
+        a.xyz_prime[(size_t)idx * 3 + 2] = (raw_in ? unnorm_c(xn2, a.box.lo[2], a.box.inv[2]) : pz) + d2;
+      }
+      a.xw[(size_t)idx * 3 + 0] = xw0;
+      a.xw[(size_t)idx * 3 + 1] = xw1;
+      a.xw[(size_t)idx * 3 + 2] = xw2;
+    }
+    // ---- density and blending heads: 3-stride VM features (72) + X0 + X1 -> 64 -> 1
+    float fd, fb;
+    {
+      float Fv[36];
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.density, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
+      f32x16 acc[2];
+      acc_bias<2>(acc, pkw + pk::K1_BD1, h);
+      mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_DEN1_F, lane);
+      mfma_seg<2, 32>(acc, X0, pkw + pk::K1_DEN1_X0, lane);
+      mfma_seg<2, 8>(acc, X1, pkw + pk::K1_DEN1_X1, lane);
+      float Hd[32];
+      acc_relu<2>(Hd, acc);
+      save_rows<36>(svb, sv::K1_FD, Fv, s, h);
+      save_rows<32>(svb, sv::K1_HD, Hd, s, h);
+      fd = dot_small<32>(Hd, pkw + pk::K1_DEN2, h) + w.db2[0];
+    }
+    {
+      float Fv[36];
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vld) v = gather_quad<4, 1>(w.blending, 2 * o + h, xw0, xw1, xw2);
+        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+      }
+      f32x16 acc[2];
+      acc_bias<2>(acc, pkw + pk::K1_BB1, h);
+      mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_BLE1_F, lane);
+      mfma_seg<2, 32>(acc, X0, pkw + pk::K1_BLE1_X0, lane);
+      mfma_seg<2, 8>(acc, X1, pkw + pk::K1_BLE1_X1, lane);
+      float Hd[32];
+      acc_relu<2>(Hd, acc);
+      save_rows<36>(svb, sv::K1_FB, Fv, s, h);
+      save_rows<32>(svb, sv::K1_HB, Hd, s, h);
+      fb = dot_small<32>(Hd, pkw + pk::K1_BLE2, h) + w.bb2[0];
+    }
+    if constexpr (FEAT) {  // compute_densityfeature / compute_blendingfeature: the raw head outputs
+      if (act && h == 0) {
+        if (a.sigma != nullptr) a.sigma[idx] = fd;
+        if (a.blending != nullptr) a.blending[idx] = fb;
+        if (a.raw != nullptr) { a.raw[(size_t)idx * 2] = fd; a.raw[(size_t)idx * 2 + 1] = fb; }
+      }
+    } else {
+    const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.0f;
+    const float blend = vld ? sigmoidf_(fb) : 0.0f;
+    const float zj = act ? a.z[idx] : 0.f;
+    const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+    const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+    const float alpha = 1.0f - expf(-sigma * ds);
+    const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+    const float incl = scan_mul32(p, s);
+    float excl = __shfl_up(incl, 1, 32);
+    if (s == 0) excl = 1.0f;
+    const float Tr = carry * excl;
+    const float wt = alpha * Tr;
+    carry *= __shfl(incl, 31, 32);
+    const bool m = act && h == 0 && wt > a.weight_thres;
+    if (act && h == 0) {
+      a.sigma[idx] = sigma;
+      a.weight[idx] = wt;
+      a.dists[idx] = ds;
+      a.blending[idx] = blend;
+      if (SAVE && a.raw != nullptr) { a.raw[(size_t)idx * 2] = fd; a.raw[(size_t)idx * 2 + 1] = fb; }
+    }
+    const unsigned long long bal = __ballot(m);
+    if (bal) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
+    }
+    }
+  }
+  }  // ray loop
+}
+
+template <bool FEAT, bool SAVE = true, bool FUSED = false>
+RDRF_D void dyn_app_body(const FieldArgs a, const DynW w, float* lds_fused, const GridCtx gc) {
+  float* lds;
+  if constexpr (FUSED) lds = lds_fused;
+  else {   // the standalone kernel owns its image as a named LDS array (constant addresses in every ds_read)
+    __shared__ __attribute__((aligned(16))) float lds_own[pk::K3_SIZE];
+    lds = lds_own;
+  }
+  lds_fill(lds, a.pk + pk::REG_K3, pk::K3_SIZE);
+  const int lane = GC_TID & 63, h = lane >> 5, s = lane & 31;
+  const int wave = GC_TID >> 6, nwaves = GC_NTHR >> 6;
+  const int count = FEAT ? a.M : *a.counter;
+  const int ntiles = (count + 31) >> 5;
+  const float* pkw = lds;
+  for (int tile = GC_BID * nwaves + wave; tile < ntiles; tile += GC_NBLK * nwaves) {
+    const int li = tile * 32 + s;
+    const bool act = li < count;
+    const int idx = act ? (FEAT ? li : a.list[li]) : 0;
+    const int n = idx / a.S;
+    const float t = FEAT ? 0.f : a.ts[n];
+    float* svb = (SAVE && a.act3) ? a.act3 + (size_t)tile * sv::K3_ROWS * 32 : nullptr;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    float xn0 = 0.f, xn1 = 0.f, xn2 = 0.f;
+    if constexpr (!FEAT) {
+      ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+      xn0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+      xn1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+      xn2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    }
+    const float xw0 = a.xw[(size_t)idx * 3 + 0], xw1 = a.xw[(size_t)idx * 3 + 1],
+                xw2 = a.xw[(size_t)idx * 3 + 2];
+    float F[16];
+    {
+      float A[108];
+#pragma unroll
+      for (int o = 0; o < 27; ++o) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, xw0, xw1, xw2);
+        A[o * 4 + 0] = v.x; A[o * 4 + 1] = v.y; A[o * 4 + 2] = v.z; A[o * 4 + 3] = v.w;
+      }
+      f32x16 accF[1];
+      acc_bias<1>(accF, nullptr, h);
+      mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
+      acc_copy<1>(F, accF);
+      save_rows<108>(svb, sv::K3_A, A, s, h);
+    }
+    if constexpr (FEAT) {  // compute_appfeature: basis_mat output (models/tensoRF.py:734-811)
+      if (act) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+          if (elem_of(kk, h) < 27) a.feat[(size_t)idx * 27 + elem_of(kk, h)] = F[kk];
+      }
+      continue;
+    }
+    float X0[32], X1[8];
+    fill_x0(X0, xn0, xn1, xn2, t, h);
+    fill_x1(X1, t, h);
+    if (svb != nullptr && h == 0) {
+      svb[(size_t)(sv::K3_VD + 0) * 32 + s] = vx; svb[(size_t)(sv::K3_VD + 1) * 32 + s] = vy;
+      svb[(size_t)(sv::K3_VD + 2) * 32 + s] = vz;
+    }
+    save_rows<16>(svb, sv::K3_F, F, s, h);
+    save_rows<32>(svb, sv::K3_X0, X0, s, h);
+    save_rows<8>(svb, sv::K3_X1, X1, s, h);
+    f32x16 acc[4];
+    acc_bias<4>(acc, pkw + pk::K3_B1, h);
+    mfma_seg<4, 16>(acc, F, pkw + pk::K3_RGB1_F, lane);
+    mfma_seg<4, 32>(acc, X0, pkw + pk::K3_RGB1_X0, lane);
+    mfma_seg<4, 8>(acc, X1, pkw + pk::K3_RGB1_X1, lane);
+    float H1[64];
+    acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::K3_H1, H1, s, h);
+    acc_bias<4>(acc, pkw + pk::K3_B2, h);
+    mfma_seg<4, 64>(acc, H1, pkw + pk::K3_RGB2, lane);
+    acc_relu<4>(H1, acc);
+    save_rows<64>(svb, sv::K3_H2, H1, s, h);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small<64>(H1, pkw + pk::K3_RGBV + o * 128, h) + w.rbv[o];
+      v += w.rwv[o * 131 + 128] * vx + w.rwv[o * 131 + 129] * vy + w.rwv[o * 131 + 130] * vz;
+      if (act && h == 0) a.rgb[(size_t)idx * 3 + o] = sigmoidf_(v);
+    }
+  }
+}
+
+// time branch of the dynamic field for the rays [0, N): 32 lanes per ray (lane o: hidden neurons o and o + 32, then
+// output o); s_h: [threads / 32][64] floats of LDS.  Every thread of the block must call (barriers inside).
+template <bool FUSED = false>
+RDRF_D void time_branch_body(const float* __restrict__ ts, const DynW w, int N, float* __restrict__ tout, float* s_h,
+                             const GridCtx gc) {
+  const int rpb = GC_NTHR >> 5;
+  const int r = GC_TID >> 5, o = GC_TID & 31;
+  for (int base = GC_BID * rpb; base < N; base += GC_NBLK * rpb) {
+    const int n = base + r;
+    const bool act = n < N;
+    const float t = act ? ts[n] : 0.f;
+    float tin[17];
+    tin[0] = t;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) sincosf(ldexpf(t, f), &tin[1 + f], &tin[9 + f]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = o + 32 * j;
+      float hk = w.l1b[k];
+#pragma unroll
+      for (int i = 0; i < 17; ++i) hk = fmaf(w.l1w[k * 17 + i], tin[i], hk);
+      s_h[r * 64 + k] = fmaxf(hk, 0.0f);
+    }
+    __syncthreads();
+    float out = 0.f;
+    if (o < 30) {
+      out = w.l2b[o];
+      for (int k = 0; k < 64; ++k) out = fmaf(w.l2w[o * 64 + k], s_h[r * 64 + k], out);   // k ascending, as before
+    }
+    if (act) tout[n * 32 + o] = out;
+    __syncthreads();
+  }
+}

@@ -1,61 +1,259 @@
 // rdrf_render.hip -- no-grad render of a ray chunk in one launch sequence (the loop body of
 // /root/reference/renderer.py:740-812: sampleXYZ -> static -> dynamic -> raw2outputs), and a
 // self-test of the MFMA layer primitive used by tests/.
-#include "rdrf_kernels.hpp"
+#include "rdrf_misc_dev.hpp"
+
+// host helpers of rdrf_fwd.hip
+void fill_common(FieldArgs& a, const RdrfFieldCfg* cfg, const float* rays, const float* ts, const float* xyz, const float* z,
+                 const uint8_t* valid, int N, int S);
+void fill_static_w(StaticW& w, const RdrfStaticParams* P);
+void fill_dyn_w(DynW& w, const RdrfDynamicParams* P);
+int ws_carve_fwd(FieldArgs& a, void* ws, size_t ws_bytes, int N, int S, void* saved, size_t saved_bytes, int dynamic);
+void dyn_pack_jobs_fwd(PackJobs& J, const RdrfDynamicParams* P);
+void static_pack_jobs_fwd(PackJobs& J, const RdrfStaticParams* P, int head);
+
+// ------------------------------------------------------------------------------------------------
+// FUSED render: sample -> static + dynamic density phases -> static + dynamic appearance phases -> compositor in ONE
+// cooperative launch (/root/reference/renderer.py:740-812 loop body).  The persistent workgroups (one per CU, 8
+// waves) walk the phases of the per-phase kernels -- the same device bodies (rdrf_fwd_dev.hpp, rdrf_misc_dev.hpp),
+// so the results are those of the launch sequence bit for bit -- separated by grid-wide barriers; the LDS is
+// re-filled with the weight image of each MLP phase (121 / 159 / 153 KB: they cannot be resident together).  What
+// it buys is the launch sequence itself: 11 stream operations -> 2, which is what a 512-ray chunk (the reference's
+// eval chunk, renderer.py:732) spends most of its time on; the per-sample intermediates stay in the L2 / MALL.
+// ------------------------------------------------------------------------------------------------
+struct RenderFusedArgs {
+  FieldArgs as, ad;      // static / dynamic field (outputs + workspaces in the caller's scratch)
+  StaticW ws;
+  DynW wd;
+  CompArgs comp;
+  float near, far;
+  unsigned* barrier;     // zero at launch
+};
+
+// grid-wide barrier of the cooperative launch (all workgroups are resident): a monotonically increasing arrival
+// counter; agent-scope fences publish this workgroup's writes (other XCDs have their own L2) and invalidate stale
+// lines before the next phase reads what other workgroups wrote.  A bounded spin: a lost workgroup cannot hang the GPU.
+RDRF_D void grid_barrier(unsigned* bar, unsigned nblk, unsigned& epoch) {
+  __syncthreads();
+  epoch += 1;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(bar, 1u);
+    const unsigned target = epoch * nblk;
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 26)) break;
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+template <int HEAD>
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_render_fused(RenderFusedArgs r) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GridCtx gc = grid_ctx();
+  unsigned epoch = 0;
+  const int N = r.as.N, S = r.as.S;
+  // ---- phase 0: sample points, per-ray time branch, clear the per-sample rgb (0 off the appearance masks) and the
+  // compaction counters
+  if (r.ad.ray_type == RDRF_RAY_NDC)
+    sample_ndc_body(r.as.rays, N, S, r.near, r.far, nullptr, r.ad.box, (float*)r.as.xyz, (float*)r.as.z, (uint8_t*)r.as.valid, gc);
+  else
+    sample_contract_body(r.as.rays, N, S, r.near, r.far, nullptr, nullptr, (float*)r.as.xyz, (float*)r.as.z,
+                         (uint8_t*)r.as.valid, gc);
+  time_branch_body<true>(r.ad.ts, r.wd, N, r.ad.tout, lds, gc);
+  {
+    const size_t n3 = (size_t)N * S * 3;
+    for (size_t i = (size_t)gc.bid * gc.nthr + gc.tid; i < n3; i += (size_t)gc.nblk * gc.nthr) {
+      r.as.rgb[i] = 0.f;
+      r.ad.rgb[i] = 0.f;
+    }
+    if (gc.bid == 0 && gc.tid == 0) { *r.as.counter = 0; *r.ad.counter = 0; }
+  }
+  grid_barrier(r.barrier, gc.nblk, epoch);
+  // ---- phase 1: density of both fields (weights, compaction of the appearance masks)
+  static_density_body<false, true>(r.as, r.ws, gc);
+  dyn_density_body<false, false, true>(r.ad, r.wd, lds, gc);
+  grid_barrier(r.barrier, gc.nblk, epoch);
+  // ---- phase 2: appearance of both fields over the compacted lists
+  static_app_body<HEAD, false, false, true>(r.as, r.ws, lds, gc);
+  __syncthreads();
+  dyn_app_body<false, false, true>(r.ad, r.wd, lds, gc);
+  grid_barrier(r.barrier, gc.nblk, epoch);
+  // ---- phase 3: raw2outputs per ray
+  composite_body(r.comp, gc);
+}
 
 extern "C" size_t rdrf_render_workspace_bytes(int N, int S) {
   const size_t ns = (size_t)N * S;
-  // xyz, xyz_prime, rgb_s, rgb_d (3 floats) + 12 scalar planes + valid + 13 outputs + field workspace
-  return ns * 4 * (3 * 4 + 12) + ns + (size_t)N * 4 * 16 + rdrf_workspace_bytes(N, S) + (1 << 14);
+  // xyz, xyz_prime, rgb_s, rgb_d (3 floats) + 12 scalar planes + valid + 13 outputs + both fields' workspaces
+  return ns * 4 * (3 * 4 + 12) + ns + (size_t)N * 4 * 16 + 2 * rdrf_workspace_bytes(N, S) + (1 << 14);
 }
 
-extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
-                               const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d,
-                               const float* rays, const float* ts, int N, int S, float near,
-                               float far, float* rgb_map, float* depth_map, void* ws, size_t ws_bytes,
-                               rdrf_stream_t stream) {
-  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
-  RDRF_CHECK(PS && PD && cfg_s && cfg_d && rays && ts && rgb_map && depth_map && N > 0 && S > 0, -1,
-             "render_fwd: bad arguments");
-  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "render_fwd: N * S * 3 must stay below 2^31: render in chunks");
-  RDRF_CHECK(ws_bytes >= rdrf_render_workspace_bytes(N, S), -3, "render_fwd: workspace too small");
+struct RenderBufs {
+  float *xyz, *z, *rgb_s, *sigma_s, *weight_s, *dists_s, *rgb_d, *sigma_d, *weight_d, *dists_d, *blending, *xyz_prime;
+  uint8_t* valid;
+  float* out[13];
+  void *fws_s, *fws_d;
+  unsigned* barrier;
+};
+static int carve_render(RenderBufs& b, void* ws, size_t ws_bytes, int N, int S, float* rgb_map, float* depth_map) {
   WsCarver c(ws, ws_bytes);
   const size_t ns = (size_t)N * S;
-  float* xyz = c.take<float>(ns * 3);
-  float* z = c.take<float>(ns);
-  uint8_t* valid = c.take<uint8_t>(ns);
-  float* rgb_s = c.take<float>(ns * 3);
-  float* sigma_s = c.take<float>(ns);
-  float* weight_s = c.take<float>(ns);
-  float* dists_s = c.take<float>(ns);
-  float* rgb_d = c.take<float>(ns * 3);
-  float* sigma_d = c.take<float>(ns);
-  float* weight_d = c.take<float>(ns);
-  float* dists_d = c.take<float>(ns);
-  float* blending = c.take<float>(ns);
-  float* xyz_prime = c.take<float>(ns * 3);
-  float* out[13];
+  b.xyz = c.take<float>(ns * 3);
+  b.z = c.take<float>(ns);
+  b.valid = c.take<uint8_t>(ns);
+  b.rgb_s = c.take<float>(ns * 3);
+  b.sigma_s = c.take<float>(ns);
+  b.weight_s = c.take<float>(ns);
+  b.dists_s = c.take<float>(ns);
+  b.rgb_d = c.take<float>(ns * 3);
+  b.sigma_d = c.take<float>(ns);
+  b.weight_d = c.take<float>(ns);
+  b.dists_d = c.take<float>(ns);
+  b.blending = c.take<float>(ns);
+  b.xyz_prime = c.take<float>(ns * 3);
   const size_t osz[13] = {0, 0, (size_t)N, ns, (size_t)N * 3, (size_t)N, (size_t)N, ns, (size_t)N * 3,
                           (size_t)N, (size_t)N, ns, (size_t)N};
-  for (int i = 0; i < 13; ++i) out[i] = (i < 2) ? nullptr : c.take<float>(osz[i]);
-  out[0] = rgb_map;
-  out[1] = depth_map;
-  void* fws = c.take<char>(rdrf_workspace_bytes(N, S));
-  RDRF_CHECK(c.ok(), -3, "render_fwd: workspace too small: need %zu have %zu", c.off, ws_bytes);
-  int rc;
+  for (int i = 0; i < 13; ++i) b.out[i] = (i < 2) ? nullptr : c.take<float>(osz[i]);
+  b.out[0] = rgb_map;
+  b.out[1] = depth_map;
+  b.barrier = c.take<unsigned>(64);
+  b.fws_s = c.take<char>(rdrf_workspace_bytes(N, S));
+  b.fws_d = c.take<char>(rdrf_workspace_bytes(N, S));
+  RDRF_CHECK(c.ok(), -3, "render: workspace too small: need %zu have %zu", c.off, ws_bytes);
+  return 0;
+}
+
+static int render_check(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s, const RdrfDynamicParams* PD,
+                        const RdrfFieldCfg* cfg_d, const float* rays, const float* ts, int N, int S, float* rgb_map,
+                        float* depth_map, size_t ws_bytes) {
+  RDRF_CHECK(PS && PD && cfg_s && cfg_d && rays && ts && rgb_map && depth_map && N > 0 && S > 0, -1, "render: bad arguments");
+  RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "render: N * S * 3 must stay below 2^31: render in chunks");
+  RDRF_CHECK(ws_bytes >= rdrf_render_workspace_bytes(N, S), -3, "render: workspace too small");
+  RDRF_CHECK(vm_ok(PS->density, 16, 4) && vm_ok(PS->app, 48, 12) && vm_ok(PD->density, 16, 4) && vm_ok(PD->blending, 16, 4) &&
+             vm_ok(PD->app, 48, 12), -1, "render: only density comps {16,4,4} / app comps {48,12,12} are built");
+  return 0;
+}
+
+/* one cooperative launch (see k_render_fused) */
+extern "C" int rdrf_render_fused_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s, const RdrfDynamicParams* PD,
+                                     const RdrfFieldCfg* cfg_d, const float* rays, const float* ts, int N, int S, float near,
+                                     float far, float* rgb_map, float* depth_map, void* ws, size_t ws_bytes,
+                                     rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;
+  int rc = render_check(PS, cfg_s, PD, cfg_d, rays, ts, N, S, rgb_map, depth_map, ws_bytes);
+  if (rc) return rc;
+  RenderBufs b;
+  rc = carve_render(b, ws, ws_bytes, N, S, rgb_map, depth_map);
+  if (rc) return rc;
+  RenderFusedArgs r;
+  memset(&r, 0, sizeof(r));
+  fill_common(r.as, cfg_s, rays, ts, b.xyz, b.z, b.valid, N, S);
+  r.as.rgb = b.rgb_s; r.as.sigma = b.sigma_s; r.as.weight = b.weight_s; r.as.dists = b.dists_s;
+  rc = ws_carve_fwd(r.as, b.fws_s, rdrf_workspace_bytes(N, S), N, S, nullptr, 0, 0);
+  if (rc) return rc;
+  fill_common(r.ad, cfg_d, rays, ts, b.xyz, b.z, b.valid, N, S);
+  r.ad.rgb = b.rgb_d; r.ad.sigma = b.sigma_d; r.ad.weight = b.weight_d; r.ad.dists = b.dists_d;
+  r.ad.blending = b.blending; r.ad.xyz_prime = b.xyz_prime;
+  rc = ws_carve_fwd(r.ad, b.fws_d, rdrf_workspace_bytes(N, S), N, S, nullptr, 0, 1);
+  if (rc) return rc;
+  fill_static_w(r.ws, PS);
+  fill_dyn_w(r.wd, PD);
+  if (PS->packed_fwd != nullptr) r.as.pk = PS->packed_fwd;
+  else {
+    PackJobs J;
+    static_pack_jobs_fwd(J, PS, cfg_s->static_head);
+    rc = pack_launch(J, (float*)r.as.pk, stream);
+    if (rc) return rc;
+  }
+  if (PD->packed_fwd != nullptr) r.ad.pk = PD->packed_fwd;
+  else {
+    PackJobs J;
+    dyn_pack_jobs_fwd(J, PD);
+    rc = pack_launch(J, (float*)r.ad.pk, stream);
+    if (rc) return rc;
+  }
+  r.comp.rgb_s = b.rgb_s; r.comp.sigma_s = b.sigma_s; r.comp.rgb_d = b.rgb_d; r.comp.sigma_d = b.sigma_d;
+  r.comp.dists = b.dists_d; r.comp.blending = b.blending; r.comp.z = b.z; r.comp.rays = rays;
+  r.comp.N = N; r.comp.S = S; r.comp.ray_type = cfg_d->ray_type; r.comp.add_white_bg = 0;
+  for (int i = 0; i < 13; ++i) r.comp.out[i] = b.out[i];
+  r.near = near; r.far = far; r.barrier = b.barrier;
+  RDRF_HIP(hipMemsetAsync(b.barrier, 0, 256, stream));
+  // one workgroup per CU at most (its LDS holds a whole weight image); fewer when the chunk has fewer units of work
+  const long tiles = ((long)N * S + 31) / 32;
+  const long units = tiles > N ? tiles : N;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    RDRF_HIP(hipGetDevice(&dev));
+    RDRF_HIP(hipGetDeviceProperties(&prop, dev));
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  long g = (units + RDRF_MAXW - 1) / RDRF_MAXW;
+  g = g < 1 ? 1 : (g > ncu ? ncu : g);
+  const size_t lds_bytes = (size_t)(pk::S3_SIZE > pk::K3_SIZE ? (pk::S3_SIZE > pk::K1_SIZE ? pk::S3_SIZE : pk::K1_SIZE)
+                                                            : (pk::K3_SIZE > pk::K1_SIZE ? pk::K3_SIZE : pk::K1_SIZE)) * 4;
+  const void* kern = cfg_s->static_head == RDRF_HEAD_MLP_FEA ? (const void*)k_render_fused<RDRF_HEAD_MLP_FEA>
+                                                            : (const void*)k_render_fused<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING>;
+  RDRF_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  void* kargs[] = {(void*)&r};
+  rdrf_prof_begin("render_fused", stream);
+  hipError_t e = hipLaunchCooperativeKernel(kern, dim3((unsigned)g), dim3(64 * RDRF_MAXW), kargs, (unsigned)lds_bytes, stream);
+  rdrf_prof_end("render_fused", stream);
+  RDRF_CHECK(e == hipSuccess, -5, "render_fused: cooperative launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+/* launch sequence of the per-phase kernels (whole frames: every kernel fills the chip, nothing to gain from fusion) */
+extern "C" int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s, const RdrfDynamicParams* PD,
+                           const RdrfFieldCfg* cfg_d, const float* rays, const float* ts, int N, int S, float near,
+                           float far, float* rgb_map, float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream) {
+  if (N == 0) return 0;
+  int rc = render_check(PS, cfg_s, PD, cfg_d, rays, ts, N, S, rgb_map, depth_map, ws_bytes);
+  if (rc) return rc;
+  RenderBufs b;
+  rc = carve_render(b, ws, ws_bytes, N, S, rgb_map, depth_map);
+  if (rc) return rc;
   if (cfg_d->ray_type == RDRF_RAY_NDC)
-    rc = rdrf_sample_ndc(rays, N, S, near, far, nullptr, cfg_d->aabb, xyz, z, valid, stream);
+    rc = rdrf_sample_ndc(rays, N, S, near, far, nullptr, cfg_d->aabb, b.xyz, b.z, b.valid, stream);
   else
-    rc = rdrf_sample_contract(rays, N, S, near, far, nullptr, nullptr, xyz, z, valid, stream);
+    rc = rdrf_sample_contract(rays, N, S, near, far, nullptr, nullptr, b.xyz, b.z, b.valid, stream);
   if (rc) return rc;
-  rc = rdrf_static_fwd(PS, cfg_s, rays, ts, xyz, z, valid, N, S, rgb_s, sigma_s, weight_s, dists_s,
-                       nullptr, 0, fws, rdrf_workspace_bytes(N, S), stream);
+  rc = rdrf_static_fwd(PS, cfg_s, rays, ts, b.xyz, b.z, b.valid, N, S, b.rgb_s, b.sigma_s, b.weight_s, b.dists_s,
+                       nullptr, 0, b.fws_s, rdrf_workspace_bytes(N, S), stream);
   if (rc) return rc;
-  rc = rdrf_dynamic_fwd(PD, cfg_d, rays, ts, xyz, z, valid, N, S, blending, weight_d, xyz_prime, rgb_d,
-                        sigma_d, dists_d, nullptr, 0, fws, rdrf_workspace_bytes(N, S), stream);
+  rc = rdrf_dynamic_fwd(PD, cfg_d, rays, ts, b.xyz, b.z, b.valid, N, S, b.blending, b.weight_d, b.xyz_prime, b.rgb_d,
+                        b.sigma_d, b.dists_d, nullptr, 0, b.fws_d, rdrf_workspace_bytes(N, S), stream);
   if (rc) return rc;
-  return rdrf_composite_fwd(rgb_s, sigma_s, rgb_d, sigma_d, dists_d, blending, z, rays, N, S,
-                            cfg_d->ray_type, 0, out, stream);
+  return rdrf_composite_fwd(b.rgb_s, b.sigma_s, b.rgb_d, b.sigma_d, b.dists_d, b.blending, b.z, rays, N, S,
+                            cfg_d->ray_type, 0, b.out, stream);
+}
+
+// Measured on MI355X (tools/render_bench.py, Balloon1 stage-0 shape, 240 x 135 frame): whole frame 7.7 ms either way (the
+// kernels ARE the frame time: their HIP-event sum is 7.9 ms); 512-ray chunks 274 us per chunk as a launch sequence -- the
+// seven kernels run back to back, their event times add up to 282 us -- against 378 us for the single cooperative launch
+// (static density at 2 waves per SIMD instead of 6, three serial LDS fills, barrier round trips).  What makes small chunks
+// slow is not the launch sequence but the wave-per-ray density phase: 512 rays = 512 busy waves of 2048.  The launch
+// sequence therefore stays the default at every size; RDRF_RENDER=fused selects the single launch.
+extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
+                               const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
+                               const float* ts, int N, int S, float near, float far, float* rgb_map,
+                               float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream) {
+  if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
+  int rc = render_check(PS, cfg_s, PD, cfg_d, rays, ts, N, S, rgb_map, depth_map, ws_bytes);
+  if (rc) return rc;
+  static int mode = -1;   // RDRF_RENDER = sequence (default) | fused
+  if (mode < 0) {
+    const char* e = getenv("RDRF_RENDER");
+    mode = (e && !strcmp(e, "fused")) ? 1 : 0;
+  }
+  if (mode == 1) return rdrf_render_fused_fwd(PS, cfg_s, PD, cfg_d, rays, ts, N, S, near, far, rgb_map, depth_map, ws, ws_bytes, stream);
+  return rdrf_render_sequence_fwd(PS, cfg_s, PD, cfg_d, rays, ts, N, S, near, far, rgb_map, depth_map, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -160,9 +160,11 @@ def OctreeRender_trilinear_fast(rays, ts, timeembeddings, tensorf, xyz_sampled, 
 
 
 @torch.no_grad()
-def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc"):
-    """No-grad render of a ray chunk through ONE C-ABI call (rdrf_render_fwd): the loop body of
-    renderer.py:740-812.  Returns (rgb_map_full[N,3], depth_map_full[N])."""
+def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc", mode="auto"):
+    """No-grad render of a ray chunk through ONE C-ABI call: the loop body of renderer.py:740-812.
+    mode "auto" (rdrf_render_fwd: the per-phase launch sequence unless RDRF_RENDER=fused), "fused" (rdrf_render_fused_fwd:
+    one cooperative launch) or "sequence" (rdrf_render_sequence_fwd); all three give the same bits.
+    Returns (rgb_map_full[N,3], depth_map_full[N])."""
     from .fields import _attach_packed, _cfg_struct, _dynamic_struct, _static_struct
     L.require_device(rays, ts)
     rays, ts = L.f32c(rays), L.f32c(ts)
@@ -179,10 +181,10 @@ def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc")
     _attach_packed(tensorf, PD, pd_list, False, True)
     cs, cd = _cfg_struct(tensorf_static, ray_type), _cfg_struct(tensorf, ray_type)
     near, far = tensorf.near_far
-    L.check(L.lib.rdrf_render_fwd(C.byref(PS), C.byref(cs), C.byref(PD), C.byref(cd), L.ptr(rays),
-                                  L.ptr(ts), N, S, C.c_float(near), C.c_float(far), L.ptr(rgb),
-                                  L.ptr(depth), L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(rays)),
-            "rdrf_render_fwd")
+    fn = {"auto": L.lib.rdrf_render_fwd, "fused": L.lib.rdrf_render_fused_fwd, "sequence": L.lib.rdrf_render_sequence_fwd}[mode]
+    L.check(fn(C.byref(PS), C.byref(cs), C.byref(PD), C.byref(cd), L.ptr(rays), L.ptr(ts), N, S, C.c_float(near),
+               C.c_float(far), L.ptr(rgb), L.ptr(depth), L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(rays)),
+            "rdrf_render_" + mode)
     return rgb, depth
 
 

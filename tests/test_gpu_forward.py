@@ -162,6 +162,31 @@ def test_fused_render_matches_unfused():
     assert_close(depth, g["ce.depth_map_full"], "render depth")
 
 
+@pytest.mark.parametrize("case,N,S", [("ndc_relu", 32, 13), ("contract_relu_te", 16, 14), ("ndc_relu", 777, 115), ("contract_relu_te", 2100, 37)])
+def test_fused_render_is_bit_identical_to_the_launch_sequence(case, N, S):
+    """rdrf_render_fused_fwd (one cooperative launch: sampler, both density phases, both appearance phases and the
+    compositor behind grid-wide barriers) runs the device bodies of the per-phase kernels: same bits as
+    rdrf_render_sequence_fwd, for both ray types / static heads, a batch smaller than the grid and one that wraps it,
+    ragged last tiles; and the same reference values as the unfused path on the golden rays."""
+    import rodynrf
+    from _gpu_util import fields_from_case, make_rays
+    g, st, dy, _ = fields_from_case(case)
+    rt = str(g["meta.ray_type"])
+    if N == g["rays"].shape[0]:
+        rays, ts = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["ts"]).cuda()
+    else:
+        rays, ts = (t.cuda() for t in make_rays(N, 3, rt))
+    a = rodynrf.render_rays(st, dy, rays, ts, N_samples=S, ray_type=rt, mode="sequence")
+    for _ in range(3):   # repeated: the barrier word, counters and LDS images are re-initialised by every launch
+        b = rodynrf.render_rays(st, dy, rays, ts, N_samples=S, ray_type=rt, mode="fused")
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    c = rodynrf.render_rays(st, dy, rays, ts, N_samples=S, ray_type=rt, mode="auto")
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    if N == g["rays"].shape[0] and S == g["z"].shape[1] and "jitter" not in g:
+        assert_close(b[0], g["ce.rgb_map_full"], "fused rgb")
+        assert_close(b[1], g["ce.depth_map_full"], "fused depth", atol=256.0 * 2.0 ** -22 if rt == "contract" else 0.0)
+
+
 def test_render_frame_matches_oracle_pipeline():
     """whole-frame driver: device ray generation -> fused render, one launch sequence vs chunks of
     100 rays vs the oracle's generate_rays -> sampleXYZ -> fields -> raw2outputs on the CPU."""
