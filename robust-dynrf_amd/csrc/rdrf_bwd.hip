@@ -1423,8 +1423,15 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
         }
         f32x16 accX[2];  // d(X0) of the density and blending heads
         acc_zero<2>(accX);
+        // head liveness (wave-uniform): a head whose output no loss reaches is not differentiated -- the reference's
+        // autograd never visits that subgraph either (passes B-D of the trainer: no term depends on the blending head
+        // before the late mask terms) -- so its 160 MFMAs per tile, its dz / d(feature) rows, its scatter set and its
+        // dW products (host side) all drop out
+        const bool live_d = FEAT ? a.g_sigma != nullptr : (a.g_sigma != nullptr || a.g_weight != nullptr);
+        const bool live_b = a.g_blending != nullptr;
 #pragma unroll
         for (int head = 0; head < 2; ++head) {
+          if (!(head == 0 ? live_d : live_b)) continue;
           const float gfh = head == 0 ? g_fd : g_fb;
           float Hh[32], dzh[32];
           load_rows<32>(svb, head == 0 ? sv::K1_HD : sv::K1_HB, Hh, s, h);
@@ -2089,10 +2096,28 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
       P.count = R.count; P.ntiles = R.ntiles;
       for (int i = 0; i < D.n; ++i) P.job[i] = D.j[i];
     };
+    auto find_blk = [&](int src, int row) {
+      for (int i = 0; i < P.nblk; ++i)
+        if (P.blk_meta[i] == ((src << 16) | row)) return i;
+      return -1;
+    };
     auto flush = [&]() -> int {
       int tot = 0;
       for (int w = 0; w < DW2_WAVES; ++w) tot += P.nprod[w];
       if (tot == 0) return 0;
+      {  // one contiguous run per source: a pruned head leaves a hole in the row ranges (its dz / activation rows are
+         // not part of any product); the hole's blocks are staged unused so that the two-run addressing holds
+        for (int src = 0; src < 2; ++src) {
+          int lo = 1 << 30, hi = -1;
+          for (int i = 0; i < P.nblk; ++i)
+            if ((P.blk_meta[i] >> 16) == src) { const int r = P.blk_meta[i] & 0xffff; lo = r < lo ? r : lo; hi = r > hi ? r : hi; }
+          for (int r = lo; r < hi; r += 32)
+            if (find_blk(src, r) < 0) {
+              RDRF_CHECK(P.nblk < DW2_MAX_BLK, -2, "dw: %d staged blocks are not enough to bridge the row ranges of this plan", DW2_MAX_BLK);
+              P.blk_meta[P.nblk++] = (src << 16) | r;
+            }
+        }
+      }
       {  // stage order = (source, first row) order; runs of consecutive rows become segments
         int order[DW2_MAX_BLK], rank[DW2_MAX_BLK], meta[DW2_MAX_BLK];
         for (int i = 0; i < P.nblk; ++i) order[i] = i;
@@ -2128,11 +2153,6 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
       rdrf_prof_end(name, stream);
       RDRF_HIP(hipGetLastError());
       return 0;
-    };
-    auto find_blk = [&](int src, int row) {
-      for (int i = 0; i < P.nblk; ++i)
-        if (P.blk_meta[i] == ((src << 16) | row)) return i;
-      return -1;
     };
     reset();
     int nprods = 0;
@@ -2419,7 +2439,7 @@ static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const Rd
 
 // dW jobs of the dynamic field's density phase (warp MLP, density / blending heads)
 static void add_density_phase_dw(DwJobs& D, const float* grows1, const float* act1, const RdrfDynamicParams* G,
-                                 int T1) {
+                                 int T1, bool live_d = true, bool live_b = true) {
   // layer3: [X0 | tout]
   dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_DZ3, 2, 64, 0, act1, sv::K1_ROWS, 93, 93, G->l3w, G->l3b, nullptr, T1);
   dw_blk(D, sv::K1_X0, SEG_WARP3_X0, 0);
@@ -2432,13 +2452,18 @@ static void add_density_phase_dw(DwJobs& D, const float* grows1, const float* ac
   dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 3, 0, act1, sv::K1_ROWS, 64, 64, G->l5w, G->l5b, nullptr, T1);
   dw_blk(D, sv::K1_H4, SEG_IDENT, 0);
   dw_blk(D, sv::K1_H4 + 32, SEG_IDENT, 32);
-  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 3, act1, sv::K1_ROWS, 64, 64, G->dw2, G->db2, nullptr, T1);
-  dw_blk(D, sv::K1_HD, SEG_IDENT, 0);
-  dw_blk(D, sv::K1_HD + 32, SEG_IDENT, 32);
-  dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, act1, sv::K1_ROWS, 64, 64, G->bw2, G->bb2, nullptr, T1);
-  dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
-  dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
+  if (live_d) {
+    dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 3, act1, sv::K1_ROWS, 64, 64, G->dw2, G->db2, nullptr, T1);
+    dw_blk(D, sv::K1_HD, SEG_IDENT, 0);
+    dw_blk(D, sv::K1_HD + 32, SEG_IDENT, 32);
+  }
+  if (live_b) {
+    dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, act1, sv::K1_ROWS, 64, 64, G->bw2, G->bb2, nullptr, T1);
+    dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
+    dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
+  }
   for (int head = 0; head < 2; ++head) {
+    if (!(head ? live_b : live_d)) continue;   // dead head: its dz rows were not written (k_dyn_density_bwd<0>)
     dw_add(D, grows1, sv::K1G_ROWS, head ? sv::K1G_DZB : sv::K1G_DZD, 2, 64, 0, act1, sv::K1_ROWS, 152, 152,
            head ? G->bw1 : G->dw1, head ? G->bb1 : G->db1, nullptr, T1);
     const int f0 = head ? sv::K1_FB : sv::K1_FD;
@@ -2621,19 +2646,25 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
         if (rc) return rc;
       }
     } else {
-      ScatterArgs sa;
-      fill_scatter_common(sa, a);
-      sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;
-      sa.nsets = 2;
-      sa.rows = b.grows1; sa.stride = sv::K1G_ROWS; sa.row0[0] = sv::K1G_DFD; sa.row0[1] = sv::K1G_DFB;
-      sa.xw = a.sp.xw;
-      sa.dxw = b.dxw; sa.dxw_accumulate = 1;
-      { int rc_ = launch_scatter("scatter_dyn_density", k_scatter<4, 1, 9>, sa, (long)t1, stream); if (rc_) return rc_; }
+      // a head without an upstream gradient (passes B-D of the trainer carry none for the blending head before the late
+      // mask terms) has d(features) == 0: its factor set is left out of the launch instead of being walked with zeros
+      const bool has_d = g_sigma != nullptr || g_weight != nullptr, has_b = g_blending != nullptr;
+      if (has_d || has_b) {
+        ScatterArgs sa;
+        fill_scatter_common(sa, a);
+        sa.nsets = 0;
+        if (has_d) { sa.vm[sa.nsets] = P->density; sa.gvm[sa.nsets] = G->density; sa.row0[sa.nsets] = sv::K1G_DFD; ++sa.nsets; }
+        if (has_b) { sa.vm[sa.nsets] = P->blending; sa.gvm[sa.nsets] = G->blending; sa.row0[sa.nsets] = sv::K1G_DFB; ++sa.nsets; }
+        sa.rows = b.grows1; sa.stride = sv::K1G_ROWS;
+        sa.xw = a.sp.xw;
+        sa.dxw = b.dxw; sa.dxw_accumulate = 1;
+        { int rc_ = launch_scatter("scatter_dyn_density", k_scatter<4, 1, 9>, sa, (long)t1, stream); if (rc_) return rc_; }
+      }
     }
     RDRF_LAUNCH("dyn_warp_bwd", (k_dyn_density_bwd<1, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((N + TB_RPB - 1) / TB_RPB), dim3(128), stream, ts, w,
                 N, b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
-    add_density_phase_dw(D, b.grows1, a.sp.act1, G, (int)t1);
+    add_density_phase_dw(D, b.grows1, a.sp.act1, G, (int)t1, g_sigma != nullptr || g_weight != nullptr, g_blending != nullptr);
   }
   rc = dw_launch(D, stream, "dw_dyn");
   return rc;
@@ -2790,9 +2821,10 @@ extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfF
   if (g_density != nullptr || g_blending != nullptr) {
     ScatterArgs sa;
     fill_scatter_common(sa, a);
-    sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;
-    sa.nsets = 2;
-    sa.rows = b.grows1; sa.stride = sv::K1G_ROWS; sa.row0[0] = sv::K1G_DFD; sa.row0[1] = sv::K1G_DFB;
+    sa.nsets = 0;   // live heads only (see k_dyn_density_bwd<0>)
+    if (g_density != nullptr) { sa.vm[sa.nsets] = P->density; sa.gvm[sa.nsets] = G->density; sa.row0[sa.nsets] = sv::K1G_DFD; ++sa.nsets; }
+    if (g_blending != nullptr) { sa.vm[sa.nsets] = P->blending; sa.gvm[sa.nsets] = G->blending; sa.row0[sa.nsets] = sv::K1G_DFB; ++sa.nsets; }
+    sa.rows = b.grows1; sa.stride = sv::K1G_ROWS;
     sa.xw = a.sp.xw;
     sa.dxw = b.dxw; sa.dxw_accumulate = 1;
     { int rc_ = launch_scatter("feat_scatter_dyn_density", k_scatter<4, 1, 9>, sa, (long)Np, stream); if (rc_) return rc_; }
@@ -2800,7 +2832,7 @@ extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfF
   RDRF_LAUNCH("feat_dyn_warp_bwd", (k_dyn_density_bwd<1, true>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
   RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((M + TB_RPB - 1) / TB_RPB), dim3(128), stream, t, w, M,
               b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
-  add_density_phase_dw(D, b.grows1, a.sp.act1, G, Np);
+  add_density_phase_dw(D, b.grows1, a.sp.act1, G, Np, g_density != nullptr, g_blending != nullptr);
   return dw_launch(D, stream, "feat_dw_dyn");
 }
 

@@ -116,7 +116,10 @@ class _CompositeFn(torch.autograd.Function):
         # the dynamic field gets no gradient at all from it
         need[1] = need[1] and have((0, 1, 2, 3, 4, 5, 6, 7, 12))
         need[3] = need[3] and have((0, 1, 2, 3, 8, 9, 10, 11, 12))
-        need[5] = need[5] and have((0, 1, 2, 3, 8, 9, 10, 11, 12))
+        # blending only enters T_full / weights_full (renderer.py:206-262): the dynamic-only maps (8..11) do not depend
+        # on it, so a loss on depth_map_d / weights_d alone (passes B-D of the trainer) sends the blending head NO
+        # gradient -- and the field's backward then leaves that head, its scatter set and its dW products out
+        need[5] = need[5] and have((0, 1, 2, 3, 12))
         g_in = L.zeros_like_many(ins, need)   # one fill for the (up to eight) gradient tensors
         ga = (C.c_void_p * 13)(*[0 if g is None else g.data_ptr() for g in g_out])
         gi = (C.c_void_p * 8)(*[0 if g is None else g.data_ptr() for g in g_in])
