@@ -197,18 +197,33 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
             table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}
             tot_ms += msk / NP
     L.lib.rdrf_prof_enable(0)
+    # per-launch averages of the two kernels whose work follows head liveness (the blending head's 19 584 FLOP per
+    # sample is differentiated in `n_both_` of the dynamic backward launches, the appearance dW belongs to pass A)
+    nb_ = table.get("dw_dyn", {}).get("launches_per_step", 0.0)
+    n_both_ = min(nb_, 2.0 if trainer.it >= cfg.get("upsamp_list", [0, 0, 0, 1 << 30])[3] else 1.0)
+    if nb_ > 0:
+        flops["dyn_heads_bwd"] = ns * (19584 + 19584 * n_both_ / nb_)
+        flops["dw_dyn"] = ns * (26496 + 19584 + 19584 * n_both_ / nb_ + f_d * F_DYN_APP / nb_)
     step_flops = sum(flops[k] * table[k]["launches_per_step"] for k in table if k in flops)
     # k_dw (weight-gradient GEMMs; launches dw_dyn / dw_static / dw_sf): streams the saved activation rows and
     # the d(pre-activation) rows of every 32-sample tile; algorithmic bytes = UNIQUE rows x 128 B
     t1 = rays_per_gpu * ((cfg["n_samples"] + 31) // 32)
     t3d, t3s = (ns * f_d + 31) // 32, (ns * f_s + 31) // 32
-    dw_bytes = {"dw_dyn": (864 * t1 + 960 * t3d) * 128.0, "dw_static": 864 * t3s * 128.0, "dw_sf": 480 * t1 * 128.0}
-    dw_keys = [k for k in dw_bytes if k in table]
+    # head liveness (csrc/rdrf_bwd.hip): the blending head is differentiated only in the passes whose loss reaches it --
+    # pass A, and pass B once the late mask terms are on (iteration >= upsamp_list[3]); the other dynamic backward
+    # launches stage 640 instead of 864 row blocks per density tile and scatter one factor set instead of two.
+    # The appearance rows (960 per compacted tile) belong to pass A alone.
+    n_dyn_bwd = table.get("dw_dyn", {}).get("launches_per_step", 0.0)
+    n_both = min(n_dyn_bwd, 2.0 if trainer.it >= cfg.get("upsamp_list", [0, 0, 0, 1 << 30])[3] else 1.0)
+    dw_step_bytes = {"dw_dyn": ((n_both * 864 + (n_dyn_bwd - n_both) * 640) * t1 + 960 * t3d) * 128.0,
+                     "dw_static": 864 * t3s * 128.0 * table.get("dw_static", {}).get("launches_per_step", 0.0),
+                     "dw_sf": 480 * t1 * 128.0 * table.get("dw_sf", {}).get("launches_per_step", 0.0)}
+    dw_keys = [k for k in dw_step_bytes if k in table]
     out = {}
     if dw_keys:
         dw_launch = sum(table[k]["launches_per_step"] for k in dw_keys)
         dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
-        dw_b = sum(dw_bytes[k] * table[k]["launches_per_step"] for k in dw_keys)
+        dw_b = sum(dw_step_bytes[k] for k in dw_keys)
         dw_f = sum(flops[k] * table[k]["launches_per_step"] for k in dw_keys)
         tr = pmc_traffic("k_dw2")
         dw_entry = {
@@ -224,13 +239,14 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
     # the gradient factors (2B), read the d(feature) row entries (4 B per component); B = 1728 B for a
     # 72-component family, 5184 B for appearance.  The bytes are L2 / Infinity-Cache resident, so `achieved` may
     # exceed the HBM `traffic`; the kernel is bound by the L2 atomic request rate.
-    sc_bytes = {"scatter_dyn_density": ns * valid_frac * 2 * (3 * 1728 + 288.0),
-                "scatter_dyn_app": ns * f_d * (3 * 5184 + 864.0),
-                "scatter_static_app": ns * f_s * (3 * 1728 + 288.0)}
-    sc_keys = [k for k in sc_bytes if k in table]
+    n_sc = table.get("scatter_dyn_density", {}).get("launches_per_step", 0.0)
+    sc_step_bytes = {"scatter_dyn_density": (n_both * 2 + (n_sc - min(n_sc, n_both)) * 1) * ns * valid_frac * (3 * 1728 + 288.0),
+                     "scatter_dyn_app": ns * f_d * (3 * 5184 + 864.0) * table.get("scatter_dyn_app", {}).get("launches_per_step", 0.0),
+                     "scatter_static_app": ns * f_s * (3 * 1728 + 288.0) * table.get("scatter_static_app", {}).get("launches_per_step", 0.0)}
+    sc_keys = [k for k in sc_step_bytes if k in table]
     sc_ms = sum(table[k]["ms_per_step"] for k in sc_keys)
     sc_launch = sum(table[k]["launches_per_step"] for k in sc_keys)
-    sc_b = sum(sc_bytes[k] * table[k]["launches_per_step"] for k in sc_keys)
+    sc_b = sum(sc_step_bytes[k] for k in sc_keys)
     tr = pmc_traffic("void k_scatter<4; 1; 9>")
     den_us = table.get("scatter_dyn_density", {}).get("avg_us")
     atom = pmc_value("sq_counters", "void k_scatter<4; 1; 9>", "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
