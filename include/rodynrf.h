@@ -107,6 +107,9 @@ const char* rdrf_last_error(void);
 
 /* Bytes of workspace a forward/backward call of either field needs for N rays x S samples. */
 size_t rdrf_workspace_bytes(int N, int S);
+/* The forward calls alone (inference: rdrf_*_fwd with saved == NULL, rdrf_render_*) need only this much of it
+ * (weight pack area, compaction list, warped coordinates: ~16 B per sample + 4 MB instead of ~6 KB per sample). */
+size_t rdrf_forward_workspace_bytes(int N, int S);
 /* Training mode: a forward call given a `saved` buffer of this size (kind 0 = static field,
  * 1 = dynamic field, 2 = scene flow) stores the activations its backward needs; the matching
  * *_bwd call must receive the same buffer untouched.  saved == NULL => inference, nothing kept. */

@@ -61,6 +61,8 @@ def _load():
     lib.rdrf_last_error.restype = C.c_char_p
     lib.rdrf_workspace_bytes.restype = C.c_size_t
     lib.rdrf_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.rdrf_forward_workspace_bytes.restype = C.c_size_t
+    lib.rdrf_forward_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_saved_bytes.restype = C.c_size_t
     lib.rdrf_saved_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, args in (("rdrf_features_saved_bytes", [C.c_int, C.c_int]),
@@ -96,7 +98,7 @@ lib = _load()
 
 # every symbol include/rodynrf.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "rdrf_abi_version", "rdrf_last_error", "rdrf_workspace_bytes", "rdrf_saved_bytes",
+    "rdrf_abi_version", "rdrf_last_error", "rdrf_workspace_bytes", "rdrf_forward_workspace_bytes", "rdrf_saved_bytes",
     "rdrf_generate_rays",
     "rdrf_generate_rays_bwd", "rdrf_generate_rays_uv", "rdrf_generate_rays_uv_bwd", "rdrf_sample_ndc", "rdrf_sample_contract", "rdrf_sample_bwd",
     "rdrf_static_fwd", "rdrf_static_bwd", "rdrf_dynamic_fwd", "rdrf_dynamic_bwd",

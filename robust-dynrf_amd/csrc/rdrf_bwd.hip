@@ -2257,10 +2257,15 @@ static void fill_bwd_common(BwdArgs& a, const RdrfFieldCfg* cfg, const float* ra
   a.static_head = cfg->static_head;
 }
 
+// forward calls (either field, scene flow): pack area + counter + tout + xw + list -- what an inference-only caller needs
+extern "C" size_t rdrf_forward_workspace_bytes(int N, int S) {
+  const size_t ns = (size_t)N * S;
+  return (size_t)PACK_AREA_FLOATS * 4 + 256 + (size_t)N * 32 * 4 + ns * 3 * 4 + ns * 4 + (1 << 12);
+}
+
 extern "C" size_t rdrf_workspace_bytes(int N, int S) {
   size_t ns = (size_t)N * S, t1 = (size_t)N * ((S + 31) / 32), t3 = (ns + 31) / 32;
-  // forward: pack area + counter + tout + xw + list
-  size_t fwd = (size_t)PACK_AREA_FLOATS * 4 + 256 + (size_t)N * 32 * 4 + ns * 3 * 4 + ns * 4 + (1 << 12);
+  size_t fwd = rdrf_forward_workspace_bytes(N, S);
   // backward: pack area + dz rows of both phases + coordinate-gradient buffers + d(tout)
   size_t bwd = (size_t)PACK_AREA_FLOATS * 4 + t1 * sv::K1G_ROWS * 32 * 4 + t3 * sv::K3G_ROWS * 32 * 4 +
                ns * 3 * 4 * 2 + (size_t)N * 32 * 4 + (1 << 14);

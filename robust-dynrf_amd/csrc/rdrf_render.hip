@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_render_fused(RenderFusedArgs
 extern "C" size_t rdrf_render_workspace_bytes(int N, int S) {
   const size_t ns = (size_t)N * S;
   // xyz, xyz_prime, rgb_s, rgb_d (3 floats) + 12 scalar planes + valid + 13 outputs + both fields' workspaces
-  return ns * 4 * (3 * 4 + 12) + ns + (size_t)N * 4 * 16 + 2 * rdrf_workspace_bytes(N, S) + (1 << 14);
+  return ns * 4 * (3 * 4 + 12) + ns + (size_t)N * 4 * 16 + 2 * rdrf_forward_workspace_bytes(N, S) + (1 << 14);
 }
 
 struct RenderBufs {
@@ -121,8 +121,8 @@ static int carve_render(RenderBufs& b, void* ws, size_t ws_bytes, int N, int S, 
   b.out[0] = rgb_map;
   b.out[1] = depth_map;
   b.barrier = c.take<unsigned>(64);
-  b.fws_s = c.take<char>(rdrf_workspace_bytes(N, S));
-  b.fws_d = c.take<char>(rdrf_workspace_bytes(N, S));
+  b.fws_s = c.take<char>(rdrf_forward_workspace_bytes(N, S));
+  b.fws_d = c.take<char>(rdrf_forward_workspace_bytes(N, S));
   RDRF_CHECK(c.ok(), -3, "render: workspace too small: need %zu have %zu", c.off, ws_bytes);
   return 0;
 }
@@ -154,12 +154,12 @@ extern "C" int rdrf_render_fused_fwd(const RdrfStaticParams* PS, const RdrfField
   memset(&r, 0, sizeof(r));
   fill_common(r.as, cfg_s, rays, ts, b.xyz, b.z, b.valid, N, S);
   r.as.rgb = b.rgb_s; r.as.sigma = b.sigma_s; r.as.weight = b.weight_s; r.as.dists = b.dists_s;
-  rc = ws_carve_fwd(r.as, b.fws_s, rdrf_workspace_bytes(N, S), N, S, nullptr, 0, 0);
+  rc = ws_carve_fwd(r.as, b.fws_s, rdrf_forward_workspace_bytes(N, S), N, S, nullptr, 0, 0);
   if (rc) return rc;
   fill_common(r.ad, cfg_d, rays, ts, b.xyz, b.z, b.valid, N, S);
   r.ad.rgb = b.rgb_d; r.ad.sigma = b.sigma_d; r.ad.weight = b.weight_d; r.ad.dists = b.dists_d;
   r.ad.blending = b.blending; r.ad.xyz_prime = b.xyz_prime;
-  rc = ws_carve_fwd(r.ad, b.fws_d, rdrf_workspace_bytes(N, S), N, S, nullptr, 0, 1);
+  rc = ws_carve_fwd(r.ad, b.fws_d, rdrf_forward_workspace_bytes(N, S), N, S, nullptr, 0, 1);
   if (rc) return rc;
   fill_static_w(r.ws, PS);
   fill_dyn_w(r.wd, PD);
@@ -224,11 +224,14 @@ extern "C" int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFi
   else
     rc = rdrf_sample_contract(rays, N, S, near, far, nullptr, nullptr, b.xyz, b.z, b.valid, stream);
   if (rc) return rc;
+  // (a side stream for the static density phase under the dynamic field's density kernel does not overlap: the MLP kernels
+  // hold all 512 VGPRs of every SIMD, so no other wave becomes resident; measured)
+  const size_t fwb = rdrf_forward_workspace_bytes(N, S);
   rc = rdrf_static_fwd(PS, cfg_s, rays, ts, b.xyz, b.z, b.valid, N, S, b.rgb_s, b.sigma_s, b.weight_s, b.dists_s,
-                       nullptr, 0, b.fws_s, rdrf_workspace_bytes(N, S), stream);
+                       nullptr, 0, b.fws_s, fwb, stream);
   if (rc) return rc;
   rc = rdrf_dynamic_fwd(PD, cfg_d, rays, ts, b.xyz, b.z, b.valid, N, S, b.blending, b.weight_d, b.xyz_prime, b.rgb_d,
-                        b.sigma_d, b.dists_d, nullptr, 0, b.fws_d, rdrf_workspace_bytes(N, S), stream);
+                        b.sigma_d, b.dists_d, nullptr, 0, b.fws_d, fwb, stream);
   if (rc) return rc;
   return rdrf_composite_fwd(b.rgb_s, b.sigma_s, b.rgb_d, b.sigma_d, b.dists_d, b.blending, b.z, rays, N, S,
                             cfg_d->ray_type, 0, b.out, stream);

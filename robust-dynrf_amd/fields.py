@@ -226,8 +226,8 @@ class _StaticFn(torch.autograd.Function):
         sigma = torch.empty(N, S, device=dev)
         weight = torch.empty(N, S, device=dev)
         dists = torch.empty(N, S, device=dev)
-        ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
         saved, sbytes = _alloc_saved(ctx, 0, N, S, dev)
+        ws = L.workspace(dev, (L.lib.rdrf_workspace_bytes if saved is not None else L.lib.rdrf_forward_workspace_bytes)(N, S))
         P = _static_struct(params)
         _attach_packed(field, P, params, False, False)
         cfg = _cfg_struct(field, ray_type)
@@ -289,8 +289,8 @@ class _DynamicFn(torch.autograd.Function):
         rgb = torch.empty(N, S, 3, device=dev)
         xyz_prime = torch.empty(N, S, 3, device=dev)
         sigma, weight, dists, blending = (torch.empty(N, S, device=dev) for _ in range(4))
-        ws = L.workspace(dev, L.lib.rdrf_workspace_bytes(N, S))
         saved, sbytes = _alloc_saved(ctx, 1, N, S, dev)
+        ws = L.workspace(dev, (L.lib.rdrf_workspace_bytes if saved is not None else L.lib.rdrf_forward_workspace_bytes)(N, S))
         P = _dynamic_struct(params)
         _attach_packed(field, P, params, False, True)
         cfg = _cfg_struct(field, ray_type)
