@@ -41,6 +41,15 @@ def elementwise_excess(a, b, elem_rtol, elem_atol_frac, atol=0.0):
     return float(((a - b).abs() / (elem_rtol * b.abs() + elem_atol_frac * scale + atol)).max())
 
 
+def record_margin(name, ratio):
+    """RDRF_MARGINS=<file>: append `test id <tab> check <tab> error / tolerance` for every tolerance check, so that one run of
+    the suite shows how far each comparison sits from its bound (tools/margins.py prints the worst ones)"""
+    path = os.environ.get("RDRF_MARGINS")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{name}\t{ratio:.4f}\n")
+
+
 def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None, atol=0.0, elem=None):
     """max-norm check: max|a-b| <= rtol * max|b| (* atol_scale) + atol.  elem = (elem_rtol, elem_atol_frac)
     adds the element-wise check |a-b| <= elem_rtol |b| + elem_atol_frac max|b| for EVERY element: small
@@ -55,10 +64,12 @@ def assert_close(a, b, name="", rtol=RTOL, atol_scale=1.0, mask=None, atol=0.0, 
         return
     scale = max(float(b.abs().max()), 1e-30)
     err = float((a - b).abs().max())
+    record_margin(name, err / (rtol * scale * atol_scale + atol + 1e-30))
     assert err <= rtol * scale * atol_scale + atol + 1e-30, (
         f"{name}: max abs err {err:.3e} > {rtol * atol_scale:.1e} * max|ref| ({scale:.3e})")
     if elem is not None:
         ex = elementwise_excess(a, b, elem[0], elem[1], atol)
+        record_margin(name + " (element-wise)", ex)
         assert ex <= 1.0, (f"{name}: element-wise |err| exceeds {elem[0]:.0e} |ref| + {elem[1]:.0e} max|ref| by a "
                            f"factor {ex:.2f}")
 

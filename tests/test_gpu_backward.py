@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import CASES, assert_close, elementwise_excess
+from _util import CASES, assert_close, elementwise_excess, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -171,10 +171,12 @@ def _midsize_once(seed, loss_kind="full", rt="ndc", N=96, S=70, grid=(40, 44, 26
         scale = max(float(b.abs().max()), 1e-30)
         err = (a - b).abs()
         ok_max = bool((err <= rtol * scale + cond).all())
+        record_margin(name, float((err / (rtol * scale + cond)).max()))
         ex = 0.0
         if elem is not None:
             ex = float((err / (elem[0] * b.abs() + elem[1] * scale + cond)).max())
             worst_el = max(worst_el, ex)
+            record_margin(name + " (element-wise)", ex)
         if not ok_max or ex > 1.0:
             bad.append(f"{name}: max abs err {float(err.max()):.3e} vs {rtol:.0e} * max|ref| ({scale:.3e}) + conditioning "
                        f"{float(cond.max()):.3e}; element-wise excess {ex:.2f}")

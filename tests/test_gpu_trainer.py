@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import assert_close
+from _util import assert_close, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -190,6 +190,7 @@ def test_trainer_step_gradient_matches_oracle_step(name, it):
         cond = (2.0 * (b - ref64.double()).abs()).clamp(max=rtol * float(b.abs().max()))
         err = (a - b).abs()
         tol = rtol * float(b.abs().max()) + cond
+        record_margin(name, float((err / tol.clamp_min(1e-30)).max()))
         if not bool((err <= tol).all()):
             i = int((err - tol).argmax())
             bad.append(f"{name}: |err| {float(err.flatten()[i]):.3e} > {rtol:.0e} * max|ref| ({float(b.abs().max()):.3e}) + "
