@@ -29,6 +29,7 @@ in HBM.  Losses keep every term that decides which hot-path outputs carry gradie
 per-iteration host sync (``.item()``): losses and the per-frame medians stay on the device.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -257,20 +258,61 @@ def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_g
     return o_s, o_d, outs, xyz
 
 
+def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
+    """Several ray-passes whose inputs do not depend on each other's outputs (passes A-D of an iteration: the rays of
+    C / D come from the data's optical flow, not from pass A), evaluated as ONE value-only static forward over all their
+    rays and one dynamic forward per GROUP of passes (lists of consecutive pass indices with the same gradient
+    liveness, so that a batched call prunes what each of its passes would).  Same arithmetic and the same draw order
+    (jitter, coin per pass, in pass order) as one ray_pass per entry; the persistent MLP kernels see 3-4x the tiles per
+    launch (tail quantisation: 2.4 -> 3 tile rounds per wave becomes 7.3 -> 8) and fill their LDS images once.
+    Returns one (o_s, o_d, outs, xyz) per pass; the per-pass tensors are views (unbind) of the batched outputs."""
+    P, N, dev = len(rays_list), rays_list[0].shape[0], rays_list[0].device
+    samples, coins = [], []
+    for rays in rays_list:
+        jit, jit_o = rng.jitter(n_samples, ray_type, dev)
+        samples.append(sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=True, jitter=jit, jitter_outer=jit_o))
+        coins.append(rng.coin())
+    rays_c, ts_c = torch.cat(rays_list), torch.cat(ts_list)
+    xyz_c, z_c, valid_c = (torch.cat([sm[i] for sm in samples]) for i in range(3))
+    with torch.no_grad():
+        o_s = st(rays_c, ts_c, None, xyz_c, z_c, valid_c, is_train=True, ray_type=ray_type)
+    split = lambda t, n: t.view(n, N, *t.shape[1:]).unbind(0)
+    s_parts = [None if o is None else split(o, P) for o in o_s]
+    o_ds = [None] * P
+    for g in groups:
+        assert list(g) == list(range(g[0], g[0] + len(g)))
+        sl = slice(g[0] * N, (g[0] + len(g)) * N)
+        o_d = dy(rays_c[sl], ts_c[sl], None, xyz_c[sl], z_c[sl], valid_c[sl], is_train=True, ray_type=ray_type)
+        d_parts = [None if o is None else split(o, len(g)) for o in o_d]   # unbind: the backward stacks the parts' gradients
+        for k, p in enumerate(g):
+            o_ds[p] = tuple(None if d is None else d[k] for d in d_parts)
+    out = []
+    for p in range(P):
+        o_sp = tuple(None if sp is None else sp[p] for sp in s_parts)
+        o_d = o_ds[p]
+        outs = raw2outputs(o_sp[6], o_sp[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], rays_list[p], is_train=True,
+                           ray_type=ray_type, add_white_bg=coins[p])
+        out.append((o_sp, o_d, outs, samples[p][0]))
+    return out
+
+
 def masked_mean(x, m):
     return (x * m).sum() / (m.sum() + 1e-8)
 
 
 class Trainer:
     def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False,
-                 dp_mode="allreduce", lr_pose=3e-3, dp_exact_stats=False):
+                 dp_mode="allreduce", lr_pose=3e-3, dp_exact_stats=False, batch_passes=None):
         """dead_work: also run the dynamic-field forward of passes E / P3 / P4, which the reference computes
         although nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical.
         dp_exact_stats (data-parallel runs): the batch statistics of the losses -- the mask sums of the masked means
         (train.py:1391-1394, 1522-1524, 1828-1832, 1277-1291) and the per-frame medians / deviations / ray counts of
         the monocular depth losses (train.py:797-807) -- are those of the WHOLE batch (one all-reduce of ~30 pairs of
         floats per loss group, one all-gather of the per-ray depths), so that an N-rank run optimises exactly the
-        single-process objective; off: per-shard statistics."""
+        single-process objective; off: per-shard statistics.
+        batch_passes (default on; RDRF_BATCH_PASSES=0): passes A-D share one static forward and passes of equal gradient
+        liveness one dynamic forward / backward (ray_passes); off = one launch sequence per pass, same arithmetic."""
+        self.batch_passes = (os.environ.get("RDRF_BATCH_PASSES", "1") != "0") if batch_passes is None else bool(batch_passes)
         self.dead_work = dead_work
         self.dp_exact_stats = bool(dp_exact_stats)
         self.cfg = cfg
@@ -386,8 +428,20 @@ class Trainer:
         def order_terms(outs):   # adaptive order loss, train.py:1277-1291 / 1666-1683
             return to_depth(outs[9]), to_depth(outs[5].detach()), (1.0 - outs[12].detach())
 
-        # ---- pass A
-        osA, oA, outA, xyzA = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
+        # ---- pass A (and, batched with it where their inputs allow, passes B-D: see ray_passes)
+        if full and self.batch_passes:
+            rays_n_of = {sgn: self.rays_for(ids, poses_d, focal_d, uv=grid + b["flow_f" if sgn > 0 else "flow_b"], view_shift=sgn)
+                         for sgn in (1, -1)}
+            # groups of equal gradient liveness: A (everything live) | B, C, D (no appearance gradient; before
+            # upsamp_list[3] no blending gradient either -- later only B has the dynamicness terms)
+            groups = [[0], [1, 2, 3]] if not late else [[0], [1], [2, 3]]
+            pA, pB, pC, pD = ray_passes(self.st, self.dy, [rays_d, rays_d, rays_n_of[1], rays_n_of[-1]],
+                                        [ts, b["ts_rand"], ts + dt, ts - dt], S, rt, rng, groups)
+            osA, oA, outA, xyzA = pA
+            batched = {"B": pB, 1: pC, -1: pD}
+        else:
+            osA, oA, outA, xyzA = ray_pass(self.st, self.dy, rays_d, ts, S, rt, rng)
+            batched = None
         if capture is not None:
             capture["A"] = (osA, oA, outA, xyzA)
         Ld.add(3.0, "square", outA[0], rgb_t).add(1.0, "square", outA[8], rgb_t)      # train.py:1323, 1331
@@ -412,7 +466,7 @@ class Trainer:
         if w_dist > 0:   # mean over the rays of the per-ray loss (eff_distloss), weighted
             Ld.add(w_dist, "identity", distloss_rays(outA[11], oA[8].detach(), 1.0 / S))
         # ---- pass B (second random time)
-        _, oB, outB, _ = ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
+        _, oB, outB, _ = batched["B"] if batched else ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
         if late:
             Ld.add(0.01, "identity", skewed(outB[12]))                                  # :1248-1266
             Ld.add(0.01, "abs", outB[12])                                               # novel_view_time_mask_loss, :1267
@@ -436,9 +490,12 @@ class Trainer:
         # ---- pass C / D: the flow-displaced rays of the neighbour frames (train.py:1433-1528, 1530-1625)
         for sgn in (1, -1):
             ind_disp, mask_t, pose_n, flow_t = disp_A[sgn]
-            rays_n = self.rays_for(ids, poses_d, focal_d, uv=grid + flow_t, view_shift=sgn)
-            ts_n = ts + sgn * dt
-            _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts_n, S, rt, rng)
+            if batched:
+                rays_n = rays_n_of[sgn]
+                _, oN, outN, _ = batched[sgn]
+            else:
+                rays_n = self.rays_for(ids, poses_d, focal_d, uv=grid + flow_t, view_shift=sgn)
+                _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts + sgn * dt, S, rt, rng)
             _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
             Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
             if w_dist > 0:
