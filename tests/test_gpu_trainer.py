@@ -420,3 +420,39 @@ def test_upsample_restarts_learning_rates_like_the_reference():
     tr.opt.lr_upsample_reset = False
     tr.upsample([24, 26, 16], 18)
     assert tr.opt.lr0 == pytest.approx(0.02 * f ** tr.it) and tr.opt.lr1 == pytest.approx(1e-3 * f ** tr.it)
+
+
+@pytest.mark.parametrize("name,stage,it", [("nvidia", "stage0", 5000), ("nvidia", "final", 30000),
+                                           ("nvidia_no_poses", "final", 30000)])
+def test_batched_passes_match_one_pass_per_launch(name, stage, it):
+    """step.ray_passes (passes A-D through one static forward, passes of equal gradient liveness through one dynamic
+    forward / backward) against one launch sequence per pass: the same draws, the same loss values, gradients equal up to the order of the atomic accumulation -- at the benchmark shape, at the
+    late stage (B alone, C + D batched) and at [706,786,471] / S = 578 with 3 x 4096 rays in one call (7.1 M samples:
+    the batched buffers pass 2^32 floats, the per-pass ones do not)."""
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    cfg = S_.scene_config(name, stage)
+    dev = torch.device("cuda", 0)
+    got = {}
+    for batched in (True, False):
+        tr = S_.Trainer(cfg, dev, batch_passes=batched)
+        tr.it = it
+        b = tr.data.make_batch(tr.it, cfg["batch_size"], None)
+        loss_d, loss_s = tr.losses(b)
+        tr.opt.zero_grad()
+        if tr.optimize_poses:
+            tr.poses.grad = None
+            tr.fov.grad = None
+        loss_s.backward()
+        loss_d.backward()
+        torch.cuda.synchronize()
+        got[batched] = (loss_d.detach().clone(), loss_s.detach().clone(), [g.detach().clone() for g in tr.grad_flats])
+        del tr, b, loss_d, loss_s
+        torch.cuda.empty_cache()
+    assert_close(got[True][0], got[False][0], "dynamic loss group", rtol=1e-6)
+    assert_close(got[True][1], got[False][1], "static loss group", rtol=1e-6)
+    for a, b_ in zip(got[True][2], got[False][2]):
+        assert float(b_.abs().max()) > 0
+        rel = float((a - b_).norm() / b_.norm())
+        record_margin("batched vs per-pass gradient (rel. L2 / 1e-5)", rel / 1e-5)
+        assert rel < 1e-5, rel
+        assert_close(a, b_, "batched vs per-pass gradient", rtol=2e-5)
