@@ -78,6 +78,24 @@ def pmc_traffic(kernel):
     return f * 1024.0 * 2.0 + w * 1024.0
 
 
+def pmc_family_per_step(csv_name, prefixes, counter):
+    """sum over the kernels whose name starts with one of `prefixes` of `counter` (mean x dispatches), per training
+    step of the profiled command (steps = dispatches of k_adam / 2: one launch per field and step); None if absent"""
+    fn, _ = _profile_csv(csv_name)
+    if fn is None:
+        return None
+    tot, adam = 0.0, 0
+    for line in open(fn).read().splitlines()[1:]:
+        parts = line.split(",")
+        if len(parts) < 4 or parts[1] != counter:
+            continue
+        if parts[0] == "k_adam":
+            adam = int(float(parts[2]))
+        if parts[0].startswith(prefixes):
+            tot += float(parts[3]) * float(parts[2])
+    return tot / (adam / 2.0) if adam else None
+
+
 def prof_get(L, name):
     ms, n = C.c_double(), C.c_int()
     L.lib.rdrf_prof_get(name.encode(), C.byref(ms), C.byref(n))
@@ -178,10 +196,15 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
     L.lib.rdrf_prof_enable(1)
     L.lib.rdrf_prof_reset()
     NP = 3
+    S_.PASSES.clear()
     for _ in range(NP):
         trainer.step(shard)
         trainer.finish_step()
     torch.cuda.synchronize()
+    # ray-passes per step by kind: the algorithmic counts below are per PASS (4096 rays x S samples); a batched launch
+    # (step.ray_passes) covers several
+    np_stat, np_stat_g = S_.PASSES["static"] / NP, S_.PASSES["static_grad"] / NP
+    np_dyn, np_dyn_bwd = S_.PASSES["dynamic"] / NP, (S_.PASSES["dynamic"] - S_.PASSES["dynamic_dead"]) / NP
     ns = rays_per_gpu * cfg["n_samples"]
     flops = {
         "dyn_density": ns * F_DYN_DENSITY, "dyn_heads_bwd": ns * (19584 + 19584), "dyn_warp_bwd": ns * 26496,
@@ -197,14 +220,24 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
             table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}
             tot_ms += msk / NP
     L.lib.rdrf_prof_enable(0)
-    # per-launch averages of the two kernels whose work follows head liveness (the blending head's 19 584 FLOP per
+    # passes per step each kernel family processes (its launches unless step.ray_passes batches them)
+    mult = {k: v["launches_per_step"] for k, v in table.items()}
+    for k in ("static_density", "static_app"):
+        if k in mult: mult[k] = np_stat
+    for k in ("dyn_density", "dyn_app", "time_branch"):
+        if k in mult: mult[k] = np_dyn
+    for k in ("dyn_heads_bwd", "dyn_warp_bwd", "scatter_dyn_density", "time_branch_bwd", "dw_dyn"):
+        if k in mult: mult[k] = np_dyn_bwd
+    for k, v in table.items():
+        v["passes_per_step"] = mult[k]
+    # per-pass averages of the two kernels whose work follows head liveness (the blending head's 19 584 FLOP per
     # sample is differentiated in `n_both_` of the dynamic backward launches, the appearance dW belongs to pass A)
-    nb_ = table.get("dw_dyn", {}).get("launches_per_step", 0.0)
+    nb_ = mult.get("dw_dyn", 0.0)
     n_both_ = min(nb_, 2.0 if trainer.it >= cfg.get("upsamp_list", [0, 0, 0, 1 << 30])[3] else 1.0)
     if nb_ > 0:
         flops["dyn_heads_bwd"] = ns * (19584 + 19584 * n_both_ / nb_)
         flops["dw_dyn"] = ns * (26496 + 19584 + 19584 * n_both_ / nb_ + f_d * F_DYN_APP / nb_)
-    step_flops = sum(flops[k] * table[k]["launches_per_step"] for k in table if k in flops)
+    step_flops = sum(flops[k] * mult[k] for k in table if k in flops)
     # k_dw (weight-gradient GEMMs; launches dw_dyn / dw_static / dw_sf): streams the saved activation rows and
     # the d(pre-activation) rows of every 32-sample tile; algorithmic bytes = UNIQUE rows x 128 B
     t1 = rays_per_gpu * ((cfg["n_samples"] + 31) // 32)
@@ -213,7 +246,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
     # pass A, and pass B once the late mask terms are on (iteration >= upsamp_list[3]); the other dynamic backward
     # launches stage 640 instead of 864 row blocks per density tile and scatter one factor set instead of two.
     # The appearance rows (960 per compacted tile) belong to pass A alone.
-    n_dyn_bwd = table.get("dw_dyn", {}).get("launches_per_step", 0.0)
+    n_dyn_bwd = mult.get("dw_dyn", 0.0)
     n_both = min(n_dyn_bwd, 2.0 if trainer.it >= cfg.get("upsamp_list", [0, 0, 0, 1 << 30])[3] else 1.0)
     dw_step_bytes = {"dw_dyn": ((n_both * 864 + (n_dyn_bwd - n_both) * 640) * t1 + 960 * t3d) * 128.0,
                      "dw_static": 864 * t3s * 128.0 * table.get("dw_static", {}).get("launches_per_step", 0.0),
@@ -224,7 +257,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         dw_launch = sum(table[k]["launches_per_step"] for k in dw_keys)
         dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
         dw_b = sum(dw_step_bytes[k] for k in dw_keys)
-        dw_f = sum(flops[k] * table[k]["launches_per_step"] for k in dw_keys)
+        dw_f = sum(flops[k] * mult[k] for k in dw_keys)
         tr = pmc_traffic("k_dw2")
         dw_entry = {
             "bound": "hbm", "achieved": dw_b / (dw_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -239,7 +272,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
     # the gradient factors (2B), read the d(feature) row entries (4 B per component); B = 1728 B for a
     # 72-component family, 5184 B for appearance.  The bytes are L2 / Infinity-Cache resident, so `achieved` may
     # exceed the HBM `traffic`; the kernel is bound by the L2 atomic request rate.
-    n_sc = table.get("scatter_dyn_density", {}).get("launches_per_step", 0.0)
+    n_sc = mult.get("scatter_dyn_density", 0.0)
     sc_step_bytes = {"scatter_dyn_density": (n_both * 2 + (n_sc - min(n_sc, n_both)) * 1) * ns * valid_frac * (3 * 1728 + 288.0),
                      "scatter_dyn_app": ns * f_d * (3 * 5184 + 864.0) * table.get("scatter_dyn_app", {}).get("launches_per_step", 0.0),
                      "scatter_static_app": ns * f_s * (3 * 1728 + 288.0) * table.get("scatter_static_app", {}).get("launches_per_step", 0.0)}
@@ -247,14 +280,17 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
     sc_ms = sum(table[k]["ms_per_step"] for k in sc_keys)
     sc_launch = sum(table[k]["launches_per_step"] for k in sc_keys)
     sc_b = sum(sc_step_bytes[k] for k in sc_keys)
-    tr = pmc_traffic("void k_scatter<4; 1; 9>")
-    den_us = table.get("scatter_dyn_density", {}).get("avg_us")
-    atom = pmc_value("sq_counters", "void k_scatter<4; 1; 9>", "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
+    # PMC figures of the whole k_scatter family (ray-tile and sorted kernels, all factor sets) per step of the committed
+    # profile, set against this run's family time
+    fam = ("void k_scatter<", "void k_scatter_sorted<")
+    f_, w_ = pmc_family_per_step("pmc_fetch", fam, "FETCH_SIZE"), pmc_family_per_step("pmc_write", fam, "WRITE_SIZE")
+    tr_step = None if (f_ is None or w_ is None) else f_ * 1024.0 * 2.0 + w_ * 1024.0
+    atom = pmc_family_per_step("sq_counters", fam, "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
     sc_entry = {
         "bound": "hbm", "achieved": sc_b / (sc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-        "frac": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": tr,
-        "hbm_real": None if (tr is None or not den_us) else tr / (den_us * 1e-6) / 1e9,
-        "l2_atomic_frac": None if (atom is None or not den_us) else atom / (den_us * 1e-6) / L2_ATOMIC_REQ_PER_S,
+        "frac": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None if tr_step is None else tr_step / sc_launch,
+        "hbm_real": None if tr_step is None else tr_step / (sc_ms * 1e-3) / 1e9,
+        "l2_atomic_frac": None if atom is None else atom / (sc_ms * 1e-3) / L2_ATOMIC_REQ_PER_S,
         "kernel": "k_scatter", "ms_per_step": sc_ms, "kernel_avg_us": sc_ms / sc_launch * 1e3,
         "launches_per_step": sc_launch, "algorithmic_bytes_per_launch": sc_b / sc_launch,
         "bound_physical": "memory-side fp32 atomic requests + LDS line atomics (not HBM: the gathered bytes are cache resident)",
@@ -265,8 +301,9 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         "limiter": "memory-side fp32-atomic request rate (~20.8 G requests/s, tools/ubench/atomics.hip) and ds_add_f32 "
                    "(~150 cycles per wave instruction): `frac` is NOMINAL (algorithmic bytes / time against the HBM peak; "
                    "the contract offers hbm | mfma); hbm_real = PMC bytes / time, l2_atomic_frac = atomic requests / "
-                   "time / 20.8 G/s of the density/blending launch and frac_l2 (against the 34.5 TB/s L2) are the "
-                   "physical figures"}
+                   "time / 20.8 G/s, both over all launches of the k_scatter family in a step, and frac_l2 (against the "
+                   "34.5 TB/s L2) are the physical figures; launches of >= 800 k samples take the sorted kernels "
+                   "(~10x fewer requests)"}
     dom_e, oth_e = (sc_entry, dw_entry) if (not dw_keys or sc_ms >= dw_ms) else (dw_entry, sc_entry)
     out = dict(dom_e)
     out.update({
@@ -274,6 +311,9 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         "step_algorithmic_tflop": step_flops / 1e12,
         "step_frac_of_peak": step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
         "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in table.items()},
+        "kernel_launches_per_step": {k: round(v["launches_per_step"], 2) for k, v in table.items()},
+        "ray_passes_per_step": {"static": np_stat, "static_with_grad": np_stat_g, "dynamic": np_dyn,
+                                "dynamic_with_grad": np_dyn_bwd},
         "sum_kernel_ms_per_step": tot_ms,
         "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s},
         "pmc_profile": _profile_csv("pmc_fetch")[1],

@@ -28,6 +28,7 @@ The dataset (RGB, RAFT flow, DPT disparity, masks) is synthetic: random tensors 
 in HBM.  Losses keep every term that decides which hot-path outputs carry gradient; there is no
 per-iteration host sync (``.item()``): losses and the per-frame medians stay on the device.
 """
+import collections
 import math
 import os
 
@@ -230,6 +231,11 @@ class StepRng:
         return self._take(S - S // 2 + 1, device), self._take(S // 2 + 1, device)
 
 
+# ray-passes evaluated since the last reset, by kind (bench.py prices its algorithmic byte / FLOP counts per PASS: a
+# batched launch covers several): static, static_grad, dynamic, dynamic_dead (dead work of passes E / P3 / P4)
+PASSES = collections.Counter()
+
+
 def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_grad=False, dynamic=True):
     """sampleXYZ -> static -> dynamic -> raw2outputs (one ray-pass).  The static field runs value-only unless
     `static_grad`; with dynamic=False (dead work of passes E / P3 / P4 skipped) zeros stand in for the dynamic
@@ -237,6 +243,7 @@ def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_g
     jit, jit_o = rng.jitter(n_samples, ray_type, rays.device) if is_train else (None, None)
     xyz, z, valid = sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=is_train, jitter=jit,
                               jitter_outer=jit_o)
+    PASSES.update(static=1, static_grad=int(static_grad), dynamic=int(dynamic), dynamic_dead=int(dynamic and static_grad))
     if static_grad:
         o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
     else:
@@ -267,6 +274,7 @@ def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
     launch (tail quantisation: 2.4 -> 3 tile rounds per wave becomes 7.3 -> 8) and fill their LDS images once.
     Returns one (o_s, o_d, outs, xyz) per pass; the per-pass tensors are views (unbind) of the batched outputs."""
     P, N, dev = len(rays_list), rays_list[0].shape[0], rays_list[0].device
+    PASSES.update(static=P, dynamic=P)
     samples, coins = [], []
     for rays in rays_list:
         jit, jit_o = rng.jitter(n_samples, ray_type, dev)
@@ -537,6 +545,7 @@ class Trainer:
             rays_n = self.rays_for(ids, poses, focal, uv=grid + flow_t, view_shift=sgn)
             jit, jit_o = rng.jitter(S, rt, rays.device)
             xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
+            PASSES.update(static=1, static_grad=1)
             o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
             _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, ray_type=rt)
             Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
