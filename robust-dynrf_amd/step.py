@@ -265,6 +265,36 @@ def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_g
     return o_s, o_d, outs, xyz
 
 
+# samples one batched field call may cover: beyond a few million the per-call buffers (saved rows: ~6 KB per sample)
+# reach tens of GB and the caching allocator's handling of such blocks costs more than the launches saved (640^3 grid,
+# 3 x 4096 x 578 samples in one call: kernel time unchanged, 84 -> 141 ms/step); the passes are then batched in smaller
+# groups
+BATCH_MAX_SAMPLES = int(float(os.environ.get("RDRF_BATCH_MAX_SAMPLES", 6e6)))
+
+
+def batch_groups(idxs, n_samples_per_pass):
+    """consecutive pass indices `idxs` cut into groups of at most BATCH_MAX_SAMPLES samples"""
+    per = max(1, BATCH_MAX_SAMPLES // max(1, n_samples_per_pass))
+    idxs = list(idxs)
+    return [idxs[i:i + per] for i in range(0, len(idxs), per)]
+
+
+def batched_field(field, rays_list, ts_list, samples, idxs, ray_type, grad=True):
+    """`field` over the concatenated rays / samples of the passes `idxs` in ONE call; returns the 10-tuple of each pass
+    (views of the batched outputs: unbind, whose backward stacks the per-pass gradients)"""
+    if len(idxs) == 1:
+        k = idxs[0]
+        with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
+            return [field(rays_list[k], ts_list[k], None, *samples[k], is_train=True, ray_type=ray_type)]
+    N = rays_list[idxs[0]].shape[0]
+    cat = lambda ts: torch.cat([ts[k] for k in idxs])
+    with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
+        o = field(cat(rays_list), cat(ts_list), None, *(torch.cat([samples[k][i] for k in idxs]) for i in range(3)),
+                  is_train=True, ray_type=ray_type)
+    parts = [None if t is None else t.view(len(idxs), N, *t.shape[1:]).unbind(0) for t in o]
+    return [tuple(None if pt is None else pt[j] for pt in parts) for j in range(len(idxs))]
+
+
 def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
     """Several ray-passes whose inputs do not depend on each other's outputs (passes A-D of an iteration: the rays of
     C / D come from the data's optical flow, not from pass A), evaluated as ONE value-only static forward over all their
@@ -272,6 +302,7 @@ def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
     liveness, so that a batched call prunes what each of its passes would).  Same arithmetic and the same draw order
     (jitter, coin per pass, in pass order) as one ray_pass per entry; the persistent MLP kernels see 3-4x the tiles per
     launch (tail quantisation: 2.4 -> 3 tile rounds per wave becomes 7.3 -> 8) and fill their LDS images once.
+    Calls are capped at BATCH_MAX_SAMPLES samples.
     Returns one (o_s, o_d, outs, xyz) per pass; the per-pass tensors are views (unbind) of the batched outputs."""
     P, N, dev = len(rays_list), rays_list[0].shape[0], rays_list[0].device
     PASSES.update(static=P, dynamic=P)
@@ -280,24 +311,19 @@ def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
         jit, jit_o = rng.jitter(n_samples, ray_type, dev)
         samples.append(sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=True, jitter=jit, jitter_outer=jit_o))
         coins.append(rng.coin())
-    rays_c, ts_c = torch.cat(rays_list), torch.cat(ts_list)
-    xyz_c, z_c, valid_c = (torch.cat([sm[i] for sm in samples]) for i in range(3))
-    with torch.no_grad():
-        o_s = st(rays_c, ts_c, None, xyz_c, z_c, valid_c, is_train=True, ray_type=ray_type)
-    split = lambda t, n: t.view(n, N, *t.shape[1:]).unbind(0)
-    s_parts = [None if o is None else split(o, P) for o in o_s]
-    o_ds = [None] * P
-    for g in groups:
-        assert list(g) == list(range(g[0], g[0] + len(g)))
-        sl = slice(g[0] * N, (g[0] + len(g)) * N)
-        o_d = dy(rays_c[sl], ts_c[sl], None, xyz_c[sl], z_c[sl], valid_c[sl], is_train=True, ray_type=ray_type)
-        d_parts = [None if o is None else split(o, len(g)) for o in o_d]   # unbind: the backward stacks the parts' gradients
-        for k, p in enumerate(g):
-            o_ds[p] = tuple(None if d is None else d[k] for d in d_parts)
+    ns = N * samples[0][1].shape[1]
+    o_ss, o_ds = [None] * P, [None] * P
+    for g in batch_groups(range(P), ns):
+        for k, o in zip(g, batched_field(st, rays_list, ts_list, samples, g, ray_type, grad=False)):
+            o_ss[k] = o
+    for group in groups:
+        assert list(group) == list(range(group[0], group[0] + len(group)))
+        for g in batch_groups(group, ns):
+            for k, o in zip(g, batched_field(dy, rays_list, ts_list, samples, g, ray_type)):
+                o_ds[k] = o
     out = []
     for p in range(P):
-        o_sp = tuple(None if sp is None else sp[p] for sp in s_parts)
-        o_d = o_ds[p]
+        o_sp, o_d = o_ss[p], o_ds[p]
         outs = raw2outputs(o_sp[6], o_sp[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], rays_list[p], is_train=True,
                            ray_type=ray_type, add_white_bg=coins[p])
         out.append((o_sp, o_d, outs, samples[p][0]))
@@ -536,29 +562,69 @@ class Trainer:
         ids, ts, fg = b["ids"], b["ts"], b["fg"]
         rng = self.rng
         weights_s, pts_ref_s, depth_s = outE[7], oE[3], outE[5]
-        for sgn, flow_t, mask_t in ((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"])):
+        col, row = grid[:, 0], grid[:, 1]
+        uv_P34 = (torch.stack([torch.clamp(col + 1.0, max=W - 0.5), row], -1),
+                  torch.stack([col, torch.clamp(row + 1.0, max=H - 0.5)], -1))
+        batched = None
+        if self.batch_passes:
+            # P1-P4 are independent of each other and have the same gradient liveness (density branch of the static field
+            # only): one static forward / backward over their 4 N rays, the draws in pass order (ray_passes)
+            rays_P = [self.rays_for(ids, poses, focal, uv=grid + b["flow_f"], view_shift=1),
+                      self.rays_for(ids, poses, focal, uv=grid + b["flow_b"], view_shift=-1),
+                      self.rays_for(ids, poses, focal, uv=uv_P34[0]), self.rays_for(ids, poses, focal, uv=uv_P34[1])]
+            smp, coins = [], []
+            for k, r in enumerate(rays_P):
+                jit, jit_o = rng.jitter(S, rt, rays.device)
+                smp.append(sampleXYZ(self.st if k < 2 else self.dy, r, S, ray_type=rt, is_train=True, jitter=jit,
+                                     jitter_outer=jit_o))
+                coins.append(rng.coin() if k >= 2 else None)
+            PASSES.update(static=4, static_grad=4)
+            ts_P = [ts] * 4
+            ns = rays.shape[0] * smp[0][1].shape[1]
+            o_P = [None] * 4
+            for g in batch_groups(range(4), ns):
+                for k, o in zip(g, batched_field(self.st, rays_P, ts_P, smp, g, rt)):
+                    o_P[k] = o
+            d_P = [None, None]
+            if self.dead_work:   # the dynamic forwards of P3 / P4: dead work the reference performs
+                PASSES.update(dynamic=2, dynamic_dead=2)
+                for g in batch_groups((2, 3), ns):
+                    for k, o in zip(g, batched_field(self.dy, rays_P, ts_P, smp, g, rt)):
+                        d_P[k - 2] = o
+            batched = (rays_P, smp, coins, o_P, d_P)
+        for k, (sgn, flow_t, mask_t) in enumerate(((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"]))):
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]                       # live: allposes_refine_f / _b
             mm = mask_t * m
             ind_flow, ind_disp = induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, grid, rays, ray_type=rt)
             Ls.add(0.01 * temp_static, "abs", ind_flow, flow_t, w=mm, norm="weight")    # :1909-1941 (x 0.02 / 2)
             # P1 / P2: the static field along the flow-displaced ray of the neighbour frame
-            rays_n = self.rays_for(ids, poses, focal, uv=grid + flow_t, view_shift=sgn)
-            jit, jit_o = rng.jitter(S, rt, rays.device)
-            xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
-            PASSES.update(static=1, static_grad=1)
-            o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
-            _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, ray_type=rt)
+            if batched:
+                rays_n, o, xyz = batched[0][k], batched[3][k], batched[1][k][0]
+            else:
+                rays_n = self.rays_for(ids, poses, focal, uv=grid + flow_t, view_shift=sgn)
+                jit, jit_o = rng.jitter(S, rt, rays.device)
+                xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
+                PASSES.update(static=1, static_grad=1)
+                o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
+            _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], xyz, grid, rays_n, ray_type=rt)
             Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
         Ls.add(1.0, "identity", frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5,
                                                  coef=c["monodepth_static"] * temp_static, dp=self._dp()))
         # P3 / P4: disparity smoothness against the x+1 / y+1 pixel neighbours (train.py:2123-2311)
-        col, row = grid[:, 0], grid[:, 1]
         inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)
-        for uv_n in (torch.stack([torch.clamp(col + 1.0, max=W - 0.5), row], -1),
-                     torch.stack([col, torch.clamp(row + 1.0, max=H - 0.5)], -1)):
-            rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
-            _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
+        for k, uv_n in enumerate(uv_P34):
+            if batched:
+                rays_n, o_s, o_d, z = batched[0][2 + k], batched[3][2 + k], batched[4][k], batched[1][2 + k][1]
+                if o_d is None:
+                    zero = torch.zeros_like(o_s[7])
+                    dyn = (torch.zeros_like(o_s[6]), zero, o_s[9], zero, z)
+                else:
+                    dyn = (o_d[6], o_d[7], o_d[9], o_d[2], o_d[8])
+                outN = raw2outputs(o_s[6], o_s[7], *dyn, rays_n, is_train=True, ray_type=rt, add_white_bg=batched[2][2 + k])
+            else:
+                rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
+                _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
             Ls.add(50.0 * temp_disp_tv, "square", inv_d, 1.0 / torch.clamp(outN[5], min=1e-6))  # :2293-2305
 
     def step(self, shard=None):

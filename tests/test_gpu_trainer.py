@@ -423,14 +423,17 @@ def test_upsample_restarts_learning_rates_like_the_reference():
 
 
 @pytest.mark.parametrize("name,stage,it", [("nvidia", "stage0", 5000), ("nvidia", "final", 30000),
-                                           ("nvidia_no_poses", "final", 30000)])
-def test_batched_passes_match_one_pass_per_launch(name, stage, it):
+                                           ("nvidia_no_poses", "final", 30000), ("davis", "stage0", 5000)])
+def test_batched_passes_match_one_pass_per_launch(name, stage, it, monkeypatch):
     """step.ray_passes (passes A-D through one static forward, passes of equal gradient liveness through one dynamic
     forward / backward) against one launch sequence per pass: the same draws, the same loss values, gradients equal up to the order of the atomic accumulation -- at the benchmark shape, at the
-    late stage (B alone, C + D batched) and at [706,786,471] / S = 578 with 3 x 4096 rays in one call (7.1 M samples:
-    the batched buffers pass 2^32 floats, the per-pass ones do not)."""
+    late stage (B alone, C + D batched), at [706,786,471] / S = 578 with 3 x 4096 rays in one dynamic call (7.1 M
+    samples: the batched buffers pass 2^32 floats, the per-pass ones do not) and 4 x 4096 in the static call of the pose
+    block's passes P1-P4, and on contracted rays (davis)."""
     S_ = importlib.import_module("robust-dynrf_amd.step")
     cfg = S_.scene_config(name, stage)
+    if name == "nvidia_no_poses":   # lift step.BATCH_MAX_SAMPLES (6 M): all of B-D / P1-P4 in one call each
+        monkeypatch.setattr(S_, "BATCH_MAX_SAMPLES", 1 << 40)
     dev = torch.device("cuda", 0)
     got = {}
     for batched in (True, False):
