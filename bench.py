@@ -295,6 +295,10 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         "launches_per_step": sc_launch, "algorithmic_bytes_per_launch": sc_b / sc_launch,
         "bound_physical": "memory-side fp32 atomic requests + LDS line atomics (not HBM: the gathered bytes are cache resident)",
         "frac_l2": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_L2_GBS,
+        # the same time priced with round 2's byte count (both factor sets of the dynamic field in every pass, whether
+        # or not the blending head receives a gradient): comparable with BENCH_r02's frac
+        "frac_round2_accounting": (sc_b + (n_sc * 2 - (n_both * 2 + (n_sc - min(n_sc, n_both)))) * ns * valid_frac
+                                   * (3 * 1728 + 288.0)) / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
         "source": {"achieved / ms_per_step / kernel_avg_us": "HIP events, this run",
                    "traffic / hbm_real / l2_atomic_frac": f"profiles/{_profile_csv('pmc_fetch')[1]}_*.csv (committed rocprofv3 PMC "
                                                           "summaries of the same command, not re-measured in this run)"},
