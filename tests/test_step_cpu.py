@@ -43,3 +43,24 @@ def test_step_rng_pool_and_coin_streams():
     assert jo[0].shape[0] == 221 - 221 // 2 + 1 and jo[1].shape[0] == 221 // 2 + 1
     assert torch.equal(jo[0], pool[256:256 + 111 + 1]) and torch.equal(jo[1], pool[384:384 + 111])
     assert float(pool.min()) >= 0.0 and float(pool.max()) < 1.0
+
+
+def test_bench_reads_the_committed_pmc_summaries():
+    """bench.py prices `roofline.traffic / hbm_real / l2_atomic_frac` from the committed rocprofv3 summaries under
+    profiles/: the parsers must find the scatter family, the dW kernel and the step count in this round's files (a
+    silent None would drop the fields from the driver's line)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    fam = ("void k_scatter<", "void k_scatter_sorted<")
+    fetch = bench.pmc_family_per_step("pmc_fetch", fam, "FETCH_SIZE")
+    write = bench.pmc_family_per_step("pmc_write", fam, "WRITE_SIZE")
+    atom = bench.pmc_family_per_step("sq_counters", fam, "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
+    assert fetch and write and atom
+    assert 1e5 < fetch < 1e7 and 1e5 < write < 1e7          # KB per training step
+    assert 1e7 < atom < 1e8                                 # memory-side atomic requests per training step
+    dw = bench.pmc_traffic("k_dw2")
+    assert dw and 1e8 < dw < 1e10                           # bytes per launch
+    assert bench._profile_csv("pmc_fetch")[1] == bench.PROFILE_TAG
