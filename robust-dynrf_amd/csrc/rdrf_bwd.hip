@@ -108,6 +108,7 @@ struct BwdArgs {
   // gradients of the RAW density / blending features, g_feat [M][27] of the appearance features
   int M, in_norm;
   const float* g_feat;
+  int small_dw;   // ray path: k_dyn_density_bwd forms the weight gradients of layer5 / density_layer2 / blending_layer2
 };
 
 struct StaticG {
@@ -117,6 +118,7 @@ struct StaticG {
 struct DynG {
   RdrfVM density, blending, app;
   float *rbv, *rwv, *l5b, *db2, *bb2;
+  float *l5w, *dw2, *bw2;   // small layers of the density phase: weight gradients formed in k_dyn_density_bwd (ray path)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1333,6 +1335,25 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
 //   PHASE 1 (warp) : coordinate gradients (appearance + density + blending scatter) ->
 //                    warp MLP backward, positional-encoding backward, g_xyz, d(tout)
 // ------------------------------------------------------------------------------------------------
+// Reduce-scatter over the 32 lanes of a half-wave: on return lane s holds the sum over the half's 32 lanes of p[s]
+// (five butterfly stages: 31 lane exchanges + 31 adds).  Used for the weight gradients of the 3- and 1-row layers of the
+// density phase (layer5, density / blending layer2): dW[e] = sum over the tile's samples of dz(sample) * in_e(sample),
+// with dz a per-lane scalar and in_e the 32 slots the lane already holds -- as MFMA products in k_dw2 these were 6 of
+// the 40 per tile, each 27/32 empty.  ALL lanes of the wave must call.
+RDRF_D float reduce_scatter32(const float (&p)[32], int s) {
+  const bool b4 = s & 16, b3 = s & 8, b2 = s & 4, b1 = s & 2, b0 = s & 1;
+  float q[16], r[8], t[4], u[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q[i] = (b4 ? p[i + 16] : p[i]) + __shfl_xor(b4 ? p[i] : p[i + 16], 16, 64);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (b3 ? q[i + 8] : q[i]) + __shfl_xor(b3 ? q[i] : q[i + 8], 8, 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = (b2 ? r[i + 4] : r[i]) + __shfl_xor(b2 ? r[i] : r[i + 4], 4, 64);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) u[i] = (b1 ? t[i + 2] : t[i]) + __shfl_xor(b1 ? t[i] : t[i + 2], 2, 64);
+  return (b0 ? u[1] : u[0]) + __shfl_xor(b0 ? u[0] : u[1], 1, 64);
+}
+
 template <int PHASE, bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[PHASE == 0 ? pkb::K1H_SIZE : pkb::K1W_SIZE];
@@ -1341,6 +1362,9 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int tpr = (a.S + 31) >> 5;
+  // small-layer weight gradients of this wave (ray path): lane (s, h) holds input element elem_of(s, h) of up to three
+  // output rows (PHASE 0: density / blending layer2; PHASE 1: the three rows of layer5) + the rows' bias sums per lane
+  float sw[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
   for (int n = blockIdx.x * nwaves + wave; n < a.N; n += gridDim.x * nwaves) {
     float vx = 0.f, vy = 0.f, vz = 0.f;
     float nrm = 1.0f;
@@ -1445,6 +1469,13 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
 #pragma unroll
           for (int kk = 0; kk < 32; ++kk) dzh[kk] = Hh[kk] > 0.f ? w2r[kk] * gfh : 0.f;
           save_rows<32>(gb, head == 0 ? sv::K1G_DZD : sv::K1G_DZB, dzh, s, h);
+          if (!FEAT && a.small_dw) {   // d(layer2 weight) = sum over the samples of g * (layer2 input = the saved activation)
+            float pw[32];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) pw[kk] = gfh * Hh[kk];
+            sw[head] += reduce_scatter32(pw, s);
+            sb[head] += gfh;
+          }
           f32x16 accF[3];
           acc_zero<3>(accF);
           mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_F : pkb::K1H_BLE1T_F), lane);
@@ -1507,6 +1538,18 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
             for (int c = 0; c < 4; ++c) {
               const float d = wa[c] * dd0 + wb[c] * dd1 + wc[c] * dd2;
               dz4[4 * q + c] = H4[4 * q + c] > 0.f ? d : 0.f;
+            }
+          }
+          if (!FEAT && a.small_dw) {   // d(layer5 weight): three output rows against the 64 saved inputs
+            sb[0] += dd0; sb[1] += dd1; sb[2] += dd2;
+#pragma unroll 1
+            for (int o = 0; o < 3; ++o) {   // one row at a time: the three butterflies unrolled together spill
+              const float dd = o == 0 ? dd0 : (o == 1 ? dd1 : dd2);
+              float pw[32];
+#pragma unroll
+              for (int kk = 0; kk < 32; ++kk) pw[kk] = dd * H4[kk];
+              const float r = reduce_scatter32(pw, s);
+              sw[0] += o == 0 ? r : 0.f; sw[1] += o == 1 ? r : 0.f; sw[2] += o == 2 ? r : 0.f;
             }
           }
         }
@@ -1579,6 +1622,33 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
     if (!FEAT && PHASE == 0 && a.g_rays && a.ray_type != RDRF_RAY_OTHER) {
       g_nrm = wave_sum(g_nrm);
       if (lane < 3) atomicAdd(a.g_rays + (size_t)n * 6 + 3 + lane, g_nrm * (lane == 0 ? vx : (lane == 1 ? vy : vz)));
+    }
+  }
+  if (!FEAT && a.small_dw) {
+    // small-layer gradients: sum the workgroup's waves in LDS, then one atomic per entry and workgroup
+    __shared__ float red[8][3][65];
+    __syncthreads();   // (also: every wave is done with `carr`)
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      red[wave][o][lane] = sw[o];
+      const float bs = wave_sum(h == 0 ? sb[o] : 0.f);   // both halves hold the same samples
+      if (lane == 0) red[wave][o][64] = bs;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const bool live_d = a.g_sigma != nullptr || a.g_weight != nullptr, live_b = a.g_blending != nullptr;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        float v = 0.f, bv = 0.f;
+        for (int wv = 0; wv < nwaves; ++wv) { v += red[wv][o][lane]; bv += red[wv][o][64]; }
+        float* gwt = PHASE == 1 ? gw.l5w + o * 64 : (o == 0 ? gw.dw2 : gw.bw2);
+        float* gbs = PHASE == 1 ? gw.l5b + o : (o == 0 ? gw.db2 : gw.bb2);
+        const bool on = PHASE == 1 ? true : (o == 0 ? live_d : (o == 1 ? live_b : false));
+        if (on) {
+          grad_add(gwt + elem_of(s, h), v);
+          if (lane == 0) grad_add(gbs, bv);
+        }
+      }
     }
   }
 }
@@ -2444,7 +2514,7 @@ static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const Rd
 
 // dW jobs of the dynamic field's density phase (warp MLP, density / blending heads)
 static void add_density_phase_dw(DwJobs& D, const float* grows1, const float* act1, const RdrfDynamicParams* G,
-                                 int T1, bool live_d = true, bool live_b = true) {
+                                 int T1, bool live_d = true, bool live_b = true, bool small_in_kernel = false) {
   // layer3: [X0 | tout]
   dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_DZ3, 2, 64, 0, act1, sv::K1_ROWS, 93, 93, G->l3w, G->l3b, nullptr, T1);
   dw_blk(D, sv::K1_X0, SEG_WARP3_X0, 0);
@@ -2453,7 +2523,10 @@ static void add_density_phase_dw(DwJobs& D, const float* grows1, const float* ac
   dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_DZ4, 2, 64, 0, act1, sv::K1_ROWS, 64, 64, G->l4w, G->l4b, nullptr, T1);
   dw_blk(D, sv::K1_H3, SEG_IDENT, 0);
   dw_blk(D, sv::K1_H3 + 32, SEG_IDENT, 32);
-  // small layers share one dz block: rows 0..2 -> layer5, row 3 -> density_layer2, row 4 -> blending_layer2
+  // small layers share one dz block: rows 0..2 -> layer5, row 3 -> density_layer2, row 4 -> blending_layer2.
+  // On the ray path k_dyn_density_bwd forms these gradients itself (reduce_scatter32): as MFMA products they were 6 of
+  // the 40 per tile, 27 of 32 rows empty, and the 12 waves of k_dw2 take 34 products in 3 rounds instead of 4
+  if (!small_in_kernel) {
   dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 3, 0, act1, sv::K1_ROWS, 64, 64, G->l5w, G->l5b, nullptr, T1);
   dw_blk(D, sv::K1_H4, SEG_IDENT, 0);
   dw_blk(D, sv::K1_H4 + 32, SEG_IDENT, 32);
@@ -2466,6 +2539,7 @@ static void add_density_phase_dw(DwJobs& D, const float* grows1, const float* ac
     dw_add(D, grows1, sv::K1G_ROWS, sv::K1G_SM, 1, 1, 4, act1, sv::K1_ROWS, 64, 64, G->bw2, G->bb2, nullptr, T1);
     dw_blk(D, sv::K1_HB, SEG_IDENT, 0);
     dw_blk(D, sv::K1_HB + 32, SEG_IDENT, 32);
+  }
   }
   for (int head = 0; head < 2; ++head) {
     if (!(head ? live_b : live_d)) continue;   // dead head: its dz rows were not written (k_dyn_density_bwd<0>)
@@ -2584,6 +2658,8 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_blending = g_blending;
   a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz; a.g_rays = g_rays; a.g_dists = g_dists; a.g_z = g_z;
+  static const bool small_dw = !(getenv("RDRF_DW_SMALL") && atoi(getenv("RDRF_DW_SMALL")) == 0);   // 0: as k_dw2 products
+  a.small_dw = small_dw ? 1 : 0;
   RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 1, N, S), -3, "dynamic_bwd: saved buffer too small");
   BwdWs b;
   int rc = carve_bwd(b, ws, ws_bytes, N, S, 1);
@@ -2595,6 +2671,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   DynG gw;
   gw.density = G->density; gw.blending = G->blending; gw.app = G->app;
   gw.rbv = G->rbv; gw.rwv = G->rwv; gw.l5b = G->l5b; gw.db2 = G->db2; gw.bb2 = G->bb2;
+  gw.l5w = G->l5w; gw.dw2 = G->dw2; gw.bw2 = G->bw2;
   if (P->packed_bwd != nullptr) a.pk = P->packed_bwd;   // caller-packed image (rdrf_dynamic_pack)
   else {
     PackJobs J;
@@ -2669,7 +2746,9 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
     RDRF_LAUNCH("dyn_warp_bwd", (k_dyn_density_bwd<1, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     RDRF_LAUNCH("time_branch_bwd", k_time_branch_bwd, dim3((N + TB_RPB - 1) / TB_RPB), dim3(128), stream, ts, w,
                 N, b.dtout, G->l1w, G->l1b, G->l2w, G->l2b);
-    add_density_phase_dw(D, b.grows1, a.sp.act1, G, (int)t1, g_sigma != nullptr || g_weight != nullptr, g_blending != nullptr);
+    const bool small_in_kernel = a.small_dw != 0;
+    add_density_phase_dw(D, b.grows1, a.sp.act1, G, (int)t1, g_sigma != nullptr || g_weight != nullptr, g_blending != nullptr,
+                         small_in_kernel);
   }
   rc = dw_launch(D, stream, "dw_dyn");
   return rc;
@@ -2795,6 +2874,7 @@ extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfF
   DynG gw;
   gw.density = G->density; gw.blending = G->blending; gw.app = G->app;
   gw.rbv = G->rbv; gw.rwv = G->rwv; gw.l5b = G->l5b; gw.db2 = G->db2; gw.bb2 = G->bb2;
+  gw.l5w = G->l5w; gw.dw2 = G->dw2; gw.bw2 = G->bw2;
   if (P->packed_bwd != nullptr) a.pk = P->packed_bwd;   // caller-packed image (rdrf_dynamic_pack)
   else {
     PackJobs J;
