@@ -100,7 +100,9 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
     focal_d = focal.detach() if torch.is_tensor(focal) else focal
     dt = 2.0 / (T - 1)
     col, row, view = O.ids2pixel(W, H, ids)
-    grid = torch.stack([col.to(poses.dtype) + 0.5, row.to(poses.dtype) + 0.5], -1)
+    grid = torch.stack([col.to(poses.dtype) + 0.5, row.to(poses.dtype) + 0.5], -1)   # pixel centres: uv of the displaced rays
+    # induce_flow's pts_2d is `allgrids[ray_idx]` = the INTEGER pixel coordinates (train.py:974-978, 1046), not the centres
+    px = torch.stack([col.to(poses.dtype), row.to(poses.dtype)], -1)
     c2w_all = O.pose_to_mtx(poses)
     temp = 1.0 / (10 ** (it // 100000))              # train.py:1034-1036
     temp_disp_tv = 1.0 / (10 ** (it // 50000))
@@ -154,7 +156,7 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
     for sgn, sf, flow_t, mask_t in ((1, sf_f, b["flow_f"], b["mask_f"]), (-1, sf_b, b["flow_b"], b["mask_b"])):
         pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
         pts_n = pts_ref + sf if ndc else torch.clamp(pts_ref + sf, min=-2.0 + 1e-6, max=2.0 - 1e-6)
-        ind_flow, ind_disp = O.induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, grid, rays_d, rt)
+        ind_flow, ind_disp = O.induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, px, rays_d, rt)
         loss_d = loss_d + 0.02 * temp * masked_mean((ind_flow - flow_t).abs(), mask_t) / 2.0
         disp_A[sgn] = (ind_disp, mask_t, pose_n, flow_t)
     # ---- pass C / D
@@ -162,7 +164,7 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
         ind_disp, mask_t, pose_n, flow_t = disp_A[sgn]
         rays_n = O.generate_rays(ids, poses_d, focal_d, H, W, ndc=ndc, near=1.0, uv=grid + flow_t, view_shift=sgn)
         _, oN, outN, _ = rp(rays_n, ts + sgn * dt)
-        _, ind_disp_n = O.induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, rt)
+        _, ind_disp_n = O.induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], px, rays_n, rt)
         loss_d = loss_d + 0.04 * temp * masked_mean((ind_disp - ind_disp_n).abs(), mask_t)
         if w_dist > 0:
             loss_d = loss_d + w_dist * O.eff_distloss(outN[11], oN[8].detach(), 1.0 / S)
@@ -177,13 +179,13 @@ def step_losses(cfg, sd_s, sd_d, batch, poses, focal, it, rng, dead_work=False, 
         for sgn, flow_t, mask_t in ((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"])):
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]
             mm = mask_t * m
-            ind_flow, ind_disp = O.induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, grid, rays, rt)
+            ind_flow, ind_disp = O.induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, px, rays, rt)
             loss_s = loss_s + 0.02 * temp_static * masked_mean((ind_flow - flow_t).abs(), mm) / 2.0
             rays_n = O.generate_rays(ids, poses, focal, H, W, ndc=ndc, near=1.0, uv=grid + flow_t, view_shift=sgn)
             jit, jit_o = rng.jitter(S, rt)
             xyz, z, valid = O.sampleXYZ(rays_n, aabb, nf, S, rt, jit, jit_o)
             o = O.field_forward(sd_s, cfg_s, rays_n, ts, xyz, z, valid, rt, dynamic=False)
-            _, ind_disp_n = O.induce_flow(H, W, focal, pose_n, o[4], o[3], grid, rays_n, rt)
+            _, ind_disp_n = O.induce_flow(H, W, focal, pose_n, o[4], o[3], px, rays_n, rt)
             loss_s = loss_s + 0.04 * temp_static * masked_mean((ind_disp - ind_disp_n).abs(), mm)
         loss_s = loss_s + cfg["monodepth_static"] * temp_static * O.frame_depth_loss(to_depth(depth_s), gt_depth, view,
                                                                                      T, mask=fg < 0.5)

@@ -174,12 +174,14 @@ class SyntheticScene:
         pix = torch.arange(self.total)
         col, row, view = pix % W, (pix // W) % H, pix // (W * H)
         self.grid_table = torch.stack([col.float() + 0.5, row.float() + 0.5], -1).to(device)
+        # `allgrids` of the reference (train.py:974-978): the INTEGER pixel coordinates -- what induce_flow subtracts
+        self.px_table = torch.stack([col.float(), row.float()], -1).to(device)
         self.view_table = view.to(device)
         self.ts_table = (view.float() * (2.0 / (T - 1)) - 1.0).to(device)
         # packed copies for make_batch: one gather per SHAPE class instead of one per tensor (11 launches -> 5);
         # row k of a packed gather is a contiguous tensor
         self._scalars = torch.stack([self.ts_table, self.disp, self.fgmask, self.flow_mask_f[:, 0], self.flow_mask_b[:, 0]])
-        self._vec2 = torch.stack([self.flow_f, self.flow_b, self.grid_table])
+        self._vec2 = torch.stack([self.flow_f, self.flow_b, self.grid_table, self.px_table])
 
     def batch(self, it, bs, which=0):
         off = ((it * 3 + which) * bs) % (self.total - bs)
@@ -196,7 +198,7 @@ class SyntheticScene:
             lo, hi = r * bs // w, (r + 1) * bs // w
             ids, ids2 = ids[lo:hi], ids2[lo:hi]
         sc, v2 = self._scalars[:, ids], self._vec2[:, ids]
-        return dict(ids=ids, ts=sc[0], ts_rand=self.ts_of(ids2), grid=v2[2], view=self.view_table[ids], rgb=self.rgb[ids],
+        return dict(ids=ids, ts=sc[0], ts_rand=self.ts_of(ids2), grid=v2[2], px=v2[3], view=self.view_table[ids], rgb=self.rgb[ids],
                     disp=sc[1], fg=sc[2], flow_f=v2[0], flow_b=v2[1], mask_f=sc[3][:, None], mask_b=sc[4][:, None])
 
 
@@ -437,6 +439,9 @@ class Trainer:
         else:
             col, row, view = ids2pixel(W, H, ids)
             grid = torch.stack([col.float() + 0.5, row.float() + 0.5], -1)
+        # pts_2d of induce_flow is `grid_train = allgrids[ray_idx]` (train.py:1046, 974-978): the integer pixel coordinates,
+        # while the flow-displaced rays start from the pixel centres (`v_ref + 0.5`, train.py:1433-1436) = `grid`
+        px = b["px"] if "px" in b else grid - 0.5
         if self.optimize_poses:
             c2w_all = pose_to_mtx(poses)
         else:   # fixed poses: the [T,3,4] table is a constant of the run
@@ -518,7 +523,7 @@ class Trainer:
         for sgn, sf, flow_t, mask_t in ((1, sf_f, b["flow_f"], b["mask_f"]), (-1, sf_b, b["flow_b"], b["mask_b"])):
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)].detach()
             pts_n = pts_ref + sf if rt == "ndc" else torch.clamp(pts_ref + sf, min=-2.0 + 1e-6, max=2.0 - 1e-6)
-            ind_flow, ind_disp = induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, grid, rays_d, ray_type=rt)
+            ind_flow, ind_disp = induce_flow(H, W, focal_d, pose_n, weights_d, pts_n, px, rays_d, ray_type=rt)
             Ld.add(0.01 * temp, "abs", ind_flow, flow_t, w=mask_t, norm="weight")       # :1392-1410 (x 0.02 / 2)
             disp_A[sgn] = (ind_disp, mask_t, pose_n, flow_t)
         # ---- pass C / D: the flow-displaced rays of the neighbour frames (train.py:1433-1528, 1530-1625)
@@ -530,7 +535,7 @@ class Trainer:
             else:
                 rays_n = self.rays_for(ids, poses_d, focal_d, uv=grid + flow_t, view_shift=sgn)
                 _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts + sgn * dt, S, rt, rng)
-            _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], grid, rays_n, ray_type=rt)
+            _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], px, rays_n, ray_type=rt)
             Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
             if w_dist > 0:
                 Ld.add(w_dist, "identity", distloss_rays(outN[11], oN[8].detach(), 1.0 / S))
@@ -542,7 +547,7 @@ class Trainer:
         if c["dist_static"] > 0 and it > 0:       # train.py:1841-1861
             Ls.add(c["dist_static"] * (it / c["n_iters"]), "identity", distloss_rays(outE[7], oE[8].detach(), 1.0 / S))
         if self.optimize_poses:
-            self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp_disp_tv, temp_static, gt_depth,
+            self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, px, view, m, temp_disp_tv, temp_static, gt_depth,
                              to_depth, Ls)
         # ---- factor-space regularisers (train.py:1718-1754, 1863-1885)
         if c["l1_weight"] > 0:
@@ -554,7 +559,7 @@ class Trainer:
         # while the gradients are finite; only the gradient is taken (step(): TVLoss.accumulate_grad_)
         return loss_d, loss_s
 
-    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, view, m, temp_disp_tv, temp_static, gt_depth,
+    def _pose_block(self, b, rays, oE, outE, poses, focal, c2w_all, grid, px, view, m, temp_disp_tv, temp_static, gt_depth,
                     to_depth, Ls):
         """train.py:1895-2311 (optimize_poses): every term reaches the static field, the poses and the focal."""
         c = self.cfg
@@ -595,7 +600,7 @@ class Trainer:
         for k, (sgn, flow_t, mask_t) in enumerate(((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"]))):
             pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]                       # live: allposes_refine_f / _b
             mm = mask_t * m
-            ind_flow, ind_disp = induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, grid, rays, ray_type=rt)
+            ind_flow, ind_disp = induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, px, rays, ray_type=rt)
             Ls.add(0.01 * temp_static, "abs", ind_flow, flow_t, w=mm, norm="weight")    # :1909-1941 (x 0.02 / 2)
             # P1 / P2: the static field along the flow-displaced ray of the neighbour frame
             if batched:
@@ -606,7 +611,7 @@ class Trainer:
                 xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
                 PASSES.update(static=1, static_grad=1)
                 o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
-            _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], xyz, grid, rays_n, ray_type=rt)
+            _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], xyz, px, rays_n, ray_type=rt)
             Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
         Ls.add(1.0, "identity", frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5,

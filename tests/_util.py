@@ -97,3 +97,45 @@ def pass_structure_draws(p, ray_type):
     else:
         jit = [(p["A.jitter"], p["A.jitter_outer"]), (p["E.jitter"], p["E.jitter_outer"])]
     return jit, [bool(p["A.white"]), bool(p["E.white"])]
+
+
+TRAINER_ITERS = ["nvidia", "nvidia_late", "nvidia_no_poses", "davis"]
+
+
+def load_trainer_iter(name):
+    """tests/golden/trainer_iter_<name>.npz (make_golden_trainer.py: iteration 0 of the reference's OWN
+    train.reconstruction() on a synthetic dataset, stopped at the first optimizer.step()).  Returns
+    (fixture dict, trainer-config dict, batch dict, sd_s, sd_d, poses9, focal_or_fov, (jitters, coins))."""
+    z = np.load(os.path.join(GOLDEN, f"trainer_iter_{name}.npz"))
+    p = {k: z[k] for k in z.files}
+    t = lambda k: torch.from_numpy(np.array(p[k]))
+    m = lambda k: p["meta." + k]
+    rt, opt_poses = str(m("ray_type")), bool(m("optimize_poses"))
+    H, W, T = int(m("H")), int(m("W")), int(m("T"))
+    cfg = dict(aabb=m("aabb").tolist(), near_far=[float(v) for v in m("near_far")], T=T, H=H, W=W, ray_type=rt,
+               batch_size=int(m("batch_size")), static_head=str(m("static_head")), optimize_poses=opt_poses,
+               tv_density=float(m("tv_density")), tv_app=float(m("tv_app")), dist_static=float(m("dist_static")),
+               dist_dynamic=float(m("dist_dynamic")), l1_weight=float(m("l1_weight")), grid=[int(v) for v in m("grid")],
+               n_samples=int(m("n_samples")), name="trainer_iter_" + name, stage="fixture",
+               monodepth_static=float(m("monodepth_static")), monodepth_dynamic=float(m("monodepth_dynamic")),
+               n_iters=int(m("n_iters")), lr_decay_target_ratio=float(m("lr_decay_target_ratio")),
+               small_scene_flow_weight=float(m("small_scene_flow_weight")),
+               smooth_scene_flow_weight=float(m("smooth_scene_flow_weight")),
+               upsamp_list=[int(v) for v in m("upsamp_list")], start_iteration=0, focal=float(p["focal_gt"]))
+    batch = {k[2:]: t(k) for k in p if k.startswith("b.")}
+    sd_s = {k[2:]: t(k) for k in p if k.startswith("s.")}
+    sd_d = {k[2:]: t(k) for k in p if k.startswith("d.")}
+    # draws in call order: per pass the jitter vector(s) (ndc: one [1,S]; contract: inner + outer) then -- when the pass
+    # ends in raw2outputs -- the white-background coin (renderer.py:269: torch.rand((1,)) < 0.5)
+    jit, coins, pend = [], [], []
+    for i in range(int(p["n_draws"])):
+        d = p[f"draw.{i:02d}"]
+        if d.shape == (1,):
+            coins.append(bool(d[0] < 0.5))
+        else:
+            pend.append(d.reshape(-1))
+            if rt == "ndc" or len(pend) == 2:
+                jit.append(pend[0] if rt == "ndc" else (pend[0], pend[1]))
+                pend = []
+    focal = t("fov") if opt_poses else float(p["focal_gt"])
+    return p, cfg, batch, sd_s, sd_d, t("poses9"), focal, (jit, coins)

@@ -489,8 +489,46 @@ def gen_pass_structure(mods):
               f"|g.rays| {float(grads[-1].abs().max()):.3e}")
 
 
+def gen_checkpoint(mods):
+    """models/tensorBase.py:460-485: a `.th` checkpoint of each field WRITTEN BY THE REFERENCE's own save() (the file
+    train.py:2413-2424 writes every progress_refresh_rate iterations: kwargs incl. se3_poses / focal_ratio_refine +
+    state_dict), on the weights of the ndc_relu case, plus what the reference's own reload recipe (train.py:433-447:
+    `Model(**kwargs)`, `.load(ckpt)`) computes from it at a few probe points -- so that loading it here can be checked
+    for values, not only for keys."""
+    TS, TD, _, _, _ = mods
+    case = np.load(os.path.join(HERE, "ndc_relu.npz"), allow_pickle=True)
+    grid = [int(v) for v in case["meta.grid"]]
+    st, dy = build_fields(TS, TD, torch.from_numpy(case["aabb"]), grid, "relu", "MLP_Fea", -10.0, 1)
+    st.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("s.")})
+    dy.load_state_dict({k[2:]: torch.from_numpy(case[k]) for k in case.files if k.startswith("d.")})
+    poses = torch.eye(3, 4)[None].repeat(12, 1, 1) + 0.01 * torch.randn(12, 3, 4, generator=torch.Generator().manual_seed(5))
+    focal = torch.tensor(41.5)
+    probe = {"xn": case["fn.xn"], "t": case["fn.t"]}
+    for tag, m in (("static", st), ("dynamic", dy)):
+        path = os.path.join(HERE, f"reference_ckpt_{tag}.th")
+        m.save(poses, focal, path)
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        kwargs = dict(ckpt["kwargs"])
+        kwargs.pop("se3_poses")
+        kwargs.pop("focal_ratio_refine")
+        kwargs.update({"device": "cpu"})
+        with contextlib.redirect_stdout(io.StringIO()):
+            m2 = type(m)(**kwargs)
+        m2.load(ckpt)
+        xn, tf = torch.from_numpy(probe["xn"]), torch.from_numpy(probe["t"])
+        with torch.no_grad():
+            probe[tag + ".density"] = m2.compute_densityfeature(xn, tf, None).numpy()
+            probe[tag + ".app"] = m2.compute_appfeature(xn, tf, None).numpy()
+        probe[tag + ".nSamples"] = np.array(m2.nSamples)
+    np.savez(os.path.join(HERE, "reference_ckpt_probe.npz"), **probe)
+    print("checkpoint: ok", os.path.getsize(os.path.join(HERE, "reference_ckpt_dynamic.th")), "bytes")
+
+
 if __name__ == "__main__":
     mods = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
+        gen_checkpoint(mods)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fn_grads":
         gen_fn_grads(mods)
         sys.exit(0)
@@ -515,3 +553,4 @@ if __name__ == "__main__":
     gen_tv(mods)
     gen_fn_grads(mods)
     gen_pass_structure(mods)
+    gen_checkpoint(mods)

@@ -97,6 +97,35 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
         assert m2.density_plane[1].stride(1) == 1 and m2.nSamples == m.nSamples
 
 
+def test_reference_written_checkpoint_loads():
+    """A `.th` file written by the REFERENCE's own TensorBase.save (tests/golden/reference_ckpt_*.th,
+    make_golden.gen_checkpoint; models/tensorBase.py:460-470) goes through the reload recipe of train.py:433-447
+    on this package's classes: every state_dict entry bit-identical to the weights the reference saved (the ndc_relu
+    case), kwargs accepted as they are, VM factors re-strided channel-last, derived sizes (nSamples) equal to what the
+    reference's own reload computed (reference_ckpt_probe.npz)."""
+    import os
+    import numpy as np
+    import rodynrf
+    from _util import GOLDEN, load_case
+    g, sd_s, _, sd_d, _ = load_case("ndc_relu")
+    probe = np.load(os.path.join(GOLDEN, "reference_ckpt_probe.npz"))
+    for tag, cls, sd in (("static", rodynrf.TensorVMSplit, sd_s), ("dynamic", rodynrf.TensorVMSplit_TimeEmbedding, sd_d)):
+        ckpt = torch.load(os.path.join(GOLDEN, f"reference_ckpt_{tag}.th"), map_location="cpu", weights_only=False)
+        assert set(ckpt.keys()) == {"kwargs", "state_dict"}
+        kwargs = dict(ckpt["kwargs"])
+        assert kwargs.pop("se3_poses").shape == (12, 3, 4) and abs(float(kwargs.pop("focal_ratio_refine")) - 41.5) < 1e-6
+        kwargs.update({"device": "cpu"})
+        m = cls(**kwargs)
+        m.load(ckpt)
+        got = m.state_dict()
+        assert set(got.keys()) == set(sd.keys()) == set(ckpt["state_dict"].keys())
+        for k, v in sd.items():
+            assert torch.equal(got[k], v), k
+        assert all(pl.stride(1) == 1 for pl in m.density_plane) and all(pl.stride(1) == 1 for pl in m.app_plane)
+        assert m.nSamples == int(probe[tag + ".nSamples"])
+        assert m.get_kwargs().keys() == {k for k in ckpt["kwargs"] if k not in ("se3_poses", "focal_ratio_refine")}
+
+
 def test_sincos_pe_formula():
     """csrc/rdrf_common.hpp sincos_pe (the positional encodings' sin / cos): two-constant Cody-Waite reduction +
     Cephes minimax polynomials, restated here in numpy fp32 (fma emulated through fp64) and bounded against fp64

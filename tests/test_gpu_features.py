@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import CASES, GOLDEN, assert_close
+from _util import CASES, FWD_ELEM, GOLDEN, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -278,3 +278,26 @@ def test_packed_weight_images_follow_the_weights():
     upd3 = run()
     assert not torch.equal(upd3[0], upd2[0])
     assert all(torch.equal(x, y) for x, y in zip(upd3, uncached()))
+
+
+def test_reference_written_checkpoint_evaluates_like_the_reference():
+    """tests/golden/reference_ckpt_*.th (written by the reference's TensorBase.save) loaded on the GPU through the reload
+    recipe of train.py:433-447: compute_densityfeature / compute_appfeature at the probe points equal what the
+    REFERENCE's own reload of the same file computed (reference_ckpt_probe.npz)."""
+    import os
+    import numpy as np
+    import rodynrf
+    from _util import GOLDEN
+    probe = np.load(os.path.join(GOLDEN, "reference_ckpt_probe.npz"))
+    xn, t = torch.from_numpy(probe["xn"]).cuda(), torch.from_numpy(probe["t"]).cuda()
+    for tag, cls in (("static", rodynrf.TensorVMSplit), ("dynamic", rodynrf.TensorVMSplit_TimeEmbedding)):
+        ckpt = torch.load(os.path.join(GOLDEN, f"reference_ckpt_{tag}.th"), map_location="cpu", weights_only=False)
+        kwargs = dict(ckpt["kwargs"])
+        kwargs.pop("se3_poses")
+        kwargs.pop("focal_ratio_refine")
+        kwargs.update({"device": "cuda:0"})
+        m = cls(**kwargs)
+        m.load(ckpt)
+        with torch.no_grad():
+            assert_close(m.compute_densityfeature(xn, t, None), probe[tag + ".density"], tag + ".density", elem=FWD_ELEM)
+            assert_close(m.compute_appfeature(xn, t, None), probe[tag + ".app"], tag + ".app", elem=FWD_ELEM)

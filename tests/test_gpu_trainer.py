@@ -459,3 +459,76 @@ def test_batched_passes_match_one_pass_per_launch(name, stage, it, monkeypatch):
         record_margin("batched vs per-pass gradient (rel. L2 / 1e-5)", rel / 1e-5)
         assert rel < 1e-5, rel
         assert_close(a, b_, "batched vs per-pass gradient", rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["nvidia", "nvidia_late", "nvidia_no_poses", "davis"])
+def test_trainer_step_matches_reference_trainer_iteration(name):
+    """SURVEY 8a row 13, the whole iteration pinned to the REFERENCE: Trainer.step (batched passes, fused loss terms,
+    two-phase backward, TV gradient) against the gradients the reference's own train.reconstruction() produced at
+    iteration 0 (tests/golden/trainer_iter_*.npz, make_golden_trainer.py) -- passes A-E, the pose block P1-P4, every loss
+    term with its gate and weight -- on the same weights, batch, jitter vectors and coins: every parameter of both
+    fields, the pose table and the field of view at 1e-4 of each tensor's max, element by element.  Where two fp32
+    evaluation orders of the same iteration legitimately differ (a relu unit on its kink: see
+    test_oracle_step_matches_reference_trainer_iteration) the element is allowed the distance between the oracle's
+    fp32 and fp64 evaluations on top."""
+    from _util import load_trainer_iter
+    from oracle import rodynrf_oracle_step as OS
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    p, cfg, batch, sd_s, sd_d, poses, focal, draws = load_trainer_iter(name)
+    dev = torch.device("cuda", 0)
+    tr = S_.Trainer(dict(cfg), dev, dead_work=True)
+    tr.st.load_state_dict(sd_s)
+    tr.dy.load_state_dict(sd_d)
+    for f in (tr.st, tr.dy):
+        f.invalidate_packed()
+    if tr.optimize_poses:
+        with torch.no_grad():
+            tr.poses.copy_(poses.to(dev))
+            tr.fov.copy_(focal.to(dev))
+    else:
+        tr.data.poses, tr.data.focal = poses.to(dev), torch.tensor(float(focal), device=dev)
+    tr.it = 0
+    tr.rng = OS.ReplayRng(*draws)
+    H, W = cfg["H"], cfg["W"]
+    b = {k: v.to(dev) for k, v in batch.items()}
+    col, row, view = b["ids"] % W, (b["ids"] // W) % H, b["ids"] // (W * H)
+    b.update(grid=torch.stack([col.float() + 0.5, row.float() + 0.5], -1), px=torch.stack([col.float(), row.float()], -1),
+             view=view)
+    tr.data.make_batch = lambda it, bs, shard=None: b
+    tr.step()
+    assert not tr.rng.jitters and not tr.rng.coins, "the trainer consumed a different number of draws than the reference"
+    # the oracle's fp32 / fp64 evaluations of the same iteration: their distance is the kink / conditioning allowance
+    _, g32 = OS.step_gradients(cfg, sd_s, sd_d, batch, poses, focal, 0, OS.ReplayRng(*draws), dead_work=True)
+    torch.set_default_dtype(torch.float64)
+    try:
+        cv = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+        _, g64 = OS.step_gradients(cfg, {k: cv(v.detach()) for k, v in sd_s.items()}, {k: cv(v.detach()) for k, v in sd_d.items()},
+                                   {k: cv(v) for k, v in batch.items()}, cv(poses), cv(focal), 0, OS.ReplayRng(*draws),
+                                   dead_work=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    bad, n = [], 0
+
+    def check(label, got, ref, o32, o64, scale, rtol):
+        a, r = got.detach().cpu().double().reshape(ref.shape), ref.double()
+        tol = rtol * scale + 2.0 * (o32.detach().double().reshape(ref.shape) - o64.double().reshape(ref.shape)).abs()
+        err = (a - r).abs()
+        record_margin(label, float((err / tol.clamp_min(1e-30)).max()))
+        if not bool((err <= tol + 1e-12).all()):
+            i = int((err - tol).argmax())
+            bad.append(f"{label}: |err| {float(err.flatten()[i]):.3e} > {rtol:.0e} * {scale:.3e} + allowance {float(tol.flatten()[i]) - rtol * scale:.3e}")
+
+    for mod, pre, gp in ((tr.st, "s.", "gs."), (tr.dy, "d.", "gd.")):
+        for k, q in mod.named_parameters():
+            ref = torch.from_numpy(p[gp + k])
+            if bool(p[gp.replace("g", "gnone_", 1) + k]):
+                assert q.grad is None or float(q.grad.abs().max()) == 0.0, f"{pre}{k}: the reference graph never reaches it"
+                continue
+            n += 1
+            check(pre + k, q.grad, ref, g32[pre + k], g64[pre + k], float(ref.abs().max()), 1e-4)
+    if tr.optimize_poses:
+        ps = float(np.abs(p["g.poses"]).max())
+        check("poses", tr.poses.grad, torch.from_numpy(p["g.poses"]), g32["poses"], g64["poses"], ps, 1e-4)
+        check("fov", tr.fov.grad, torch.from_numpy(p["g.fov"]), g32["fov"], g64["fov"],
+              max(float(np.abs(p["g.fov"]).max()), 1e-2 * ps), 1e-4)
+    assert n > 60 and not bad, "\n".join(bad)
