@@ -146,13 +146,33 @@ def self_spawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def timed_steps(trainer, shard, steps, warmup, world, dev):
+def mask_fractions(S_, trainer, n_rays=None):
+    """(valid, app_mask_static, app_mask_dynamic) of the CURRENT weights on a fixed probe batch: the work of the appearance
+    kernels, their scatters and dW products follows the app-mask fractions, and those move as the weights train (random
+    initialiser: ~0.5 / ~0.74; after ~40 iterations ~0.46 / ~0.35)"""
+    import torch
+    cfg = trainer.cfg
+    with torch.no_grad():
+        ids = trainer.data.batch(0, n_rays or min(cfg["batch_size"], 4096), 0)
+        rays = trainer.rays_for(ids).detach()
+        ts = trainer.data.ts_of(ids)
+        o_s, o_d, _, smp = S_.ray_pass(trainer.st, trainer.dy, rays, ts, cfg["n_samples"], cfg["ray_type"], S_.StepRng(),
+                                       is_train=False)
+        _, _, vmask = S_.sampleXYZ(trainer.dy, rays, cfg["n_samples"], ray_type=cfg["ray_type"], is_train=False)
+        return (float(vmask.float().mean()), float((o_s[4] > 1e-4).float().mean()), float((o_d[4] > 1e-4).float().mean()))
+
+
+def timed_steps(trainer, shard, steps, warmup, world, dev, fractions=None):
+    """W untimed + K timed iterations; `fractions` (dict) receives the app-mask fractions at the first and after the last
+    timed iteration (probe forwards outside the timed region)"""
     import torch
     import torch.distributed as dist
     loss = None
     for _ in range(warmup):
         trainer.step(shard)
         trainer.finish_step()
+    if fractions is not None:
+        fractions["start"] = mask_fractions(fractions["S_"], trainer)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -170,6 +190,8 @@ def timed_steps(trainer, shard, steps, warmup, world, dev):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if fractions is not None:
+        fractions["end"] = mask_fractions(fractions.pop("S_"), trainer)
     return dt / steps, loss
 
 
@@ -181,26 +203,36 @@ KERNELS = ["pack", "generate_rays", "generate_rays_bwd", "sample_ndc", "sample_c
            "dw_static", "scene_flow_bwd", "dw_sf", "adam"]
 
 
-def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
-    """per-kernel HIP-event timings of NP profiled steps + the algorithmic byte / FLOP counts of DESIGN.md 6"""
+def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
+    """per-kernel HIP-event timings of the profiled steps + the algorithmic byte / FLOP counts of DESIGN.md 6.
+    window = (make_trainer, warmup, steps): the profiled steps are iterations warmup .. warmup + steps of a FRESH trainer
+    (same seeds, same batches, same draws as the timed run), i.e. the SAME training states the timed region covered --
+    the appearance work follows the app-mask fractions, which fall from ~0.74 to ~0.35 (dynamic field) over the first
+    ~40 iterations from the reference initialiser, so kernel times taken at a later state cannot be set against
+    `ms_per_step`.  Without `window`: 3 steps at the trainer's current state."""
     import torch
-    with torch.no_grad():
-        ids = trainer.data.batch(0, rays_per_gpu, 0)
-        rays = trainer.rays_for(ids).detach()
-        ts = trainer.data.ts_of(ids)
-        o_s, o_d, _, _ = S_.ray_pass(trainer.st, trainer.dy, rays, ts, cfg["n_samples"], cfg["ray_type"], S_.StepRng())
-        _, _, vmask = S_.sampleXYZ(trainer.dy, rays, cfg["n_samples"], ray_type=cfg["ray_type"], is_train=True)
-        valid_frac = float(vmask.float().mean())
-        f_d = float((o_d[4] > 1e-4).float().mean())
-        f_s = float((o_s[4] > 1e-4).float().mean())
+    own = None
+    if window is not None:
+        make_trainer, w_steps, NP = window
+        own = trainer = make_trainer()
+        for _ in range(w_steps):
+            trainer.step(shard)
+            trainer.finish_step()
+    else:
+        NP = 3
+    fr0 = mask_fractions(S_, trainer, rays_per_gpu)
+    torch.cuda.synchronize()
     L.lib.rdrf_prof_enable(1)
     L.lib.rdrf_prof_reset()
-    NP = 3
     S_.PASSES.clear()
     for _ in range(NP):
         trainer.step(shard)
         trainer.finish_step()
     torch.cuda.synchronize()
+    L.lib.rdrf_prof_enable(0)
+    fr1 = mask_fractions(S_, trainer, rays_per_gpu)
+    # the window's mean fractions price the appearance work of the profiled steps
+    valid_frac, f_s, f_d = (0.5 * (a + b) for a, b in zip(fr0, fr1))
     # ray-passes per step by kind: the algorithmic counts below are per PASS (4096 rays x S samples); a batched launch
     # (step.ray_passes) covers several
     np_stat, np_stat_g = S_.PASSES["static"] / NP, S_.PASSES["static_grad"] / NP
@@ -219,7 +251,6 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         if n:
             table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}
             tot_ms += msk / NP
-    L.lib.rdrf_prof_enable(0)
     # passes per step each kernel family processes (its launches unless step.ray_passes batches them)
     mult = {k: v["launches_per_step"] for k, v in table.items()}
     for k in ("static_density", "static_app"):
@@ -319,7 +350,16 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         "ray_passes_per_step": {"static": np_stat, "static_with_grad": np_stat_g, "dynamic": np_dyn,
                                 "dynamic_with_grad": np_dyn_bwd},
         "sum_kernel_ms_per_step": tot_ms,
-        "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s},
+        "profiled_steps": NP,
+        "profiled_window": ("iterations warmup .. warmup + steps of a fresh trainer: the states of the timed region"
+                            if window is not None else "3 iterations at the trainer's current state"),
+        "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s,
+                      "at_window_start": {"app_mask_static": fr0[1], "app_mask_dynamic": fr0[2]},
+                      "at_window_end": {"app_mask_static": fr1[1], "app_mask_dynamic": fr1[2]}},
+        # fp32-MFMA fraction of every MLP kernel of the profiled steps (algorithmic FLOP of the passes it ran / its HIP-event
+        # time / 157.3 TFLOP/s): the physical figure of the kernels that are not atomic-bound
+        "mfma_frac": {k: round(flops[k] * mult[k] / (table[k]["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                      for k in table if k in flops and table[k]["ms_per_step"] > 0},
         "pmc_profile": _profile_csv("pmc_fetch")[1],
     })
     # SURVEY.md section 8(d) canonical constants: per sample B_fwd(f) = 4032 + 6912 f bytes, F_fwd(f) = 66004 +
@@ -339,10 +379,18 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms):
         "note": f"SURVEY 8(d) constants with {npass} ray-passes per training ray; branches without a loss are not "
                 "differentiated (as in the reference's autograd), so this counts more work than is executed; "
                 "step_frac_of_peak counts only what runs; gather bytes are L2/MALL-resident algorithmic bytes"}
+    if own is not None:
+        del own
     return out
 
 
-def render_leg(R, trainer, cfg, dev, chunk, frames=5):
+RENDER_KERNELS = ["pack", "sample_ndc", "sample_contract", "static_density", "static_app", "time_branch", "dyn_density", "dyn_app",
+                  "composite", "render_fused"]
+
+
+def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5):
+    """BASELINE.json's second metric: Mpix/s of the no-grad chunk loop of renderer.py:740-812 (+ its roofline: SURVEY 8(d)
+    F_fwd / B_fwd per sample x samples / time, with the two fields' measured app-mask fractions of THIS frame)."""
     import torch
     H, W = cfg["H"], cfg["W"]
     ids = torch.arange(H * W, device=dev)
@@ -361,8 +409,48 @@ def render_leg(R, trainer, cfg, dev, chunk, frames=5):
         frame()
     torch.cuda.synchronize()
     dtf = (time.perf_counter() - t0) / frames
-    return {"value": H * W / dtf / 1e6, "unit": "Mpix/s", "frame": [H, W], "chunk": chunk,
-            "samples_per_ray": cfg["n_samples"], "ms_per_frame": dtf * 1e3}
+    out = {"value": H * W / dtf / 1e6, "unit": "Mpix/s", "frame": [H, W], "chunk": chunk,
+           "samples_per_ray": cfg["n_samples"], "ms_per_frame": dtf * 1e3}
+    # ---- roofline of the frame: per-kernel HIP events of one more frame, the frame's own app-mask fractions
+    with torch.no_grad():
+        o_s, o_d, _, _ = S_.ray_pass(trainer.st, trainer.dy, rays_f, ts_f, cfg["n_samples"], cfg["ray_type"], S_.StepRng(),
+                                     is_train=False)
+        f_s, f_d = float((o_s[4] > 1e-4).float().mean()), float((o_d[4] > 1e-4).float().mean())
+    torch.cuda.synchronize()
+    L.lib.rdrf_prof_enable(1)
+    L.lib.rdrf_prof_reset()
+    frame()
+    torch.cuda.synchronize()
+    L.lib.rdrf_prof_enable(0)
+    table = {}
+    for k in RENDER_KERNELS:
+        msk, n = prof_get(L, k)
+        if n:
+            table[k] = {"ms_per_frame": round(msk, 4), "launches": n}
+    ns = H * W * cfg["n_samples"]
+    flop = ns * (340.0 + F_DYN_DENSITY + f_s * F_STAT_APP + f_d * F_DYN_APP)          # executed, per field fraction
+    gbytes = ns * (576.0 + 3456.0 + f_s * 1728.0 + f_d * 5184.0)                       # VM gather bytes (L2 resident)
+    f_avg = 0.5 * (f_s + f_d)
+    flop_survey, bytes_survey = ns * (66004.0 + 145362.0 * f_avg), ns * (4032.0 + 6912.0 * f_avg)   # SURVEY 8(d) constants
+    kern_ms = sum(v["ms_per_frame"] for k, v in table.items() if k != "render_fused" or len(table) == 1)
+    mfma = {}
+    for k, f in (("dyn_density", ns * F_DYN_DENSITY), ("dyn_app", ns * f_d * F_DYN_APP), ("static_app", ns * f_s * F_STAT_APP)):
+        if k in table and table[k]["ms_per_frame"] > 0:
+            mfma[k] = round(f / (table[k]["ms_per_frame"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    out["roofline"] = {
+        "bound": "mfma", "achieved": flop / dtf / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": flop / dtf / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        "gather_bytes_nominal": {"achieved": gbytes / dtf / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": gbytes / dtf / 1e9 / PEAK_HBM_GBS,
+                                 "note": "algorithmic VM gather bytes / time against the HBM peak: the bytes are L2 / MALL resident"},
+        "survey_canonical": {"f_app": f_avg, "frac_flop": flop_survey / dtf / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                             "frac_bytes": bytes_survey / dtf / 1e9 / PEAK_HBM_GBS},
+        "fractions": {"app_mask_static": f_s, "app_mask_dynamic": f_d},
+        "kernel_ms_per_frame": {k: v["ms_per_frame"] for k, v in table.items()},
+        "kernel_launches_per_frame": {k: v["launches"] for k, v in table.items()},
+        "sum_kernel_ms_per_frame": kern_ms, "mfma_frac": mfma,
+        "source": "HIP events of one frame of this run (rdrf_prof_*); ms_per_frame is the wall clock of the timed frames"}
+    return out
 
 
 def main():
@@ -418,7 +506,12 @@ def main():
                          dp_exact_stats=not args.dp_per_shard_stats)
     shard = (rank, world)
 
-    dt, loss = timed_steps(trainer, shard, args.steps, args.warmup, world, dev)
+    def make_trainer():
+        return S_.Trainer(dict(cfg), dev, weights=args.weights, dead_work=not args.exploit_liveness, dp_mode=args.dp,
+                          dp_exact_stats=not args.dp_per_shard_stats)
+
+    frs = {"S_": S_}
+    dt, loss = timed_steps(trainer, shard, args.steps, args.warmup, world, dev, fractions=frs)
     ms = dt * 1e3
     value = cfg["batch_size"] / dt
     loss_val = float(loss.item())
@@ -444,6 +537,11 @@ def main():
                    "loss_statistics": ("whole batch (all-reduced mask sums, gathered per-frame depth statistics)"
                                        if trainer._dp() is not None else "single process"),
                    "final_loss": loss_val,
+                   "app_mask_fractions_over_the_timed_steps": {
+                       "first": {"static": frs["start"][1], "dynamic": frs["start"][2]},
+                       "last": {"static": frs["end"][1], "dynamic": frs["end"][2]},
+                       "note": "the appearance kernels' work follows these; they fall as the reference-initialised weights "
+                               "train, so a 20-step window right after start-up times a heavier step than a 200-step one"},
                    "dead_dynamic_forwards": "skipped (dead work, SURVEY 3.1)" if args.exploit_liveness
                    else "executed (dead work the reference also computes)"},
     }
@@ -456,15 +554,18 @@ def main():
                                      "note": "dead dynamic forwards skipped (SURVEY 3.1: nothing consumes them)"}
         trainer.dead_work = True
     if not args.no_roofline:   # collective: every rank runs the profiled steps (rank 0 reports)
-        rf = roofline(L, S_, trainer, cfg, shard, rpg, ms)
+        # the profiled steps replay the timed region's own iterations on a fresh trainer (same seeds): a kernel sum that can
+        # be set against ms_per_step
+        rf = roofline(L, S_, trainer, cfg, shard, rpg, ms, window=(make_trainer, args.warmup, min(args.steps, 400)))
         if rank == 0:
             out["roofline"] = rf
+            out["roofline"]["ms_per_step_minus_kernel_sum"] = ms - rf["sum_kernel_ms_per_step"]
     if rank == 0 and world == 1 and not args.no_render:
         # BASELINE.json's second metric: render Mpix/s through the no-grad chunk loop of renderer.py:740-812 --
         # whole frames per call, and the reference's own eval chunk of 512 rays (renderer.py:732)
         H, W = cfg["H"], cfg["W"]
-        out["render"] = render_leg(R, trainer, cfg, dev, args.render_chunk or H * W)
-        out["render_chunk512"] = render_leg(R, trainer, cfg, dev, 512, frames=2)
+        out["render"] = render_leg(L, R, S_, trainer, cfg, dev, args.render_chunk or H * W)
+        out["render_chunk512"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=2)
     if rank == 0 and world == 1 and not args.no_final_stage and args.config == "nvidia" and args.stage == "stage0":
         # 78 % of the reference's iterations run after the last upsampling (configs/Nvidia.txt: upsamp_list[-1] =
         # 22000 of 100000): the same step at the final resolution
@@ -479,7 +580,7 @@ def main():
             fin["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_step",
                                                   "step_frac_of_peak", "kernel_ms_per_step", "fractions")}
         if not args.no_render:
-            fin["render"] = render_leg(R, tr_f, cfg_f, dev, cfg_f["H"] * cfg_f["W"], frames=3)
+            fin["render"] = render_leg(L, R, S_, tr_f, cfg_f, dev, cfg_f["H"] * cfg_f["W"], frames=3)
         out["final_stage"] = fin
         del tr_f
     if rank == 0 and world == 1 and not args.no_sparse and args.weights == "dense":
@@ -492,7 +593,7 @@ def main():
             sp["fractions"] = rf["fractions"]
             sp["kernel_ms_per_step"] = rf["kernel_ms_per_step"]
         if not args.no_render:
-            sp["render"] = render_leg(R, tr_s, cfg, dev, cfg["H"] * cfg["W"], frames=3)
+            sp["render"] = render_leg(L, R, S_, tr_s, cfg, dev, cfg["H"] * cfg["W"], frames=3)
         out["sparse_weights"] = sp
         del tr_s
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

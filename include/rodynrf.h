@@ -36,15 +36,18 @@ extern "C" {
 #endif
 
 /* 2: RdrfStaticParams / RdrfDynamicParams grew the trailing packed_fwd / packed_bwd pointers (round 2);
- * 3: sorted scatter workspace + fused render entry points (round 3).  A binding built against another version must
- * refuse to load: the structs are passed by pointer and read to their full length. */
-#define RDRF_ABI_VERSION 3
+ * 3: sorted scatter workspace + fused render entry points (round 3);
+ * 4: rdrf_set_scatter_mode replaces the RDRF_SCATTER / RDRF_RENDER environment switches -- no entry point reads the
+ *    caller's environment any more (round 4).  A binding built against another version must refuse to load: the structs
+ *    are passed by pointer and read to their full length. */
+#define RDRF_ABI_VERSION 4
 
 typedef void* rdrf_stream_t; /* hipStream_t */
 
 enum { RDRF_RAY_NDC = 0, RDRF_RAY_CONTRACT = 1, RDRF_RAY_OTHER = 2 };
 enum { RDRF_ACT_RELU = 0, RDRF_ACT_SOFTPLUS = 1 };
 enum { RDRF_HEAD_MLP_FEA = 0, RDRF_HEAD_MLP_FEA_TIMEEMBEDDING = 1 };
+enum { RDRF_SCATTER_RAY = 0, RDRF_SCATTER_SORTED = 1, RDRF_SCATTER_AUTO = 2 };
 
 /* One vector-matrix factor set (3 planes + 3 lines).  Components are always contiguous (channel
  * stride 1); the texel strides are explicit so that the planes containing the ray-marching axis can
@@ -398,7 +401,7 @@ int rdrf_frame_depth_loss_bwd(const float* g_raw, const float* out, const float*
  *                             with each phase's weight image).  Same device code as the per-phase kernels: identical bits.
  *   rdrf_render_sequence_fwd  the per-phase kernels as a launch sequence (11 stream operations).
  *   rdrf_render_fwd           the launch sequence (measured faster at every size on MI355X: 274 vs 378 us per 512-ray
- *                             chunk, equal on whole frames; csrc/rdrf_render.hip); RDRF_RENDER=fused selects the single launch. */
+ *                             chunk, equal on whole frames; csrc/rdrf_render.hip). */
 size_t rdrf_render_workspace_bytes(int N, int S);
 int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
                     const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
@@ -412,6 +415,12 @@ int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg
                              const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
                              const float* ts, int N, int S, float near, float far, float* rgb_map,
                              float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
+/* ---- process-wide choice of the density / blending scatter of the dynamic field's backward (models/tensoRF.py:646-811,
+ * grid_sampler_2d_backward semantics either way): RDRF_SCATTER_RAY = ray tiles, RDRF_SCATTER_SORTED = samples grouped by
+ * plane cell first (about 10x fewer memory-side atomic requests, a fixed grouping cost per launch), RDRF_SCATTER_AUTO
+ * (default) = sorted from 800 k samples per launch.  Returns 0, or -1 for an unknown mode. */
+int rdrf_set_scatter_mode(int mode);
 
 /* ---- deterministic debugging build (librodynrf_det.so = the same sources with -DRDRF_DETERMINISTIC) ----------------
  * Every addition into a BOUND flat gradient buffer (scatter of the VM factors, line flushes, dW / bias sums, time

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DETERMINISTIC = os.environ.get("RDRF_DETERMINISTIC", "0") == "1"
 LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf_det.so" if DETERMINISTIC else "librodynrf.so"))  # RDRF_LIB: A/B builds
 
-ABI_VERSION = 3   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
+ABI_VERSION = 4   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
 
 RAY_TYPES = {"ndc": 0, "contract": 1}
 ACTS = {"relu": 0, "softplus": 1}
@@ -112,9 +112,17 @@ SYMBOLS = [
     "rdrf_loss_terms_stats", "rdrf_loss_terms_finish", "rdrf_deterministic", "rdrf_det_bind", "rdrf_det_finish",
     "rdrf_render_fused_fwd", "rdrf_render_sequence_fwd",
     "rdrf_frame_depth_loss_workspace_bytes", "rdrf_frame_depth_loss_fwd", "rdrf_frame_depth_loss_bwd",
-    "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_selftest_mlp", "rdrf_prof_reset",
+    "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_set_scatter_mode", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]
+
+
+SCATTER_MODES = {"ray": 0, "sorted": 1, "auto": 2}
+
+
+def set_scatter_mode(mode):
+    """rdrf_set_scatter_mode: "auto" (default: sorted from 800 k samples per launch) | "ray" | "sorted" """
+    check(lib.rdrf_set_scatter_mode(SCATTER_MODES[mode]), "rdrf_set_scatter_mode")
 
 
 class RdrfTensor4(C.Structure):

@@ -1824,124 +1824,7 @@ struct DwJob {
 struct DwJobs {
   DwJob j[RDRF_MAX_DW_JOBS];
   int n;
-  // work items (one wave each; nbo * ceil(nblk/4) per job).  A job's items are kept inside one
-  // 4-wave workgroup whenever they fit (item0 is padded to a multiple of 4 otherwise): the waves of a
-  // workgroup walk the same tiles at the same time, so the dz block shared by the in-groups of one
-  // out-block and the input blocks shared by all out-blocks are fetched from HBM once and hit in
-  // L1/L2 for the other waves (PMC before: 3.73 GB fetched per launch for 2.45 GB of unique rows).
-  int item0[RDRF_MAX_DW_JOBS], nitems[RDRF_MAX_DW_JOBS], total_items;
 };
-
-__global__ __launch_bounds__(256, 2) void k_dw(DwJobs jobs) {
-  // per wave: the dz block + up to four input blocks of the current tile, 256 x 16 B each,
-  // XOR-swizzled (position of (row, 16-byte chunk c) = row*8 + (c ^ ((row>>1)&7))) so that both the
-  // coalesced writes (lane -> row 8i + lane/8, chunk lane%8) and the operand reads (lane -> row li,
-  // chunk 4h+q) are bank-conflict free
-  __shared__ f32x4 stage[4][5 * 256];
-  const int lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
-  const int wave = threadIdx.x >> 6;
-  const int item = blockIdx.y * 4 + wave;
-  int ji = -1;
-  for (int i = 0; i < jobs.n; ++i)
-    if (item >= jobs.item0[i] && item < jobs.item0[i] + jobs.nitems[i]) ji = i;
-  if (ji < 0) return;   // padding slot
-  const DwJob& J = jobs.j[ji];
-  const int local = item - jobs.item0[ji];
-  const int ngrp = (J.nblk + 3) >> 2;
-  const int bo = local / ngrp, grp = local - bo * ngrp;
-  // input blocks are split EVENLY over the groups (6 -> 3 + 3, not 4 + 2): the waves of a workgroup
-  // sit on different SIMDs, so unequal items leave the SIMDs of the light ones idle
-  const int per = (J.nblk + ngrp - 1) / ngrp;
-  const int b0 = grp * per;
-  const int nb = (J.nblk - b0) < per ? (J.nblk - b0) : per;
-  const int ntiles = J.count ? ((*J.count + 31) >> 5) : J.ntiles;
-  f32x16 acc[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-  float bsum = 0.f;
-  // Rows are [32 samples] fp32 = 128 B and the MFMA wants lane (li, h) to hold 16 samples of row li.
-  // Loading that directly (16 B per lane from 64 different 64-byte lines per instruction) made the
-  // kernel L1-tag-rate bound (ablation: loads alone 4.15 ms/step, MFMAs alone 3.34, HBM bytes
-  // irrelevant).  So each instruction now reads 1 KB CONTIGUOUS (8 rows, 16 lines), the tile goes
-  // through the wave's LDS stage, and ds_read_b128 delivers the operand layout.  The global loads of
-  // the wave's next tile are issued before the MFMAs of the current one.
-  int brow[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) brow[b] = J.blk_row0[b0 + (b < nb ? b : nb - 1)];
-  f32x4* my = stage[wave];
-  int wpos[4], rpos[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * i + (lane >> 3);
-    wpos[i] = row * 8 + ((lane & 7) ^ ((row >> 1) & 7));
-    rpos[i] = li * 8 + ((4 * h + i) ^ ((li >> 1) & 7));
-  }
-  f32x4 g[20];
-  auto gload = [&](int t) {
-    const float* ab = J.A + ((size_t)t * J.A_stride + J.A_row0 + bo * 32) * 32 + lane * 4;
-    const float* bb = J.B + (size_t)t * J.B_stride * 32 + lane * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = ld4(ab + i * 256);
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) g[4 + 4 * b + i] = ld4(bb + (size_t)brow[b] * 32 + i * 256);
-  };
-  int t = blockIdx.x;
-  if (t < ntiles) gload(t);
-  while (t < ntiles) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) my[k * 256 + wpos[i]] = g[4 * k + i];
-    __builtin_amdgcn_wave_barrier();
-    const int tn = t + gridDim.x;
-    gload(tn < ntiles ? tn : t);   // unconditional: a redundant reload on the last trip
-    f32x4 av4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) av4[q] = my[rpos[q]];
-    if (grp == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bsum += av4[q].x + av4[q].y + av4[q].z + av4[q].w;
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (b < nb) {
-        f32x4 bv4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv4[q] = my[(1 + b) * 256 + rpos[q]];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].x, bv4[q].x, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].y, bv4[q].y, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].z, bv4[q].z, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].w, bv4[q].w, acc[b], 0, 0, 0);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    t = tn;
-  }
-  // write-out: C row i = (rr&3) + 8*(rr>>2) + 4*h (out neuron), column = li (input element)
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (b < nb) {
-      const int col = seg_imap(J.blk_seg[b0 + b], J.blk_e0[b0 + b] + li, J.in_dim);
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int orow = bo * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h - J.out_row0;
-        if (col >= 0 && orow >= 0 && orow < J.out_dim) grad_add(J.dW + (size_t)orow * J.ld + col, acc[b][rr]);
-      }
-    }
-  }
-  if (grp == 0 && J.db != nullptr) {
-    bsum += __shfl_xor(bsum, 32, 64);
-    const int orow = bo * 32 + li - J.out_row0;
-    if (h == 0 && orow >= 0 && orow < J.out_dim) grad_add(J.db + orow, bsum);
-  }
-}
 
 static void dw_add(DwJobs& D, const float* A, int A_stride, int A_row0, int nbo, int out_dim,
                    int out_row0, const float* B, int B_stride, int in_dim, int ld, float* dW,
@@ -2133,28 +2016,9 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
   }
 }
 
-static int dw_launch_old(DwJobs& D, hipStream_t stream, const char* name) {
-  int items = 0;
-  for (int i = 0; i < D.n; ++i) {
-    const int n = D.j[i].nbo * ((D.j[i].nblk + 3) / 4);
-    if (n >= 4 || (items & 3) + n > 4) items = (items + 3) & ~3;
-    D.item0[i] = items;
-    D.nitems[i] = n;
-    items += n;
-  }
-  D.total_items = items;
-  const int gy = (items + 3) / 4;
-  int gx = (256 * 8 + gy - 1) / gy;
-  gx = gx < 1 ? 1 : gx;
-  RDRF_LAUNCH(name, k_dw, dim3(gx, gy), dim3(256), stream, D);
-  return 0;
-}
-
 // one plan per group of jobs that walk the same rows (same dz array, same activation array, same tile
 // space); a group whose products or blocks exceed one plan is cut into several launches
 static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
-  static const bool use_old = getenv("RDRF_DW_OLD") != nullptr;   // A/B switch for measurements
-  if (use_old) return dw_launch_old(D, stream, name);
   bool done[RDRF_MAX_DW_JOBS] = {false};
   for (int g0 = 0; g0 < D.n; ++g0) {
     if (done[g0]) continue;
@@ -2205,7 +2069,7 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
           }
         }
       }
-      if (getenv("RDRF_DW_DEBUG")) {
+      if (RDRF_ENV("RDRF_DW_DEBUG")) {
         fprintf(stderr, "dw plan %s: nblk %d products %d segs", name, P.nblk, tot);
         for (int g = 0; g < P.nseg; ++g) {
           const int end = g + 1 < P.nseg ? P.seg_blk0[g + 1] : P.nblk;
@@ -2418,7 +2282,7 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;   // one big workgroup per CU vs. two or three
   const int wpb = threads / 64;
   long g = (ntiles + wpb - 1) / wpb;
-  static const long cap_env = getenv("RDRF_SC_CAP") ? atol(getenv("RDRF_SC_CAP")) : 0;   // experiments
+  static const long cap_env = RDRF_ENV("RDRF_SC_CAP") ? atol(RDRF_ENV("RDRF_SC_CAP")) : 0;   // experiments (tools build)
   const long cap = threads == 512 ? 256 : (cap_env > 0 ? cap_env : 768);
   g = g < 1 ? 1 : (g > cap ? cap : g);
   rdrf_prof_begin(name, stream);
@@ -2428,22 +2292,25 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   return 0;
 }
 
-// RDRF_SCATTER = auto (default) | ray | sorted: how the density / blending gradients of the dynamic field's ray path reach the
-// factor planes -- the ray-tile kernel (k_scatter), or samples grouped by plane cell first (k_scatter_sorted: ~10x fewer
-// memory-side atomic requests).  Measured on MI355X at the Balloon1 stage-0 shape: sorted = 14 us keys +
-// 150 us radix sort + 340 / 140 / 140 us for the three planes = 816 us per launch against 695 us for the ray-tile kernel;
-// with its global atomics compiled out the sorted passes take 370 us, with the LDS line atomics out as well 174 us -- the
-// slow part is ds_add_f32 (~150 cycles per wave instruction), which grouping by plane cell scatters over random line
-// entries.  Kept as an option: it is the only path whose request count does not depend on the warp field's smoothness.
-static int scatter_mode(size_t ns) {
-  static int m = -1;   // -1 unset, 0 ray, 1 sorted, 2 auto
-  if (m < 0) {
-    const char* e = getenv("RDRF_SCATTER");
-    m = !e ? 2 : (!strcmp(e, "sorted") ? 1 : (!strcmp(e, "ray") ? 0 : 2));
-  }
-  // auto: the sort is a fixed ~170 us per launch, the saving grows with the batch: measured break-even between the
-  // Balloon1 stage-0 shape (4096 x 115 samples: sorted 816 us vs ray 695 us) and the final shape (4096 x 270: 1562 vs 1802)
-  return m == 2 ? (ns >= (size_t)800000 ? 1 : 0) : m;
+// rdrf_set_scatter_mode(RDRF_SCATTER_AUTO (default) | _RAY | _SORTED): how the density / blending gradients of the dynamic
+// field's ray path reach the factor planes -- the ray-tile kernel (k_scatter), or samples grouped by plane cell first
+// (k_scatter_sorted: ~10x fewer memory-side atomic requests).  Measured on MI355X at the Balloon1 stage-0 shape (DESIGN.md
+// 9): the grouping is a fixed cost per launch, the saving grows with the batch.  Kept selectable: sorted is the only path
+// whose request count does not depend on the warp field's smoothness, and the parity tests run both at every size.
+static int g_scatter_mode = RDRF_SCATTER_AUTO;
+extern "C" int rdrf_set_scatter_mode(int mode) {
+  RDRF_CHECK(mode == RDRF_SCATTER_AUTO || mode == RDRF_SCATTER_RAY || mode == RDRF_SCATTER_SORTED, -1,
+             "rdrf_set_scatter_mode: mode must be RDRF_SCATTER_AUTO, _RAY or _SORTED");
+  g_scatter_mode = mode;
+  return 0;
+}
+static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
+  int m = g_scatter_mode;
+  if (const char* e = RDRF_ENV("RDRF_SCATTER")) m = !strcmp(e, "sorted") ? RDRF_SCATTER_SORTED : (!strcmp(e, "ray") ? RDRF_SCATTER_RAY : m);
+  // auto: measured break-even between the Balloon1 stage-0 shape (4096 x 115 samples: sorted 816 us vs ray 695 us) and the
+  // final shape (4096 x 270: 1562 vs 1802)
+  if (m == RDRF_SCATTER_AUTO) return ns >= (size_t)800000 ? 1 : 0;
+  return m == RDRF_SCATTER_SORTED ? 1 : 0;
 }
 
 template <int PLANE>
@@ -2658,7 +2525,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   fill_bwd_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.g_rgb = g_rgb; a.g_sigma = g_sigma; a.g_weight = g_weight; a.g_blending = g_blending;
   a.g_xyz_prime = g_xyz_prime; a.g_xyz = g_xyz; a.g_rays = g_rays; a.g_dists = g_dists; a.g_z = g_z;
-  static const bool small_dw = !(getenv("RDRF_DW_SMALL") && atoi(getenv("RDRF_DW_SMALL")) == 0);   // 0: as k_dw2 products
+  static const bool small_dw = !(RDRF_ENV("RDRF_DW_SMALL") && atoi(RDRF_ENV("RDRF_DW_SMALL")) == 0);   // 0: as k_dw2 products (tools build)
   a.small_dw = small_dw ? 1 : 0;
   RDRF_CHECK(carve_saved(a.sp, saved, saved_bytes, 1, N, S), -3, "dynamic_bwd: saved buffer too small");
   BwdWs b;

@@ -18,6 +18,23 @@
 
 #include "rodynrf.h"
 
+// compile-time ablation blocks (tools/abl_*.sh, tools/prof_names.py) exist in the tools build only
+#ifndef RDRF_TOOLS
+#undef RDRF_ABL_NOATOM
+#undef RDRF_ABL_NOGLOBAL
+#undef RDRF_ABL_NOSCAN
+#undef RDRF_ABL_NOLDS
+#undef RDRF_ABL_NOGBWD
+#undef RDRF_ABL_SC_NLV
+#undef RDRF_ABL_SC_NOXY
+#undef RDRF_ABL_SC_NOZ
+#undef RDRF_ABL_DW_NOLOAD
+#undef RDRF_ABL_DW_NOMFMA
+#undef RDRF_ABL_NOGATHER
+#undef RDRF_ABL_OCML_SINCOS
+#undef RDRF_ABL_NOSAVE
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

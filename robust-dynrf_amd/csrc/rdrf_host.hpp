@@ -9,6 +9,16 @@
 
 void rdrf_set_error(const char* fmt, ...);
 
+// A/B switches of tools/ab_*.sh and tools/abl_*.sh.  The product library never reads the caller's environment: a C-ABI
+// call's behaviour depends on its arguments (and on explicit rdrf_set_* calls) only.  `make tools` builds
+// librodynrf_tools.so with -DRDRF_TOOLS, where these lookups and the RDRF_ABL_* ablation blocks are live.
+#ifdef RDRF_TOOLS
+#include <stdlib.h>
+#define RDRF_ENV(name) getenv(name)
+#else
+#define RDRF_ENV(name) ((const char*)nullptr)
+#endif
+
 #define RDRF_CHECK(cond, code, ...)  \
   do {                               \
     if (!(cond)) {                   \

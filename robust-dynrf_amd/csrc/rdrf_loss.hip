@@ -326,11 +326,15 @@ extern "C" int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, con
   size_t np2 = 1;
   while (np2 < (size_t)N) np2 <<= 1;
   const size_t lds = np2 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RDRF_HIP(hipFuncSetAttribute((const void*)k_frame_depth_loss, hipFuncAttributeMaxDynamicSharedMemorySize, FDL_MAXN * 4));
-    attr_set = true;
+  if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit: raise it for this launch's need, on the current device
+    int dev = 0, lds_max = 0;
+    RDRF_HIP(hipGetDevice(&dev));
+    RDRF_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    RDRF_CHECK(lds <= (size_t)lds_max, -1, "frame_depth_loss: %d rays need %zu bytes of LDS, the device has %d", N, lds, lds_max);
+    RDRF_HIP(hipFuncSetAttribute((const void*)k_frame_depth_loss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  // rays whose frame id lies outside [0, T) are selected by no workgroup: their gradient is 0, not uninitialised memory
+  RDRF_HIP(hipMemsetAsync(g_raw, 0, (size_t)N * sizeof(float), stream));
   rdrf_prof_begin("frame_depth_loss", stream);
   hipLaunchKernelGGL(k_frame_depth_loss, dim3(T), dim3(FDL_THREADS), lds, stream, pred, gt, frame, mask, N, g_raw, part);
   hipLaunchKernelGGL(k_frame_depth_finish, dim3(mask ? (N + 255) / 256 : 1), dim3(256), 0, stream, (const float*)part, T, coef,

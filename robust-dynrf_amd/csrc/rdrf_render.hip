@@ -32,10 +32,14 @@ struct RenderFusedArgs {
 
 // grid-wide barrier of the cooperative launch (all workgroups are resident): a monotonically increasing arrival
 // counter; agent-scope fences publish this workgroup's writes (other XCDs have their own L2) and invalidate stale
-// lines before the next phase reads what other workgroups wrote.  A bounded spin: a lost workgroup cannot hang the GPU.
-RDRF_D void grid_barrier(unsigned* bar, unsigned nblk, unsigned& epoch) {
+// lines before the next phase reads what other workgroups wrote.  A bounded spin: a lost workgroup cannot hang the GPU;
+// a barrier that times out raises the error word bar[1], every workgroup then leaves at its next barrier and the
+// compositor phase is replaced by NaN outputs -- a stalled launch gives a loudly wrong image, never a plausible one.
+// Returns false when the launch has failed.
+RDRF_D bool grid_barrier(unsigned* bar, unsigned nblk, unsigned& epoch) {
   __syncthreads();
   epoch += 1;
+  __shared__ unsigned failed_s;
   if (threadIdx.x == 0) {
     __threadfence();
     atomicAdd(bar, 1u);
@@ -43,11 +47,16 @@ RDRF_D void grid_barrier(unsigned* bar, unsigned nblk, unsigned& epoch) {
     unsigned spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 26)) break;
+      if (++spins > (1u << 26) || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        atomicExch(bar + 1, 1u);
+        break;
+      }
     }
     __threadfence();
+    failed_s = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  return failed_s == 0u;
 }
 
 template <int HEAD>
@@ -72,18 +81,26 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_render_fused(RenderFusedArgs
     }
     if (gc.bid == 0 && gc.tid == 0) { *r.as.counter = 0; *r.ad.counter = 0; }
   }
-  grid_barrier(r.barrier, gc.nblk, epoch);
+  bool ok = grid_barrier(r.barrier, gc.nblk, epoch);
   // ---- phase 1: density of both fields (weights, compaction of the appearance masks)
   static_density_body<false, true>(r.as, r.ws, gc);
   dyn_density_body<false, false, true>(r.ad, r.wd, lds, gc);
-  grid_barrier(r.barrier, gc.nblk, epoch);
+  ok = grid_barrier(r.barrier, gc.nblk, epoch) && ok;
   // ---- phase 2: appearance of both fields over the compacted lists
   static_app_body<HEAD, false, false, true>(r.as, r.ws, lds, gc);
   __syncthreads();
   dyn_app_body<false, false, true>(r.ad, r.wd, lds, gc);
-  grid_barrier(r.barrier, gc.nblk, epoch);
+  ok = grid_barrier(r.barrier, gc.nblk, epoch) && ok;
   // ---- phase 3: raw2outputs per ray
-  composite_body(r.comp, gc);
+  if (ok) {
+    composite_body(r.comp, gc);
+  } else {   // a barrier timed out: the phases ran on partial data -- poison this workgroup's share of the image
+    const float nan = __int_as_float(0x7fc00000);
+    for (int i = gc.bid * gc.nthr + gc.tid; i < N; i += gc.nblk * gc.nthr) {
+      r.comp.out[0][i * 3 + 0] = nan; r.comp.out[0][i * 3 + 1] = nan; r.comp.out[0][i * 3 + 2] = nan;
+      r.comp.out[1][i] = nan;
+    }
+  }
 }
 
 extern "C" size_t rdrf_render_workspace_bytes(int N, int S) {
@@ -186,14 +203,10 @@ extern "C" int rdrf_render_fused_fwd(const RdrfStaticParams* PS, const RdrfField
   // one workgroup per CU at most (its LDS holds a whole weight image); fewer when the chunk has fewer units of work
   const long tiles = ((long)N * S + 31) / 32;
   const long units = tiles > N ? tiles : N;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    RDRF_HIP(hipGetDevice(&dev));
-    RDRF_HIP(hipGetDeviceProperties(&prop, dev));
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  int ncu = 0, dev = 0;   // of the CURRENT device (a process may drive several)
+  RDRF_HIP(hipGetDevice(&dev));
+  RDRF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (ncu <= 0) ncu = 256;
   long g = (units + RDRF_MAXW - 1) / RDRF_MAXW;
   g = g < 1 ? 1 : (g > ncu ? ncu : g);
   const size_t lds_bytes = (size_t)(pk::S3_SIZE > pk::K3_SIZE ? (pk::S3_SIZE > pk::K1_SIZE ? pk::S3_SIZE : pk::K1_SIZE)
@@ -242,7 +255,7 @@ extern "C" int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFi
 // seven kernels run back to back, their event times add up to 282 us -- against 378 us for the single cooperative launch
 // (static density at 2 waves per SIMD instead of 6, three serial LDS fills, barrier round trips).  What makes small chunks
 // slow is not the launch sequence but the wave-per-ray density phase: 512 rays = 512 busy waves of 2048.  The launch
-// sequence therefore stays the default at every size; RDRF_RENDER=fused selects the single launch.
+// sequence is what rdrf_render_fwd runs at every size; rdrf_render_fused_fwd is the explicit entry point of the single launch.
 extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s,
                                const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
                                const float* ts, int N, int S, float near, float far, float* rgb_map,
@@ -250,12 +263,6 @@ extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* c
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   int rc = render_check(PS, cfg_s, PD, cfg_d, rays, ts, N, S, rgb_map, depth_map, ws_bytes);
   if (rc) return rc;
-  static int mode = -1;   // RDRF_RENDER = sequence (default) | fused
-  if (mode < 0) {
-    const char* e = getenv("RDRF_RENDER");
-    mode = (e && !strcmp(e, "fused")) ? 1 : 0;
-  }
-  if (mode == 1) return rdrf_render_fused_fwd(PS, cfg_s, PD, cfg_d, rays, ts, N, S, near, far, rgb_map, depth_map, ws, ws_bytes, stream);
   return rdrf_render_sequence_fwd(PS, cfg_s, PD, cfg_d, rays, ts, N, S, near, far, rgb_map, depth_map, ws, ws_bytes, stream);
 }
 

@@ -165,7 +165,7 @@ def OctreeRender_trilinear_fast(rays, ts, timeembeddings, tensorf, xyz_sampled, 
 @torch.no_grad()
 def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc", mode="auto"):
     """No-grad render of a ray chunk through ONE C-ABI call: the loop body of renderer.py:740-812.
-    mode "auto" (rdrf_render_fwd: the per-phase launch sequence unless RDRF_RENDER=fused), "fused" (rdrf_render_fused_fwd:
+    mode "auto" (rdrf_render_fwd: the per-phase launch sequence), "fused" (rdrf_render_fused_fwd:
     one cooperative launch) or "sequence" (rdrf_render_sequence_fwd); all three give the same bits.
     Returns (rgb_map_full[N,3], depth_map_full[N])."""
     from .fields import _attach_packed, _cfg_struct, _dynamic_struct, _static_struct

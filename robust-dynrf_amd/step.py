@@ -636,6 +636,10 @@ class Trainer:
         """One iteration on this rank's shard of the batch: forward of every pass, two-phase backward (static
         group first; its gradient exchange starts while the dynamic group is still differentiating).
         Returns the loss tensor (device, no sync)."""
+        if shard is not None and self.dp_exact_stats and self.cfg["batch_size"] % shard[1] != 0:
+            # the exact-statistics exchange all-gathers the per-ray depths with all_gather_into_tensor: equal shards only
+            raise ValueError(f"dp_exact_stats needs batch_size ({self.cfg['batch_size']}) divisible by the world size "
+                             f"({shard[1]}); use --dp-per-shard-stats or a divisible batch")
         b = self.data.make_batch(self.it, self.cfg["batch_size"], shard)
         loss_d, loss_s = self.losses(b)
         c = self.cfg
