@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L.lib, sym), f"librodynrf.so does not export {sym}"
     assert set(L.SYMBOLS) == declared
-    assert L.lib.rdrf_abi_version() == L.ABI_VERSION == 3
+    assert L.lib.rdrf_abi_version() == L.ABI_VERSION == 4
 
 
 def test_state_dict_contract_and_layout():
@@ -165,3 +165,16 @@ def test_sincos_pe_formula():
     S, Cc = sincos_pe(a)
     worst = max(worst, np.abs(S - np.sin(a.astype(np.float64))).max(), np.abs(Cc - np.cos(a.astype(np.float64))).max())
     assert worst < 1.2e-7, worst
+
+
+def test_product_library_does_not_read_the_environment():
+    """a C-ABI call's behaviour must not depend on the caller's environment.  The product library (and its
+    deterministic twin) import no getenv; the A/B switches live in the tools build only (make -C robust-dynrf_amd/csrc
+    tools: -DRDRF_TOOLS)."""
+    import subprocess
+    for name in ("librodynrf.so", "librodynrf_det.so"):
+        so = os.path.join(ROOT, "robust-dynrf_amd", name)
+        if not os.path.exists(so):
+            pytest.skip(name + " not built")
+        syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+        assert "getenv" not in syms, f"{name} imports getenv"
