@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import CASES, FWD_ELEM, GOLDEN, assert_close
+from _util import CASES, GOLDEN, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -299,5 +299,6 @@ def test_reference_written_checkpoint_evaluates_like_the_reference():
         m = cls(**kwargs)
         m.load(ckpt)
         with torch.no_grad():
-            assert_close(m.compute_densityfeature(xn, t, None), probe[tag + ".density"], tag + ".density", elem=FWD_ELEM)
-            assert_close(m.compute_appfeature(xn, t, None), probe[tag + ".app"], tag + ".app", elem=FWD_ELEM)
+            # (max-norm, like test_golden_function_vectors: the features are cancelling sums of 72 / 216 products)
+            assert_close(m.compute_densityfeature(xn, t, None), probe[tag + ".density"], tag + ".density")
+            assert_close(m.compute_appfeature(xn, t, None), probe[tag + ".app"], tag + ".app")

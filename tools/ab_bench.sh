@@ -2,6 +2,8 @@
 # A/B of two builds / env settings on ONE box: tools/ab_bench.sh "<env A>" "<env B>" [bench args]
 # prints ms/step and the per-kernel table of each arm (interleaved, 2 rounds)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+# the RDRF_* experiment switches of the C library exist in the tools build only: make -C robust-dynrf_amd/csrc tools
+[ -f robust-dynrf_amd/librodynrf_tools.so ] && export RDRF_LIB=${RDRF_LIB:-$PWD/robust-dynrf_amd/librodynrf_tools.so}
 A="$1"; B="$2"; shift 2
 mkdir -p gpurun_out
 for r in 1 2; do

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B/C of env settings on ONE box: tools/ab_env3.sh "<env A>" "<env B>" "<env C>" [bench args]; 2 interleaved rounds
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+# the RDRF_* experiment switches of the C library exist in the tools build only: make -C robust-dynrf_amd/csrc tools
+[ -f robust-dynrf_amd/librodynrf_tools.so ] && export RDRF_LIB=${RDRF_LIB:-$PWD/robust-dynrf_amd/librodynrf_tools.so}
 A="$1"; B="$2"; Cc="$3"; shift 3
 mkdir -p gpurun_out
 for r in 1 2; do

@@ -1,0 +1,65 @@
+"""Per-kernel HIP-event times of the FORWARD field kernels on a fixed workload (reference-initialised weights, fixed rays:
+app-mask fractions ~0.49 static / ~0.74 dynamic, the state the driver's 20-step window starts from), in inference mode
+(no saved rows) and in training mode (rows saved), for A/B runs of kernel builds:
+
+    RDRF_LIB=$PWD/robust-dynrf_amd/abl_x.so python tools/fwd_ab.py [N=16384] [S=115] [grid=141,157,94]
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+S_ = importlib.import_module("robust-dynrf_amd.step")
+L = importlib.import_module("robust-dynrf_amd._lib")
+R = importlib.import_module("robust-dynrf_amd.renderer")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+cfg = S_.scene_config("nvidia", "stage0")
+if len(sys.argv) > 2:
+    cfg["n_samples"] = int(sys.argv[2])
+if len(sys.argv) > 3:
+    cfg["grid"] = [int(v) for v in sys.argv[3].split(",")]
+dev = torch.device("cuda", 0)
+st, dy = S_.build_fields(cfg, dev)
+data = S_.SyntheticScene(cfg, dev)
+ids = data.perm[:N]
+from importlib import import_module
+RU = import_module("robust-dynrf_amd.ray_utils")
+rays = RU.generate_rays(ids, data.poses, data.focal, cfg["H"], cfg["W"], ndc=True, near=1.0).detach()
+ts = data.ts_of(ids)
+S = cfg["n_samples"]
+jit = torch.rand(S, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+KS = ["static_density", "static_app", "time_branch", "dyn_density", "dyn_app", "composite"]
+
+
+def one(train):
+    with torch.set_grad_enabled(train):
+        xyz, z, valid = R.sampleXYZ(dy, rays, S, ray_type="ndc", is_train=True, jitter=jit)
+        o_s = st(rays, ts, None, xyz, z, valid, is_train=True, ray_type="ndc")
+        o_d = dy(rays, ts, None, xyz, z, valid, is_train=True, ray_type="ndc")
+    return o_s, o_d
+
+
+for train in (False, True):
+    for _ in range(2):
+        o_s, o_d = one(train)
+    torch.cuda.synchronize()
+    fs, fd = float((o_s[4] > 1e-4).float().mean()), float((o_d[4] > 1e-4).float().mean())
+    del o_s, o_d
+    L.lib.rdrf_prof_enable(1)
+    L.lib.rdrf_prof_reset()
+    K = 5
+    for _ in range(K):
+        o = one(train)
+        del o
+    torch.cuda.synchronize()
+    L.lib.rdrf_prof_enable(0)
+    row = []
+    for k in KS:
+        ms, n = C.c_double(), C.c_int()
+        L.lib.rdrf_prof_get(k.encode(), C.byref(ms), C.byref(n))
+        if n.value:
+            row.append(f"{k} {ms.value / n.value * 1e3:8.1f}")
+    print(f"{'train' if train else 'infer'} N={N} S={S} app s/d {fs:.3f}/{fd:.3f} | us per launch: " + " | ".join(row), flush=True)
