@@ -33,6 +33,7 @@
 #undef RDRF_ABL_NOGATHER
 #undef RDRF_ABL_OCML_SINCOS
 #undef RDRF_ABL_NOSAVE
+#undef RDRF_ABL_APP_NOPE
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -335,7 +336,7 @@ struct QuadTaps {  // everything the backward needs as well
 
 RDRF_D f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
-template <int C0Q, int C1Q>
+template <int C0Q, int C1Q, int ABL = 0>
 RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, float x2) {
   QuadSel<C0Q, C1Q> s = quad_sel<C0Q, C1Q>(g);
   const int pi = s.pi;
@@ -361,12 +362,21 @@ RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, fl
   const int x0c = min(max(tx.i0, 0), Ws - 1) << lv, x1c = min(max(tx.i0 + 1, 0), Ws - 1) << lv;
   const int y0c = min(max(ty.i0, 0), Hs - 1) << lv, y1c = min(max(ty.i0 + 1, 0), Hs - 1) << lv;
   const int l0c = min(max(tl.i0, 0), Ls - 1) << lv, l1c = min(max(tl.i0 + 1, 0), Ls - 1) << lv;
-  const f32x4 v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo);
-  const f32x4 v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
-  const f32x4 v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo);
-  const f32x4 v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
-  const f32x4 a0 = ld4(Lp + (size_t)l0c * C + qo);
-  const f32x4 a1 = ld4(Lp + (size_t)l1c * C + qo);
+  f32x4 v00, v01, v10, v11, a0, a1;
+  if constexpr (ABL == 1) {   // the addresses are still formed, nothing is fetched
+    const float f0 = (float)(y0c * sH + x0c * sW + qo) * 1e-9f, f1 = (float)(y0c * sH + x1c * sW + qo) * 1e-9f;
+    const float f2 = (float)(y1c * sH + x0c * sW + qo) * 1e-9f, f3 = (float)(y1c * sH + x1c * sW + qo) * 1e-9f;
+    const float f4 = (float)(l0c * C + qo) * 1e-9f, f5 = (float)(l1c * C + qo) * 1e-9f;
+    v00 = f32x4{f0, f1, f2, f3}; v01 = f32x4{f1, f2, f3, f0}; v10 = f32x4{f2, f3, f0, f1}; v11 = f32x4{f3, f0, f1, f2};
+    a0 = f32x4{f4, f5, f4, f5}; a1 = f32x4{f5, f4, f5, f4};
+  } else {
+    v00 = ld4(P + (size_t)(y0c * sH + x0c * sW) + qo);
+    v01 = ld4(P + (size_t)(y0c * sH + x1c * sW) + qo);
+    v10 = ld4(P + (size_t)(y1c * sH + x0c * sW) + qo);
+    v11 = ld4(P + (size_t)(y1c * sH + x1c * sW) + qo);
+    a0 = ld4(Lp + (size_t)l0c * C + qo);
+    a1 = ld4(Lp + (size_t)l1c * C + qo);
+  }
   const float wx0 = tx.ok0 ? tx.w0 : 0.f, wx1 = tx.ok1 ? tx.w1 : 0.f;
   const float wy0 = ty.ok0 ? ty.w0 : 0.f, wy1 = ty.ok1 ? ty.w1 : 0.f;
   const float wl0 = tl.ok0 ? tl.w0 : 0.f, wl1 = tl.ok1 ? tl.w1 : 0.f;
@@ -375,13 +385,165 @@ RDRF_D QuadTaps gather_quad_taps(const RdrfVM& vm, int g, float x0, float x1, fl
   return r;
 }
 
-template <int C0Q, int C1Q>
+template <int C0Q, int C1Q, int ABL = 0>
 RDRF_D f32x4 gather_quad(const RdrfVM& vm, int g, float x0, float x1, float x2) {
 #ifdef RDRF_ABL_NOGATHER
   return f32x4{x0, x1, x2, (float)g};
 #endif
-  QuadTaps t = gather_quad_taps<C0Q, C1Q>(vm, g, x0, x1, x2);
+  if constexpr (ABL == 2) return f32x4{x0 * 0.01f, x1 * 0.01f, x2 * 0.01f, (float)g * 1e-3f};
+  QuadTaps t = gather_quad_taps<C0Q, C1Q, ABL>(vm, g, x0, x1, x2);
   return t.pv * t.lv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VM gather with SHARED taps (forward kernels).  The three planes of a factor set are spanned by the same three grid
+// axes (plane XY <-> line Z, XZ <-> Y, YZ <-> X; the host checks vm_one_grid), so at one stride level there are only
+// three distinct 1-D taps -- one per axis -- whatever the number of planes, quads and factor sets read at that point.
+// gather_quad above recomputes all three for EVERY quad (81 tap1d + 162 address computations per lane and tile in
+// k_dyn_app: measured by ablation, the tap arithmetic was 17 % of that kernel's time -- more than the waits on its
+// loads); here a lane forms the axis taps once per level, the four texel pointers / two line pointers / bilinear weights
+// once per (level, plane), and every quad of that plane is six 16-byte loads at immediate offsets + the interpolation.
+// Same arithmetic per element (tap1d, clamped addresses, validity folded into the weights,
+// (v00 w00 + v01 w01 + v10 w10 + v11 w11) * (a0 wl0 + a1 wl1)) as gather_quad_taps.
+// ---------------------------------------------------------------------------------------------
+struct AxisTap {
+  int i0, i1;     // clamped tap indices in level-0 texels (already << level)
+  float w0, w1;   // interpolation weights, 0 where the tap is out of range (zero padding)
+};
+RDRF_D AxisTap axis_tap(float c, int L, int lv) {
+  const int st = 1 << lv, Ls = (L + st - 1) >> lv;
+  const Tap1 t = tap1d(c, Ls);
+  AxisTap a;
+  a.i0 = min(max(t.i0, 0), Ls - 1) << lv;
+  a.i1 = min(max(t.i0 + 1, 0), Ls - 1) << lv;
+  a.w0 = t.ok0 ? t.w0 : 0.f;
+  a.w1 = t.ok1 ? t.w1 : 0.f;
+  return a;
+}
+struct PlaneTaps {
+  const float *p00, *p01, *p10, *p11, *l0, *l1;
+  float w00, w01, w10, w11, wl0, wl1;
+};
+// plane `pi` of `vm` at the taps (ax, ay) of its two axes, its line at `al`; `qoff` floats are added to every pointer
+// (the lane's first quad)
+RDRF_D PlaneTaps plane_taps(const RdrfVM& vm, int pi, const AxisTap& ax, const AxisTap& ay, const AxisTap& al, int qoff) {
+  const float* P = pi == 0 ? vm.plane[0] : (pi == 1 ? vm.plane[1] : vm.plane[2]);
+  const float* Lp = pi == 0 ? vm.line[0] : (pi == 1 ? vm.line[1] : vm.line[2]);
+  const int sH = pi == 0 ? vm.sH[0] : (pi == 1 ? vm.sH[1] : vm.sH[2]);
+  const int sW = pi == 0 ? vm.sW[0] : (pi == 1 ? vm.sW[1] : vm.sW[2]);
+  const int C = pi == 0 ? vm.C[0] : (pi == 1 ? vm.C[1] : vm.C[2]);
+  PlaneTaps t;
+  t.p00 = P + (size_t)(ay.i0 * sH + ax.i0 * sW) + qoff;
+  t.p01 = P + (size_t)(ay.i0 * sH + ax.i1 * sW) + qoff;
+  t.p10 = P + (size_t)(ay.i1 * sH + ax.i0 * sW) + qoff;
+  t.p11 = P + (size_t)(ay.i1 * sH + ax.i1 * sW) + qoff;
+  t.l0 = Lp + (size_t)al.i0 * C + qoff;
+  t.l1 = Lp + (size_t)al.i1 * C + qoff;
+  t.w00 = ax.w0 * ay.w0; t.w01 = ax.w1 * ay.w0; t.w10 = ax.w0 * ay.w1; t.w11 = ax.w1 * ay.w1;
+  t.wl0 = al.w0; t.wl1 = al.w1;
+  return t;
+}
+// the three axis taps of the normalised point (x0, x1, x2) at stride level lv (axis sizes: the XY plane and its line)
+struct PointTaps { AxisTap x, y, z; };
+RDRF_D PointTaps point_taps(const RdrfVM& vm, float x0, float x1, float x2, int lv) {
+  PointTaps p;
+  p.x = axis_tap(x0, vm.W[0], lv);
+  p.y = axis_tap(x1, vm.H[0], lv);
+  p.z = axis_tap(x2, vm.L[0], lv);
+  return p;
+}
+RDRF_D AxisTap select_axis(bool first, const AxisTap& a, const AxisTap& b) {
+  AxisTap t;
+  t.i0 = first ? a.i0 : b.i0; t.i1 = first ? a.i1 : b.i1; t.w0 = first ? a.w0 : b.w0; t.w1 = first ? a.w1 : b.w1;
+  // opaque scalars: left alone, the SLP vectoriser packs the selected weights into vectors and then shuffles them
+  // through SCRATCH memory (32 bytes of stack + a vmcnt wait in the middle of every gather sequence)
+  asm volatile("" : "+v"(t.w0), "+v"(t.w1), "+v"(t.i0), "+v"(t.i1));
+  return t;
+}
+// the XZ plane for half 0, the YZ plane for half 1 (lane-dependent plane: the INPUTS of plane_taps are selected -- a
+// select between two finished PlaneTaps structs was lowered through scratch memory)
+RDRF_D PlaneTaps plane_taps_xz_or_yz(const RdrfVM& vm, const PointTaps& pt, int h, int qoff) {
+  const bool yz = h != 0;
+  return plane_taps(vm, yz ? 2 : 1, select_axis(yz, pt.y, pt.x), pt.z, select_axis(yz, pt.x, pt.y), qoff);
+}
+RDRF_D void shift_taps(PlaneTaps& t, int off) {
+  t.p00 += off; t.p01 += off; t.p10 += off; t.p11 += off; t.l0 += off; t.l1 += off;
+}
+// one quad of plane_tap * line_tap at float offset `off` (a compile-time constant at the call sites: an immediate)
+RDRF_D f32x4 taps_combine(const PlaneTaps& t, f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11, f32x4 a0, f32x4 a1) {
+  const f32x4 pv = v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
+  const f32x4 lv = a0 * t.wl0 + a1 * t.wl1;
+  return pv * lv;
+}
+RDRF_D f32x4 taps_quad(const PlaneTaps& t, int off) {
+  return taps_combine(t, ld4(t.p00 + off), ld4(t.p01 + off), ld4(t.p10 + off), ld4(t.p11 + off), ld4(t.l0 + off), ld4(t.l1 + off));
+}
+// NQ quads of one plane, `stride` floats apart: ALL 6 NQ loads are issued before the first one is used.  Left to itself hipcc
+// schedules the gathers for register pressure -- four to six loads, s_waitcnt vmcnt(0), interpolate, the next quad: ~30
+// dependent memory round trips per 32-sample tile of k_dyn_app, ~20 us of the ~40 us a wave spends outside its MFMA
+// chains per tile, which two waves per SIMD cannot cover (matrix pipe 60 % busy).  One batch = one round trip.
+template <int NQ>
+RDRF_D void taps_quads(const PlaneTaps& t, int stride, f32x4 (&out)[NQ]) {
+  f32x4 v00[NQ], v01[NQ], v10[NQ], v11[NQ], a0[NQ], a1[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    v00[q] = ld4(t.p00 + q * stride); v01[q] = ld4(t.p01 + q * stride);
+    v10[q] = ld4(t.p10 + q * stride); v11[q] = ld4(t.p11 + q * stride);
+    a0[q] = ld4(t.l0 + q * stride); a1[q] = ld4(t.l1 + q * stride);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) out[q] = taps_combine(t, v00[q], v01[q], v10[q], v11[q], a0[q], a1[q]);
+}
+// one quad of each of three (plane, offset) pairs in one batch
+RDRF_D void taps_quads3(const PlaneTaps& ta, const PlaneTaps& tb, const PlaneTaps& tc, f32x4 (&out)[3]) {
+  const f32x4 a00 = ld4(ta.p00), a01 = ld4(ta.p01), a10 = ld4(ta.p10), a11 = ld4(ta.p11), al0 = ld4(ta.l0), al1 = ld4(ta.l1);
+  const f32x4 b00 = ld4(tb.p00), b01 = ld4(tb.p01), b10 = ld4(tb.p10), b11 = ld4(tb.p11), bl0 = ld4(tb.l0), bl1 = ld4(tb.l1);
+  const f32x4 c00 = ld4(tc.p00), c01 = ld4(tc.p01), c10 = ld4(tc.p10), c11 = ld4(tc.p11), cl0 = ld4(tc.l0), cl1 = ld4(tc.l1);
+  __builtin_amdgcn_sched_barrier(0);
+  out[0] = taps_combine(ta, a00, a01, a10, a11, al0, al1);
+  out[1] = taps_combine(tb, b00, b01, b10, b11, bl0, bl1);
+  out[2] = taps_combine(tc, c00, c01, c10, c11, cl0, cl1);
+}
+// half h's nine quads of one stride level of a {48,12,12}-component set, canonical order: out[4 j + c], j = 0..8 = quad
+// w = 2 j + h of the level (w < 12: XY quad w, 12..14: XZ quad w - 12, 15..17: YZ quad w - 15)
+template <int OFF, int NOUT>
+RDRF_D void gather_level_app(const RdrfVM& vm, const PointTaps& pt, int h, float (&out_)[NOUT]) {
+  {
+    const PlaneTaps xy = plane_taps(vm, 0, pt.x, pt.y, pt.z, 4 * h);
+    f32x4 v[6];
+    taps_quads<6>(xy, 8, v);   // 36 loads in flight
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      out_[OFF + 4 * j + 0] = v[j].x; out_[OFF + 4 * j + 1] = v[j].y; out_[OFF + 4 * j + 2] = v[j].z; out_[OFF + 4 * j + 3] = v[j].w;
+    }
+  }
+  // j = 6: XZ quad h;  j = 7: h ? YZ quad 0 : XZ quad 2;  j = 8: YZ quad 1 + h   (lane-dependent quads: pointer shifts)
+  PlaneTaps t6 = plane_taps(vm, 1, pt.x, pt.z, pt.y, 0), t8 = plane_taps(vm, 2, pt.y, pt.z, pt.x, 0);
+  const PlaneTaps t7 = plane_taps_xz_or_yz(vm, pt, h, h ? 0 : 8);
+  shift_taps(t6, 4 * h);
+  shift_taps(t8, 4 + 4 * h);
+  f32x4 w[3];
+  taps_quads3(t6, t7, t8, w);   // 18 loads in flight
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    out_[OFF + 24 + 4 * j + 0] = w[j].x; out_[OFF + 24 + 4 * j + 1] = w[j].y; out_[OFF + 24 + 4 * j + 2] = w[j].z; out_[OFF + 24 + 4 * j + 3] = w[j].w;
+  }
+}
+// half h's three quads of one stride level of a {16,4,4}-component set: out[4 j + c], j = 0..2 = quad w = 2 j + h
+// (w < 4: XY quad w, 4: XZ, 5: YZ)
+template <int OFF, int NOUT>
+RDRF_D void gather_level_den(const RdrfVM& vm, const PointTaps& pt, int h, float (&out)[NOUT]) {
+  const PlaneTaps xy = plane_taps(vm, 0, pt.x, pt.y, pt.z, 4 * h);
+  PlaneTaps xy2 = xy;
+  shift_taps(xy2, 8);
+  const PlaneTaps t2 = plane_taps_xz_or_yz(vm, pt, h, 0);
+  f32x4 v[3];
+  taps_quads3(xy, xy2, t2, v);   // 18 loads in flight
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    out[OFF + 4 * j + 0] = v[j].x; out[OFF + 4 * j + 1] = v[j].y; out[OFF + 4 * j + 2] = v[j].z; out[OFF + 4 * j + 3] = v[j].w;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -258,7 +258,7 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "static_fwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "static_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
-             "static_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+             "static_fwd: only density comps {16,4,4} / app comps {48,12,12}, the planes and lines of a set spanning one grid, are built");
   FieldArgs a;
   fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
@@ -304,8 +304,8 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && N > 0 && S > 0, -1, "dynamic_fwd: bad arguments");
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "dynamic_fwd: N * S * 3 must stay below 2^31 (32-bit sample indices): render / train in smaller chunks");
-  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
-             "dynamic_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12) && vm_same_grid(P->density, P->blending), -1,
+             "dynamic_fwd: only density comps {16,4,4} / app comps {48,12,12}, the planes and lines of a set spanning one grid, are built");
   FieldArgs a;
   fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
@@ -373,7 +373,7 @@ extern "C" int rdrf_static_features_fwd(const RdrfStaticParams* P, const RdrfFie
   if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && xn && M > 0 && (density || app), -1, "static_features_fwd: bad arguments");
   RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->app, 48, 12), -1,
-             "static_features_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+             "static_features_fwd: only density comps {16,4,4} / app comps {48,12,12}, the planes and lines of a set spanning one grid, are built");
   const int Np = (M + 31) / 32;
   FieldArgs a;
   fill_common(a, cfg, nullptr, nullptr, xn, nullptr, nullptr, Np, 32);
@@ -408,8 +408,8 @@ extern "C" int rdrf_dynamic_features_fwd(const RdrfDynamicParams* P, const RdrfF
   if (M == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(P && cfg && x && t && M > 0 && (density || blending || app || xyz_prime), -1,
              "dynamic_features_fwd: bad arguments");
-  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12), -1,
-             "dynamic_features_fwd: only density comps {16,4,4} / app comps {48,12,12} are built");
+  RDRF_CHECK(vm_ok(P->density, 16, 4) && vm_ok(P->blending, 16, 4) && vm_ok(P->app, 48, 12) && vm_same_grid(P->density, P->blending), -1,
+             "dynamic_features_fwd: only density comps {16,4,4} / app comps {48,12,12}, the planes and lines of a set spanning one grid, are built");
   const int Np = (M + 31) / 32;
   FieldArgs a;
   fill_common(a, cfg, nullptr, t, x, nullptr, nullptr, Np, 32);

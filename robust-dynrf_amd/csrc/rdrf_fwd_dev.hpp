@@ -40,15 +40,20 @@ RDRF_D void static_density_body(const FieldArgs a, const StaticW w, const GridCt
         x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
         x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
       }
-#pragma unroll
-      for (int pi = 0; pi < 3; ++pi) {  // quads 0..3 plane 0, 4 plane 1, 5 plane 2
+      {  // quads 0..3 plane XY, 4 plane XZ, 5 plane YZ; one set of axis taps for all six (shared-tap gather)
+        const PointTaps pt = point_taps(w.density, x0, x1, x2, 0);
+        const PlaneTaps xy = plane_taps(w.density, 0, pt.x, pt.y, pt.z, 0);
         float sp = 0.f;
 #pragma unroll
-        for (int g = (pi == 0 ? 0 : 3 + pi); g < (pi == 0 ? 4 : 4 + pi); ++g) {
-          f32x4 v = gather_quad<4, 1>(w.density, g, x0, x1, x2);
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = taps_quad(xy, 4 * q);
           sp += v.x + v.y + v.z + v.w;
         }
         f += sp;
+        const f32x4 v1 = taps_quad(plane_taps(w.density, 1, pt.x, pt.z, pt.y, 0), 0);
+        f += v1.x + v1.y + v1.z + v1.w;
+        const f32x4 v2 = taps_quad(plane_taps(w.density, 2, pt.y, pt.z, pt.x, 0), 0);
+        f += v2.x + v2.y + v2.z + v2.w;
       }
     }
     if (a.raw != nullptr && act) a.raw[idx] = f;
@@ -116,11 +121,10 @@ RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused
       x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
     }
     float G[36];
+    gather_level_app<0>(w.app, point_taps(w.app, x0, x1, x2, 0), h, G);
+    if (!act) {
 #pragma unroll
-    for (int o = 0; o < 9; ++o) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, x0, x1, x2);
-      G[o * 4 + 0] = v.x; G[o * 4 + 1] = v.y; G[o * 4 + 2] = v.z; G[o * 4 + 3] = v.w;
+      for (int i = 0; i < 36; ++i) G[i] = 0.f;
     }
     f32x16 accF[1];
     acc_bias<1>(accF, nullptr, h);
@@ -280,11 +284,12 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
     float fd, fb;
     {
       float Fv[36];
+      gather_level_den<0>(w.density, point_taps(w.density, xw0, xw1, xw2, 0), h, Fv);
+      gather_level_den<12>(w.density, point_taps(w.density, xw0, xw1, xw2, 1), h, Fv);
+      gather_level_den<24>(w.density, point_taps(w.density, xw0, xw1, xw2, 2), h, Fv);
+      if (!vld) {
 #pragma unroll
-      for (int o = 0; o < 9; ++o) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vld) v = gather_quad<4, 1>(w.density, 2 * o + h, xw0, xw1, xw2);
-        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+        for (int i = 0; i < 36; ++i) Fv[i] = 0.f;
       }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BD1, h);
@@ -299,11 +304,12 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
     }
     {
       float Fv[36];
+      gather_level_den<0>(w.blending, point_taps(w.blending, xw0, xw1, xw2, 0), h, Fv);
+      gather_level_den<12>(w.blending, point_taps(w.blending, xw0, xw1, xw2, 1), h, Fv);
+      gather_level_den<24>(w.blending, point_taps(w.blending, xw0, xw1, xw2, 2), h, Fv);
+      if (!vld) {
 #pragma unroll
-      for (int o = 0; o < 9; ++o) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vld) v = gather_quad<4, 1>(w.blending, 2 * o + h, xw0, xw1, xw2);
-        Fv[o * 4 + 0] = v.x; Fv[o * 4 + 1] = v.y; Fv[o * 4 + 2] = v.z; Fv[o * 4 + 3] = v.w;
+        for (int i = 0; i < 36; ++i) Fv[i] = 0.f;
       }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BB1, h);
@@ -385,22 +391,44 @@ RDRF_D void dyn_app_body(const FieldArgs a, const DynW w, float* lds_fused, cons
       xn1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
       xn2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
     }
-    const float xw0 = a.xw[(size_t)idx * 3 + 0], xw1 = a.xw[(size_t)idx * 3 + 1],
-                xw2 = a.xw[(size_t)idx * 3 + 2];
+    const float xw0 = a.xw[(size_t)idx * 3 + 0], xw1 = a.xw[(size_t)idx * 3 + 1], xw2 = a.xw[(size_t)idx * 3 + 2];
     float F[16];
     {
-      float A[108];
-#pragma unroll
-      for (int o = 0; o < 27; ++o) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (act) v = gather_quad<12, 3>(w.app, 2 * o + h, xw0, xw1, xw2);
-        A[o * 4 + 0] = v.x; A[o * 4 + 1] = v.y; A[o * 4 + 2] = v.z; A[o * 4 + 3] = v.w;
-      }
+      // level by level: gather a level's 36 features (two load batches), feed them to the basis product, store their
+      // rows -- the 108 gathered values never coexist, which leaves the registers for 36 loads in flight
       f32x16 accF[1];
       acc_bias<1>(accF, nullptr, h);
-      mfma_seg<1, 108>(accF, A, pkw + pk::K3_BASIS, lane);
+      {
+        float A[36];
+        gather_level_app<0>(w.app, point_taps(w.app, xw0, xw1, xw2, 0), h, A);
+        if (!act) {
+#pragma unroll
+          for (int i = 0; i < 36; ++i) A[i] = 0.f;
+        }
+        mfma_seg<1, 36>(accF, A, pkw + pk::K3_BASIS, lane);
+        save_rows<36>(svb, sv::K3_A, A, s, h);
+      }
+      {
+        float A[36];
+        gather_level_app<0>(w.app, point_taps(w.app, xw0, xw1, xw2, 1), h, A);
+        if (!act) {
+#pragma unroll
+          for (int i = 0; i < 36; ++i) A[i] = 0.f;
+        }
+        mfma_seg<1, 36>(accF, A, pkw + pk::K3_BASIS + 9 * 256, lane);
+        save_rows<36>(svb, sv::K3_A + 72, A, s, h);
+      }
+      {
+        float A[36];
+        gather_level_app<0>(w.app, point_taps(w.app, xw0, xw1, xw2, 2), h, A);
+        if (!act) {
+#pragma unroll
+          for (int i = 0; i < 36; ++i) A[i] = 0.f;
+        }
+        mfma_seg<1, 36>(accF, A, pkw + pk::K3_BASIS + 18 * 256, lane);
+        save_rows<36>(svb, sv::K3_A + 144, A, s, h);
+      }
       acc_copy<1>(F, accF);
-      save_rows<108>(svb, sv::K3_A, A, s, h);
     }
     if constexpr (FEAT) {  // compute_appfeature: basis_mat output (models/tensoRF.py:734-811)
       if (act) {
@@ -411,8 +439,15 @@ RDRF_D void dyn_app_body(const FieldArgs a, const DynW w, float* lds_fused, cons
       continue;
     }
     float X0[32], X1[8];
+#ifdef RDRF_ABL_APP_NOPE
+#pragma unroll
+    for (int i = 0; i < 32; ++i) X0[i] = xn0 * (float)(i + 1) + t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) X1[i] = t * (float)(i + 1);
+#else
     fill_x0(X0, xn0, xn1, xn2, t, h);
     fill_x1(X1, t, h);
+#endif
     if (svb != nullptr && h == 0) {
       svb[(size_t)(sv::K3_VD + 0) * 32 + s] = vx; svb[(size_t)(sv::K3_VD + 1) * 32 + s] = vy;
       svb[(size_t)(sv::K3_VD + 2) * 32 + s] = vz;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rdrf_common.hpp"
@@ -73,8 +74,16 @@ struct WsCarver {
   bool ok() const { return off <= cap; }
 };
 
+// component counts + the three planes / lines span ONE grid (plane XY <-> line Z, XZ <-> Y, YZ <-> X): the forward
+// kernels compute one tap per grid axis and share it between the planes (rdrf_common.hpp, shared-tap gather)
+static inline bool vm_one_grid(const RdrfVM& v) {
+  return v.W[0] == v.W[1] && v.W[0] == v.L[2] && v.H[0] == v.W[2] && v.H[0] == v.L[1] && v.H[1] == v.H[2] && v.H[1] == v.L[0];
+}
+static inline bool vm_same_grid(const RdrfVM& a, const RdrfVM& b) {
+  return a.W[0] == b.W[0] && a.H[0] == b.H[0] && a.L[0] == b.L[0];
+}
 static inline bool vm_ok(const RdrfVM& v, int c0, int c1) {
-  return v.C[0] == c0 && v.C[1] == c1 && v.C[2] == c1;
+  return v.C[0] == c0 && v.C[1] == c1 && v.C[2] == c1 && vm_one_grid(v);
 }
 
 // device-wide stable key sort (rdrf_sort.hip)

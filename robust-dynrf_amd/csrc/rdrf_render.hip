@@ -151,7 +151,8 @@ static int render_check(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s, c
   RDRF_CHECK((size_t)N * S * 3 < (size_t)INT32_MAX, -1, "render: N * S * 3 must stay below 2^31: render in chunks");
   RDRF_CHECK(ws_bytes >= rdrf_render_workspace_bytes(N, S), -3, "render: workspace too small");
   RDRF_CHECK(vm_ok(PS->density, 16, 4) && vm_ok(PS->app, 48, 12) && vm_ok(PD->density, 16, 4) && vm_ok(PD->blending, 16, 4) &&
-             vm_ok(PD->app, 48, 12), -1, "render: only density comps {16,4,4} / app comps {48,12,12} are built");
+             vm_ok(PD->app, 48, 12) && vm_same_grid(PD->density, PD->blending), -1,
+             "render: only density comps {16,4,4} / app comps {48,12,12} of one grid are built");
   return 0;
 }
 

@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "robust-dynrf_amd", "csrc")
 
 
 def table(src):
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "--offload-arch=gfx950",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-lds=1", "--offload-arch=gfx950",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-result",
            "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
