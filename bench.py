@@ -199,7 +199,7 @@ KERNELS = ["pack", "generate_rays", "generate_rays_bwd", "sample_ndc", "sample_c
            "static_app", "time_branch", "dyn_density", "dyn_app", "composite", "scene_flow", "induce_flow",
            "induce_flow_bwd", "distloss", "distloss_bwd", "tv_fwd", "tv_bwd", "tv_grad", "dense_l1", "dense_l1_bwd", "composite_bwd",
            "dyn_app_bwd", "scatter_dyn_app", "dyn_heads_bwd", "scatter_dyn_density", "dyn_warp_bwd", "time_branch_bwd",
-           "dw_dyn", "static_app_bwd", "scatter_static_app", "static_density_bwd", "scatter_static_density",
+           "dw_dyn", "static_app_bwd", "scatter_static_app", "static_density_bwd", "scatter_static_density", "sort",
            "dw_static", "scene_flow_bwd", "dw_sf", "adam"]
 
 
@@ -388,7 +388,7 @@ RENDER_KERNELS = ["pack", "sample_ndc", "sample_contract", "static_density", "st
                   "composite", "render_fused"]
 
 
-def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5):
+def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5, streams=1):
     """BASELINE.json's second metric: Mpix/s of the no-grad chunk loop of renderer.py:740-812 (+ its roofline: SURVEY 8(d)
     F_fwd / B_fwd per sample x samples / time, with the two fields' measured app-mask fractions of THIS frame)."""
     import torch
@@ -399,9 +399,9 @@ def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5):
     ts_f = trainer.data.ts_of(ids + 3 * H * W)
 
     def frame():
-        for c0 in range(0, H * W, chunk):
-            R.render_rays(trainer.st, trainer.dy, rays_f[c0:c0 + chunk], ts_f[c0:c0 + chunk],
-                          N_samples=cfg["n_samples"], ray_type=cfg["ray_type"])
+        R.render_chunks(trainer.st, trainer.dy, rays_f, ts_f, chunk, N_samples=cfg["n_samples"], ray_type=cfg["ray_type"],
+                        streams=streams)
+    frame()
     frame()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -409,7 +409,7 @@ def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5):
         frame()
     torch.cuda.synchronize()
     dtf = (time.perf_counter() - t0) / frames
-    out = {"value": H * W / dtf / 1e6, "unit": "Mpix/s", "frame": [H, W], "chunk": chunk,
+    out = {"value": H * W / dtf / 1e6, "unit": "Mpix/s", "frame": [H, W], "chunk": chunk, "hip_streams": streams,
            "samples_per_ray": cfg["n_samples"], "ms_per_frame": dtf * 1e3}
     # ---- roofline of the frame: per-kernel HIP events of one more frame, the frame's own app-mask fractions
     with torch.no_grad():
@@ -565,7 +565,10 @@ def main():
         # whole frames per call, and the reference's own eval chunk of 512 rays (renderer.py:732)
         H, W = cfg["H"], cfg["W"]
         out["render"] = render_leg(L, R, S_, trainer, cfg, dev, args.render_chunk or H * W)
-        out["render_chunk512"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=2)
+        # the reference's eval chunk (renderer.py:732): sequential on one stream, and the same chunks issued round-robin on
+        # four HIP streams (independent chunks; one chunk fills 64-110 of the 256 CUs)
+        out["render_chunk512"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=2, streams=4)
+        out["render_chunk512_one_stream"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=2, streams=1)
     if rank == 0 and world == 1 and not args.no_final_stage and args.config == "nvidia" and args.stage == "stage0":
         # 78 % of the reference's iterations run after the last upsampling (configs/Nvidia.txt: upsamp_list[-1] =
         # 22000 of 100000): the same step at the final resolution

@@ -13,7 +13,7 @@ Importing this package loads librodynrf.so and raises if it is missing: there is
 """
 from . import _lib
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding, TensorBase
-from .renderer import (sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays, render_rays,
+from .renderer import (sampleXYZ, raw2outputs, OctreeRender_trilinear_fast, sample_rays, render_rays, render_chunks,
                        induce_flow, induce_flow_single, render_3d_point, render_single_3d_point,
                        eff_distloss, flatten_eff_distloss, render_frame, psnr)
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
@@ -23,5 +23,5 @@ from ._lib import RdrfError
 
 __all__ = ["render_frame", "psnr", "TVLoss", "pose_to_mtx", "eff_distloss", "flatten_eff_distloss", "induce_flow", "induce_flow_single", "render_3d_point", "render_single_3d_point",
            "TensorVMSplit", "TensorVMSplit_TimeEmbedding", "TensorBase", "sampleXYZ", "raw2outputs",
-           "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "generate_rays", "ids2pixel", "LossTerms",
+           "OctreeRender_trilinear_fast", "sample_rays", "render_rays", "render_chunks", "generate_rays", "ids2pixel", "LossTerms",
            "RdrfError"]

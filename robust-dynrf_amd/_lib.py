@@ -170,10 +170,13 @@ _ws = {}
 
 
 def workspace(device, nbytes):
-    buf = _ws.get(device)
+    """scratch of the C entry points, one buffer per (device, stream): calls on different streams (render_chunks) must
+    not share scratch"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-        _ws[device] = buf
+        _ws[key] = buf
     return buf
 
 

@@ -191,6 +191,40 @@ def render_rays(tensorf_static, tensorf, rays, ts, N_samples=-1, ray_type="ndc",
     return rgb, depth
 
 
+_stream_pool = {}
+
+
+@torch.no_grad()
+def render_chunks(tensorf_static, tensorf, rays, ts, chunk, N_samples=-1, ray_type="ndc", streams=4):
+    """The chunk loop of renderer.py:740-812 (`for chunk_idx in range(N_rays_all // chunk + ...)`) with the chunks issued
+    round-robin on `streams` HIP streams: the chunks are independent, and one 512-ray chunk (renderer.py:732) fills only
+    64-110 of the 256 CUs (one workgroup per CU: the MLP kernels keep their weights in 121-159 KB of LDS), so two to three
+    chunks run side by side.  streams <= 1: the plain sequential loop.  Returns (rgb_map [N,3], depth_map [N])."""
+    N = rays.shape[0]
+    dev = rays.device
+    rgb = torch.empty(N, 3, device=dev)
+    depth = torch.empty(N, device=dev)
+    if streams <= 1 or N <= chunk:
+        for c0 in range(0, N, chunk):
+            r, d = render_rays(tensorf_static, tensorf, rays[c0:c0 + chunk], ts[c0:c0 + chunk], N_samples, ray_type)
+            rgb[c0:c0 + chunk], depth[c0:c0 + chunk] = r, d
+        return rgb, depth
+    pool = _stream_pool.setdefault((dev, streams), [torch.cuda.Stream(device=dev) for _ in range(streams)])
+    cur = torch.cuda.current_stream(dev)
+    start = torch.cuda.Event()
+    start.record(cur)
+    for k, c0 in enumerate(range(0, N, chunk)):
+        st = pool[k % streams]
+        if k < streams:
+            st.wait_event(start)   # inputs (and the weights) are ready on the caller's stream
+        with torch.cuda.stream(st):
+            r, d = render_rays(tensorf_static, tensorf, rays[c0:c0 + chunk], ts[c0:c0 + chunk], N_samples, ray_type)
+            rgb[c0:c0 + chunk], depth[c0:c0 + chunk] = r, d
+    for st in pool:
+        cur.wait_stream(st)
+    return rgb, depth
+
+
 @torch.no_grad()
 def render_frame(tensorf_static, tensorf, poses9, focal, frame, H, W, N_samples=-1, ray_type="ndc",
                  chunk=None, t=None):

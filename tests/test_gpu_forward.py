@@ -219,6 +219,28 @@ def test_render_frame_matches_oracle_pipeline():
     assert float(rodynrf.psnr(a, a + 0.1)) == pytest.approx(20.0, abs=1e-3)
 
 
+@pytest.mark.parametrize("rt", ["ndc", "contract"])
+def test_render_chunks_on_hip_streams_is_bit_identical(rt):
+    """render_chunks: the 512-ray eval chunks of renderer.py:732-812 issued round-robin on 4 HIP streams (own scratch and
+    own packed weight image per stream) give the same bits as the sequential loop and as one call over all rays; repeated,
+    with a weight update in between (the per-stream packed images must follow it)."""
+    import rodynrf
+    from _gpu_util import fields_from_case, make_rays
+    g, st, dy, _ = fields_from_case("ndc_relu" if rt == "ndc" else "contract_relu_te")
+    rays, ts = (t.cuda() for t in make_rays(3000, 5, rt))
+    S = 40
+    for rep in range(2):
+        whole = rodynrf.render_rays(st, dy, rays, ts, N_samples=S, ray_type=rt)
+        seq = rodynrf.render_chunks(st, dy, rays, ts, 512, N_samples=S, ray_type=rt, streams=1)
+        par = rodynrf.render_chunks(st, dy, rays, ts, 512, N_samples=S, ray_type=rt, streams=4)
+        torch.cuda.synchronize()
+        for a, b in ((whole, seq), (whole, par)):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        with torch.no_grad():   # change the weights: every stream's image is re-packed before its next chunk
+            dy.renderModule.mlp[0].weight.mul_(1.01)
+            st.basis_mat.weight.mul_(0.99)
+
+
 def test_upsample_volume_grid_then_forward():
     """upsample_volume_grid (models/tensoRF.py:223-232, 838-850; bilinear, align_corners): the new
     factors keep the channel-last storage, stepSize / nSamples follow, and both fields still match
