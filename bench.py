@@ -384,6 +384,19 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
     return out
 
 
+def price_step(rf, ms, rays_per_gpu):
+    """fill the fields of a roofline() result that depend on the timed region's ms/step (the profiled replay runs BEFORE the
+    timed region: it doubles as the clock warm-up of the process, see main())"""
+    rf["step_frac_of_peak"] = rf["step_algorithmic_tflop"] / (ms * 1e-3) / PEAK_F32_MFMA_TFLOPS
+    sc = rf["survey_canonical"]
+    t_meas = ms * 1e-3 / rays_per_gpu
+    sc["frac_flop"] = sc["flop_per_training_ray"] / (PEAK_F32_MFMA_TFLOPS * 1e12 * t_meas)
+    sc["frac_bytes"] = sc["gather_bytes_per_training_ray"] / (8e12 * t_meas)
+    sc["achieved"] = max(sc["frac_flop"], sc["frac_bytes"])
+    rf["ms_per_step_minus_kernel_sum"] = ms - rf["sum_kernel_ms_per_step"]
+    return rf
+
+
 RENDER_KERNELS = ["pack", "sample_ndc", "sample_contract", "static_density", "static_app", "time_branch", "dyn_density", "dyn_app",
                   "composite", "render_fused"]
 
@@ -467,6 +480,9 @@ def main():
     ap.add_argument("--dp-per-shard-stats", action="store_true",
                     help="N > 1: normalise the masked-mean / per-frame depth losses by each rank's own batch statistics "
                          "instead of all-reducing them (default: exact single-process statistics, SURVEY 8e)")
+    ap.add_argument("--scatter", default="auto", choices=["auto", "ray", "sorted"],
+                    help="density / blending scatter of the dynamic field (rdrf_set_scatter_mode); auto = sorted from 800 k "
+                         "samples per launch")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -499,6 +515,7 @@ def main():
     S_ = importlib.import_module("robust-dynrf_amd.step")
     R = importlib.import_module("robust-dynrf_amd.renderer")
 
+    L.set_scatter_mode(args.scatter)
     cfg = S_.scene_config(args.config, args.stage)
     rpg = args.rays_per_gpu or cfg["batch_size"]
     cfg["batch_size"] = rpg * world   # weak scaling: fixed rays per GPU
@@ -510,6 +527,15 @@ def main():
         return S_.Trainer(dict(cfg), dev, weights=args.weights, dead_work=not args.exploit_liveness, dp_mode=args.dp,
                           dp_exact_stats=not args.dp_per_shard_stats)
 
+    # Order: the profiled replay FIRST (a fresh trainer with the same seeds runs iterations 0 .. warmup + steps, the last
+    # `steps` of them under HIP events), then the timed region on the main trainer.  The replay gives the kernel table of
+    # exactly the iterations that are timed afterwards, and it is the process's clock warm-up: the first ~second of GPU
+    # work of a fresh process runs the MFMA-bound kernels up to ~10 % slower than steady state (measured: a 20-step
+    # window timed right at start-up showed ms_per_step - kernel sum = 2.2 ms, of which 1.3 ms was clock ramp -- the same
+    # kernels profiled 4 s later were that much faster), which a training run of 100 000 iterations never sees.
+    rf = None
+    if not args.no_roofline:   # collective: every rank runs the profiled steps (rank 0 reports)
+        rf = roofline(L, S_, trainer, cfg, shard, rpg, 1.0, window=(make_trainer, args.warmup, min(args.steps, 400)))
     frs = {"S_": S_}
     dt, loss = timed_steps(trainer, shard, args.steps, args.warmup, world, dev, fractions=frs)
     ms = dt * 1e3
@@ -553,13 +579,8 @@ def main():
         out["liveness_exploited"] = {"value": cfg["batch_size"] / dt2, "unit": "rays/s", "ms_per_step": dt2 * 1e3,
                                      "note": "dead dynamic forwards skipped (SURVEY 3.1: nothing consumes them)"}
         trainer.dead_work = True
-    if not args.no_roofline:   # collective: every rank runs the profiled steps (rank 0 reports)
-        # the profiled steps replay the timed region's own iterations on a fresh trainer (same seeds): a kernel sum that can
-        # be set against ms_per_step
-        rf = roofline(L, S_, trainer, cfg, shard, rpg, ms, window=(make_trainer, args.warmup, min(args.steps, 400)))
-        if rank == 0:
-            out["roofline"] = rf
-            out["roofline"]["ms_per_step_minus_kernel_sum"] = ms - rf["sum_kernel_ms_per_step"]
+    if rf is not None and rank == 0:
+        out["roofline"] = price_step(rf, ms, rpg)
     if rank == 0 and world == 1 and not args.no_render:
         # BASELINE.json's second metric: render Mpix/s through the no-grad chunk loop of renderer.py:740-812 --
         # whole frames per call, and the reference's own eval chunk of 512 rays (renderer.py:732)

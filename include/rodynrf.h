@@ -38,7 +38,7 @@ extern "C" {
 /* 2: RdrfStaticParams / RdrfDynamicParams grew the trailing packed_fwd / packed_bwd pointers (round 2);
  * 3: sorted scatter workspace + fused render entry points (round 3);
  * 4: rdrf_set_scatter_mode replaces the RDRF_SCATTER / RDRF_RENDER environment switches -- no entry point reads the
- *    caller's environment any more (round 4).  A binding built against another version must refuse to load: the structs
+ *    caller's environment any more; rdrf_render_chunks_fwd (round 4).  A binding built against another version must refuse to load: the structs
  *    are passed by pointer and read to their full length. */
 #define RDRF_ABI_VERSION 4
 
@@ -415,6 +415,16 @@ int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg
                              const RdrfDynamicParams* PD, const RdrfFieldCfg* cfg_d, const float* rays,
                              const float* ts, int N, int S, float near, float far, float* rgb_map,
                              float* depth_map, void* ws, size_t ws_bytes, rdrf_stream_t stream);
+
+/* ---- the eval chunk loop of renderer.py:740-812 (chunk = 512 rays, renderer.py:732) as one native call: the launch
+ * sequences of the chunks are issued round-robin on `nstreams` caller streams (0: all on main_stream), which first wait for
+ * main_stream and which main_stream finally waits for.  Both parameter structs must carry packed_fwd; ws: nstreams slices of
+ * rdrf_render_workspace_bytes(chunk, S) (rdrf_render_chunks_workspace_bytes).  Same bits as rdrf_render_fwd per chunk. */
+size_t rdrf_render_chunks_workspace_bytes(int chunk, int S, int nstreams);
+int rdrf_render_chunks_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s, const RdrfDynamicParams* PD,
+                           const RdrfFieldCfg* cfg_d, const float* rays, const float* ts, int N, int S, int chunk,
+                           float near, float far, float* rgb_map, float* depth_map, void* ws, size_t ws_bytes,
+                           rdrf_stream_t main_stream, const rdrf_stream_t* streams, int nstreams);
 
 /* ---- process-wide choice of the density / blending scatter of the dynamic field's backward (models/tensoRF.py:646-811,
  * grid_sampler_2d_backward semantics either way): RDRF_SCATTER_RAY = ray tiles, RDRF_SCATTER_SORTED = samples grouped by

@@ -84,6 +84,8 @@ def _load():
     lib.rdrf_frame_depth_loss_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     lib.rdrf_render_workspace_bytes.restype = C.c_size_t
     lib.rdrf_render_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.rdrf_render_chunks_workspace_bytes.restype = C.c_size_t
+    lib.rdrf_render_chunks_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.rdrf_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.rdrf_det_bind.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.rdrf_det_finish.argtypes = [C.c_int, C.c_void_p]
@@ -112,7 +114,8 @@ SYMBOLS = [
     "rdrf_loss_terms_stats", "rdrf_loss_terms_finish", "rdrf_deterministic", "rdrf_det_bind", "rdrf_det_finish",
     "rdrf_render_fused_fwd", "rdrf_render_sequence_fwd",
     "rdrf_frame_depth_loss_workspace_bytes", "rdrf_frame_depth_loss_fwd", "rdrf_frame_depth_loss_bwd",
-    "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_set_scatter_mode", "rdrf_selftest_mlp", "rdrf_prof_reset",
+    "rdrf_render_workspace_bytes", "rdrf_render_fwd", "rdrf_render_chunks_workspace_bytes", "rdrf_render_chunks_fwd",
+    "rdrf_set_scatter_mode", "rdrf_selftest_mlp", "rdrf_prof_reset",
     "rdrf_prof_enable", "rdrf_prof_get",
 ]
 

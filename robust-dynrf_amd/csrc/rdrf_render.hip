@@ -268,6 +268,59 @@ extern "C" int rdrf_render_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* c
 }
 
 // ------------------------------------------------------------------------------------------------
+// The reference's eval loop (renderer.py:740-812: `for chunk_idx in range(N_rays_all // chunk + ...)`, chunk = 512,
+// renderer.py:732) as ONE native call: the chunks' launch sequences are issued round-robin on `nstreams` caller streams.
+// Why native: issued from Python, one chunk costs ~250 us of host time (struct marshalling + 10 launches) against
+// ~190 us of GPU time -- the loop is host-bound; from here a chunk costs its launches.  Why streams: one 512-ray chunk
+// fills 64-110 of the 256 CUs (the MLP kernels hold one workgroup per CU: 121-159 KB of LDS), the chunks are
+// independent, so several run side by side.  Both packed weight images must be supplied (packed_fwd: they are shared,
+// read-only, by every stream); `ws` is cut into one slice of rdrf_render_workspace_bytes(chunk, S) per stream.
+// Ordering: every stream first waits for `main_stream` (inputs, weights), `main_stream` finally waits for every stream.
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t rdrf_render_chunks_workspace_bytes(int chunk, int S, int nstreams) {
+  return (size_t)(nstreams < 1 ? 1 : nstreams) * ((rdrf_render_workspace_bytes(chunk, S) + 255) & ~(size_t)255);
+}
+extern "C" int rdrf_render_chunks_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s, const RdrfDynamicParams* PD,
+                                      const RdrfFieldCfg* cfg_d, const float* rays, const float* ts, int N, int S, int chunk,
+                                      float near, float far, float* rgb_map, float* depth_map, void* ws, size_t ws_bytes,
+                                      rdrf_stream_t main_stream_, const rdrf_stream_t* streams, int nstreams) {
+  if (N == 0) return 0;
+  RDRF_CHECK(PS && PD && cfg_s && cfg_d && rays && ts && rgb_map && depth_map && ws && chunk > 0 && S > 0, -1,
+             "render_chunks: bad arguments");
+  RDRF_CHECK(PS->packed_fwd != nullptr && PD->packed_fwd != nullptr, -1,
+             "render_chunks: both packed weight images are required (rdrf_static_pack / rdrf_dynamic_pack)");
+  RDRF_CHECK(nstreams >= 0 && nstreams <= 16 && (nstreams == 0 || streams != nullptr), -1, "render_chunks: 0..16 streams");
+  hipStream_t main_stream = (hipStream_t)main_stream_;
+  const int ns = nstreams < 1 ? 1 : nstreams;
+  const size_t slice = (rdrf_render_workspace_bytes(chunk < N ? chunk : N, S) + 255) & ~(size_t)255;
+  RDRF_CHECK(ws_bytes >= slice * ns, -3, "render_chunks: workspace too small: need %zu have %zu", slice * ns, ws_bytes);
+  hipEvent_t ev_start = nullptr, ev_done[16];
+  if (nstreams >= 1) {
+    RDRF_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+    RDRF_HIP(hipEventRecord(ev_start, main_stream));
+    for (int k = 0; k < nstreams; ++k) RDRF_HIP(hipStreamWaitEvent((hipStream_t)streams[k], ev_start, 0));
+  }
+  int rc = 0, k = 0;
+  for (int c0 = 0; c0 < N && rc == 0; c0 += chunk, ++k) {
+    const int n = N - c0 < chunk ? N - c0 : chunk;
+    const int si = k % ns;
+    rdrf_stream_t st = nstreams >= 1 ? streams[si] : main_stream_;
+    rc = rdrf_render_sequence_fwd(PS, cfg_s, PD, cfg_d, rays + (size_t)c0 * 6, ts + c0, n, S, near, far, rgb_map + (size_t)c0 * 3,
+                                  depth_map + c0, (char*)ws + slice * si, slice, st);
+  }
+  if (nstreams >= 1) {   // join (also on error: the streams must not run past the caller's buffers unobserved)
+    for (int q = 0; q < nstreams; ++q) {
+      if (hipEventCreateWithFlags(&ev_done[q], hipEventDisableTiming) != hipSuccess) { rc = rc ? rc : -5; continue; }
+      (void)hipEventRecord(ev_done[q], (hipStream_t)streams[q]);
+      (void)hipStreamWaitEvent(main_stream, ev_done[q], 0);
+      (void)hipEventDestroy(ev_done[q]);   // released when the recorded work completes
+    }
+    (void)hipEventDestroy(ev_start);
+  }
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // self-test: y[M][64] = relu(x[M][64] W^T + b) through pack + LDS + mfma_seg, one tile per wave
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_selftest(const float* __restrict__ x,

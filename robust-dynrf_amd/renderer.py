@@ -196,32 +196,38 @@ _stream_pool = {}
 
 @torch.no_grad()
 def render_chunks(tensorf_static, tensorf, rays, ts, chunk, N_samples=-1, ray_type="ndc", streams=4):
-    """The chunk loop of renderer.py:740-812 (`for chunk_idx in range(N_rays_all // chunk + ...)`) with the chunks issued
-    round-robin on `streams` HIP streams: the chunks are independent, and one 512-ray chunk (renderer.py:732) fills only
-    64-110 of the 256 CUs (one workgroup per CU: the MLP kernels keep their weights in 121-159 KB of LDS), so two to three
-    chunks run side by side.  streams <= 1: the plain sequential loop.  Returns (rgb_map [N,3], depth_map [N])."""
-    N = rays.shape[0]
-    dev = rays.device
+    """The chunk loop of renderer.py:740-812 (`for chunk_idx in range(N_rays_all // chunk + ...)`, chunk = 512 at
+    renderer.py:732) as ONE native call (rdrf_render_chunks_fwd): the chunks' launch sequences are issued from C,
+    round-robin on `streams` HIP streams (0 / 1: all on the current stream).  Issued chunk by chunk from Python the loop
+    is host-bound (~250 us of marshalling per chunk against ~190 us of GPU work); and one 512-ray chunk fills only
+    64-110 of the 256 CUs, so independent chunks run side by side.  Same bits as render_rays on the whole batch.
+    Returns (rgb_map [N,3], depth_map [N])."""
+    from .fields import _attach_packed, _cfg_struct, _dynamic_struct, _static_struct
+    L.require_device(rays, ts)
+    rays, ts = L.f32c(rays), L.f32c(ts)
+    N, dev = rays.shape[0], rays.device
+    S = int(N_samples) if N_samples and N_samples > 0 else tensorf.nSamples
+    chunk = int(chunk)
     rgb = torch.empty(N, 3, device=dev)
     depth = torch.empty(N, device=dev)
-    if streams <= 1 or N <= chunk:
-        for c0 in range(0, N, chunk):
-            r, d = render_rays(tensorf_static, tensorf, rays[c0:c0 + chunk], ts[c0:c0 + chunk], N_samples, ray_type)
-            rgb[c0:c0 + chunk], depth[c0:c0 + chunk] = r, d
+    if N == 0:
         return rgb, depth
-    pool = _stream_pool.setdefault((dev, streams), [torch.cuda.Stream(device=dev) for _ in range(streams)])
-    cur = torch.cuda.current_stream(dev)
-    start = torch.cuda.Event()
-    start.record(cur)
-    for k, c0 in enumerate(range(0, N, chunk)):
-        st = pool[k % streams]
-        if k < streams:
-            st.wait_event(start)   # inputs (and the weights) are ready on the caller's stream
-        with torch.cuda.stream(st):
-            r, d = render_rays(tensorf_static, tensorf, rays[c0:c0 + chunk], ts[c0:c0 + chunk], N_samples, ray_type)
-            rgb[c0:c0 + chunk], depth[c0:c0 + chunk] = r, d
-    for st in pool:
-        cur.wait_stream(st)
+    ns = int(streams) if streams and streams > 1 and N > chunk else 0
+    ws = L.workspace(dev, int(L.lib.rdrf_render_chunks_workspace_bytes(min(chunk, N), S, max(ns, 1))))
+    ps_list, pd_list = tensorf_static._param_list(), tensorf._param_list()
+    PS, PD = _static_struct(ps_list), _dynamic_struct(pd_list)
+    _attach_packed(tensorf_static, PS, ps_list, False, False)   # one image each, packed on the current stream, shared
+    _attach_packed(tensorf, PD, pd_list, False, True)           # read-only by every side stream
+    cs, cd = _cfg_struct(tensorf_static, ray_type), _cfg_struct(tensorf, ray_type)
+    near, far = tensorf.near_far
+    pool = _stream_pool.setdefault((dev, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
+    arr = (C.c_void_p * max(ns, 1))(*[st.cuda_stream for st in pool]) if ns else None
+    L.check(L.lib.rdrf_render_chunks_fwd(C.byref(PS), C.byref(cs), C.byref(PD), C.byref(cd), L.ptr(rays), L.ptr(ts), N, S, chunk,
+                                         C.c_float(near), C.c_float(far), L.ptr(rgb), L.ptr(depth), L.ptr(ws),
+                                         C.c_size_t(ws.numel()), L.stream_of(rays), arr, ns), "rdrf_render_chunks_fwd")
+    for st in pool:   # the caching allocator must not hand these buffers to another stream's request while the side
+        for t in (rays, ts, rgb, depth, ws):   # streams may still read / write them
+            t.record_stream(st)
     return rgb, depth
 
 
