@@ -429,7 +429,7 @@ int rdrf_render_chunks_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s
 /* ---- process-wide choice of the density / blending scatter of the dynamic field's backward (models/tensoRF.py:646-811,
  * grid_sampler_2d_backward semantics either way): RDRF_SCATTER_RAY = ray tiles, RDRF_SCATTER_SORTED = samples grouped by
  * plane cell first (about 10x fewer memory-side atomic requests, a fixed grouping cost per launch), RDRF_SCATTER_AUTO
- * (default) = sorted from 800 k samples per launch.  Returns 0, or -1 for an unknown mode. */
+ * (default) = sorted from 300 k samples per launch.  Returns 0, or -1 for an unknown mode. */
 int rdrf_set_scatter_mode(int mode);
 
 /* ---- deterministic debugging build (librodynrf_det.so = the same sources with -DRDRF_DETERMINISTIC) ----------------

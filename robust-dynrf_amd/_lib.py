@@ -124,7 +124,7 @@ SCATTER_MODES = {"ray": 0, "sorted": 1, "auto": 2}
 
 
 def set_scatter_mode(mode):
-    """rdrf_set_scatter_mode: "auto" (default: sorted from 800 k samples per launch) | "ray" | "sorted" """
+    """rdrf_set_scatter_mode: "auto" (default: sorted from 300 k samples per launch) | "ray" | "sorted" """
     check(lib.rdrf_set_scatter_mode(SCATTER_MODES[mode]), "rdrf_set_scatter_mode")
 
 

@@ -2307,9 +2307,10 @@ extern "C" int rdrf_set_scatter_mode(int mode) {
 static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
   int m = g_scatter_mode;
   if (const char* e = RDRF_ENV("RDRF_SCATTER")) m = !strcmp(e, "sorted") ? RDRF_SCATTER_SORTED : (!strcmp(e, "ray") ? RDRF_SCATTER_RAY : m);
-  // auto: measured break-even between the Balloon1 stage-0 shape (4096 x 115 samples: sorted 816 us vs ray 695 us) and the
-  // final shape (4096 x 270: 1562 vs 1802)
-  if (m == RDRF_SCATTER_AUTO) return ns >= (size_t)800000 ? 1 : 0;
+  // auto: with the hand-written radix sort (72 us for 1.4 M keys; rocPRIM took 150) the sorted path wins from the
+  // Balloon1 stage-0 pass (4096 x 115 = 471 k samples: 12.57 vs 12.72 ms/step, interleaved A/B on one box) upwards, and
+  // sends a tenth of the atomic requests; below ~300 k samples the fixed cost of its seven extra launches dominates
+  if (m == RDRF_SCATTER_AUTO) return ns >= (size_t)300000 ? 1 : 0;
   return m == RDRF_SCATTER_SORTED ? 1 : 0;
 }
 
