@@ -337,7 +337,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
                    "(~150 cycles per wave instruction): `frac` is NOMINAL (algorithmic bytes / time against the HBM peak; "
                    "the contract offers hbm | mfma); hbm_real = PMC bytes / time, l2_atomic_frac = atomic requests / "
                    "time / 20.8 G/s, both over all launches of the k_scatter family in a step, and frac_l2 (against the "
-                   "34.5 TB/s L2) are the physical figures; launches of >= 800 k samples take the sorted kernels "
+                   "34.5 TB/s L2) are the physical figures; launches of >= 300 k samples take the sorted kernels "
                    "(~10x fewer requests)"}
     dom_e, oth_e = (sc_entry, dw_entry) if (not dw_keys or sc_ms >= dw_ms) else (dw_entry, sc_entry)
     out = dict(dom_e)
@@ -481,7 +481,7 @@ def main():
                     help="N > 1: normalise the masked-mean / per-frame depth losses by each rank's own batch statistics "
                          "instead of all-reducing them (default: exact single-process statistics, SURVEY 8e)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "ray", "sorted"],
-                    help="density / blending scatter of the dynamic field (rdrf_set_scatter_mode); auto = sorted from 800 k "
+                    help="density / blending scatter of the dynamic field (rdrf_set_scatter_mode); auto = sorted from 300 k "
                          "samples per launch")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-repeats", type=int, default=3)
