@@ -76,6 +76,14 @@ RDRF_HD constexpr int dfs_off(int Q) {   // feature quad Q = 6 level + w  (w < 4
   return (Q % 6) < 4 ? (Q / 6) * 16 + 4 * (Q % 6) : ((Q % 6) == 4 ? 48 + 4 * (Q / 6) : 60 + 4 * (Q / 6));
 }
 
+// sample-major d(feature) record of the SORTED APPEARANCE scatter: 216 floats per compacted sample, ordered
+// [XY: level 0 (48) | level 1 (48) | level 2 (48)] [XZ: 3 x 12] [YZ: 3 x 12]  (an XY level block = three 64-byte lines)
+#define DFA_FLOATS 216
+RDRF_HD constexpr int dfa_off(int Q) {   // feature quad Q = 18 level + w  (w < 12: XY quad w, 12..14: XZ, 15..17: YZ)
+  return (Q % 18) < 12 ? (Q / 18) * 48 + 4 * (Q % 18)
+                       : ((Q % 18) < 15 ? 144 + 12 * (Q / 18) + 4 * ((Q % 18) - 12) : 180 + 12 * (Q / 18) + 4 * ((Q % 18) - 15));
+}
+
 struct BwdArgs {
   const float* rays;
   const float* ts;
@@ -99,6 +107,7 @@ struct BwdArgs {
   float* dtout;    // [N*32]
   float* dfs;      // sorted scatter: d(features) of the density / blending heads SAMPLE-major, [N*S][2][72] in the
                    // order [XY quads of level 0, 1, 2 | XZ quads | YZ quads] (nullptr: row layout for the ray-tile scatter)
+  float* dfa;      // sorted appearance scatter: d(app features) per COMPACTED sample, [count][216] (dfa_off); nullptr: rows
   // outputs
   float* g_xyz;
   float* g_rays;   // [N][6] (+=): through dists (ray norm) and the static head's view directions
@@ -748,7 +757,8 @@ RDRF_D void feat_dF(float (&dF)[16], const float* g_feat, int idx, bool act, int
   }
 }
 
-template <bool FEAT>
+// REC: d(app features) go out as sample-major records for the sorted scatter (a.dfa) instead of DA rows
+template <bool FEAT, bool REC = false>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ __attribute__((aligned(16))) float lds[pkb::K3_SIZE];
   lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_SIZE);
@@ -833,7 +843,24 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
       mfma_seg<7, 16>(acc, dF, basisT, lane);
       float dA[112];
       acc_copy<7>(dA, acc);
-      save_rows<112>(gb, sv::K3G_DA, dA, s, h);
+      if constexpr (REC) {
+        // sample-major record for the sorted scatter: this lane half holds the feature quads Q = 2 m + h (slots
+        // 4m..4m+3) of compacted sample li; one 16-byte store per quad, the two halves write adjacent quads
+        if (act) {
+          // quad 2 m + 1 sits 4 floats after quad 2 m in the record, except for the (XZ quad 2 | YZ quad 0) pair of
+          // every level: one base pointer per half + immediate offsets
+          float* rec = a.dfa + (size_t)li * DFA_FLOATS + 4 * h;
+          float* recx = a.dfa + (size_t)li * DFA_FLOATS + (h ? dfa_off(15) - dfa_off(14) : 0);
+#pragma unroll
+          for (int m = 0; m < 27; ++m) {
+            static_assert(dfa_off(1) == dfa_off(0) + 4 && dfa_off(13) == dfa_off(12) + 4 && dfa_off(17) == dfa_off(16) + 4, "record layout");
+            float* dst = (m % 9 == 7 ? recx : rec) + dfa_off(2 * m);
+            *reinterpret_cast<f32x4*>(dst) = f32x4{dA[4 * m], dA[4 * m + 1], dA[4 * m + 2], dA[4 * m + 3]};
+          }
+        }
+      } else {
+        save_rows<112>(gb, sv::K3G_DA, dA, s, h);
+      }
     }
     if (act && h == 0) {
       a.dxn_app[(size_t)idx * 3 + 0] = dn0; a.dxn_app[(size_t)idx * 3 + 1] = dn1;
@@ -1213,6 +1240,8 @@ struct SortKeyArgs {
   const float* xw;
   const uint8_t* valid;
   const float* grows1;   // K1G_SM rows 3 / 4 hold g_fd / g_fb: a sample with both zero scatters nothing
+  const int* list;       // appearance: the compacted sample ids (entry li of the key arrays = compacted sample li) ...
+  const int* count;      // ... and their device count; nullptr: every sample of the batch, liveness from valid / grows1
   int N, S;
   int W[3], H[3];        // level-0 plane sizes
   int kb;                // bits of the cell part of the key
@@ -1229,10 +1258,16 @@ RDRF_D int cell_axis(float c, int L, bool& any) {
 
 __global__ __launch_bounds__(256) void k_sort_keys(SortKeyArgs a) {
   const int NS = a.N * a.S, tpr = (a.S + 31) >> 5;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NS; idx += gridDim.x * blockDim.x) {
+  const int count = a.list ? *a.count : 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NS; e += gridDim.x * blockDim.x) {
     bool live = false;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    {
+    if (a.list) {
+      live = e < count;
+      const int idx = live ? a.list[e] : 0;
+      x0 = a.xw[(size_t)idx * 3 + 0]; x1 = a.xw[(size_t)idx * 3 + 1]; x2 = a.xw[(size_t)idx * 3 + 2];
+    } else {
+      const int idx = e;
       const int n = idx / a.S, j = idx - n * a.S;
       const float* sm = a.grows1 + ((size_t)(n * tpr + (j >> 5)) * sv::K1G_ROWS + sv::K1G_SM) * 32 + (j & 31);
       live = a.valid[idx] != 0 && (sm[3 * 32] != 0.f || sm[4 * 32] != 0.f);
@@ -1245,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_sort_keys(SortKeyArgs a) {
       const int ix = cell_axis(cx, a.W[p], ax), iy = cell_axis(cy, a.H[p], ay);
       const bool in = live && ax && ay;
       const unsigned cell = in ? (unsigned)(iy * (a.W[p] + 3) + ix) : ((1u << a.kb) - 1u);
-      a.keys[(size_t)p * NS + idx] = ((unsigned)p << a.kb) | cell;
+      a.keys[(size_t)p * NS + e] = ((unsigned)p << a.kb) | cell;
     }
   }
 }
@@ -1268,16 +1303,20 @@ __global__ void k_sort_counts(const unsigned* __restrict__ keys_sorted, int NS, 
 struct SortedScatterArgs {
   RdrfVM vm[2], gvm[2];
   int set_mask;            // bit k: set k has a gradient
-  const unsigned* order;   // [NS] sorted positions of THIS plane (value = plane * NS + sample index)
+  const unsigned* order;   // [NS] sorted positions of THIS plane (value = plane * NS + entry index)
   const int* count;        // live entries of this plane
   unsigned base;           // plane * NS
-  const float* dfs;
+  const float* dfs;        // records: entry e at dfs + e * rec_floats (+ set * floats per set)
+  int rec_floats;
+  const int* list;         // appearance: entry e is compacted sample e, its sample id is list[e]; nullptr: entry = sample id
   const float* xw;
   float* dxw;              // += coordinate gradients
   int lds_bytes;
 };
 
-template <int PLANE>
+// C0Q / C1Q: quads of an XY / XZ-YZ texel: <4, 1> density and blending ({16,4,4} components, two sets per record),
+// <12, 3> appearance ({48,12,12}, one set, entries = the compacted list)
+template <int PLANE, int C0Q, int C1Q>
 __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) {
   extern __shared__ float lacc[];
   const int nl0 = lines_floats(a.vm[0]), nl1 = lines_floats(a.vm[1]);
@@ -1289,26 +1328,36 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int count = *a.count;
   constexpr int SPT = PLANE == 0 ? 16 : 32;   // samples per wave step
+  // record of one set: [XY level 0 | 1 | 2 (XYF floats each)] [XZ: 3 x ZF] [YZ: 3 x ZF]
+  constexpr int XYF = 4 * C0Q, ZF = 4 * C1Q, SETF = 3 * XYF + 6 * ZF, QPL = C0Q + 2 * C1Q;
   const int ntiles = (count + SPT - 1) / SPT;
   for (int t = blockIdx.x * nwaves + wave; t < ntiles; t += gridDim.x * nwaves) {
     const int pos = t * SPT + (PLANE == 0 ? s16 : s);
     const bool live = pos < count;
-    const int idx = live ? (int)(a.order[pos] - a.base) : 0;
+    const int ent = live ? (int)(a.order[pos] - a.base) : 0;
+    const int idx = a.list ? a.list[ent] : ent;
     const float x0 = a.xw[(size_t)idx * 3 + 0], x1 = a.xw[(size_t)idx * 3 + 1], x2 = a.xw[(size_t)idx * 3 + 2];
     float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
 #pragma unroll 1
     for (int set = 0; set < 2; ++set) {
       if (!((a.set_mask >> set) & 1)) continue;
       const LdsLines ll = make_lds_lines(use_lacc ? lacc + (set ? nl0 : 0) : nullptr, a.vm[set]);
-      const float* rec = a.dfs + (size_t)idx * DFS_FLOATS + set * 72;
+      const float* rec = a.dfs + (size_t)ent * a.rec_floats + set * SETF;
 #pragma unroll 1
       for (int lv = 0; lv < 3; ++lv) {
         if constexpr (PLANE == 0) {
-          const f32x4 dq = live ? ld4(rec + lv * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-          gather_xy4_bwd<4, 1>(a.vm[set], a.gvm[set], lv, q, x0, x1, x2, dq, live, q == 0, dw0, dw1, dw2, ll);
+#pragma unroll 1
+          for (int grp = 0; grp < C0Q / 4; ++grp) {
+            const f32x4 dq = live ? ld4(rec + lv * XYF + grp * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gather_xy4_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], lv, 4 * grp + q, x0, x1, x2, dq, live, q == 0, dw0, dw1, dw2, ll);
+          }
         } else {
-          const f32x4 dq = live ? ld4(rec + 48 + (PLANE - 1) * 12 + lv * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-          gather_zquad_bwd<4, 1>(a.vm[set], a.gvm[set], lv * 6 + 4 + (PLANE - 1), h, x0, x1, x2, dq, live, s, dw0, dw1, dw2, ll);
+#pragma unroll 1
+          for (int zq = 0; zq < C1Q; ++zq) {
+            const f32x4 dq = live ? ld4(rec + 3 * XYF + (PLANE - 1) * 3 * ZF + lv * ZF + 4 * zq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gather_zquad_bwd<C0Q, C1Q>(a.vm[set], a.gvm[set], lv * QPL + C0Q + (PLANE - 1) * C1Q + zq, h, x0, x1, x2, dq, live, s,
+                                       dw0, dw1, dw2, ll);
+          }
         }
       }
     }
@@ -2204,7 +2253,7 @@ extern "C" size_t rdrf_workspace_bytes(int N, int S) {
   size_t bwd = (size_t)PACK_AREA_FLOATS * 4 + t1 * sv::K1G_ROWS * 32 * 4 + t3 * sv::K3G_ROWS * 32 * 4 +
                ns * 3 * 4 * 2 + (size_t)N * 32 * 4 + (1 << 14);
   // sorted scatter: sample-major d(feature) records, keys in / out, sorted positions, counters, radix-sort scratch
-  bwd += ns * DFS_FLOATS * 4 + 3 * ns * 4 * 3 + 1024 + rdrf_sort_temp_bytes((unsigned)(3 * ns), 32) + (1 << 12);
+  bwd += ns * DFS_FLOATS * 4 + ns * DFA_FLOATS * 4 + 3 * ns * 4 * 3 + 1024 + rdrf_sort_temp_bytes((unsigned)(3 * ns), 32) + (1 << 12);
   size_t sf = (size_t)PACK_AREA_FLOATS * 4 + t3 * sv::SFG_ROWS * 32 * 4 + (1 << 12);
   size_t m = fwd > bwd ? fwd : bwd;
   return m > sf ? m : sf;
@@ -2212,6 +2261,7 @@ extern "C" size_t rdrf_workspace_bytes(int N, int S) {
 
 struct BwdWs {
   float* dfs;            // sorted scatter (dynamic field)
+  float* dfa;            // sorted appearance scatter: [N*S] records of DFA_FLOATS (capacity; count <= N*S entries are used)
   unsigned *keys_in, *keys_out, *order;
   int* counts;
   void* sort_tmp;
@@ -2235,8 +2285,10 @@ static int carve_bwd(BwdWs& b, void* ws, size_t ws_bytes, int N, int S, int dyna
   b.dtout = dynamic ? c.take<float>((size_t)N * 32) : nullptr;
   b.gf = dynamic ? nullptr : c.take<float>(t1 * 32);
   b.dfs = nullptr;
+  b.dfa = nullptr;
   if (dynamic) {
     b.dfs = c.take<float>(ns * DFS_FLOATS);
+    b.dfa = c.take<float>(ns * DFA_FLOATS);
     b.keys_in = c.take<unsigned>(3 * ns);
     b.keys_out = c.take<unsigned>(3 * ns);
     b.order = c.take<unsigned>(3 * ns);
@@ -2314,7 +2366,7 @@ static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
   return m == RDRF_SCATTER_SORTED ? 1 : 0;
 }
 
-template <int PLANE>
+template <int PLANE, int C0Q, int C1Q>
 static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStream_t stream) {
   const long bytes = 4L * (lines_floats_host(sa.vm[0]) + lines_floats_host(sa.vm[1]));
   sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
@@ -2322,7 +2374,7 @@ static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStr
   sa.lds_bytes = 0;
 #endif
   if (sa.lds_bytes > 48 * 1024)
-    RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_sorted<PLANE>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
+    RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_sorted<PLANE, C0Q, C1Q>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
   const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;
   const int wpb = threads / 64;
   const long ntiles = (max_samples + (PLANE == 0 ? 15 : 31)) / (PLANE == 0 ? 16 : 32);
@@ -2331,22 +2383,19 @@ static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStr
   g = g < 1 ? 1 : (g > cap ? cap : g);
   static const char* names[3] = {"scatter_sorted_xy", "scatter_sorted_xz", "scatter_sorted_yz"};
   rdrf_prof_begin(names[PLANE], stream);
-  hipLaunchKernelGGL(k_scatter_sorted<PLANE>, dim3((unsigned)g), dim3(threads), (size_t)sa.lds_bytes, stream, sa);
+  hipLaunchKernelGGL((k_scatter_sorted<PLANE, C0Q, C1Q>), dim3((unsigned)g), dim3(threads), (size_t)sa.lds_bytes, stream, sa);
   rdrf_prof_end(names[PLANE], stream);
   RDRF_HIP(hipGetLastError());
   return 0;
 }
 
-// density / blending scatter of the dynamic field's ray path, samples grouped by plane cell (see k_scatter_sorted)
-static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDynamicParams* P, const RdrfDynamicParams* G,
-                                      int set_mask, hipStream_t stream) {
+// keys of the entries (all samples, or the compacted list), stable sort by (plane | cell), live counts per plane
+static int sorted_scatter_prepare(SortKeyArgs& ka, const RdrfVM& vm, const BwdArgs& a, const BwdWs& b, hipStream_t stream) {
   const size_t ns = (size_t)a.N * a.S;
-  SortKeyArgs ka;
-  ka.xw = a.sp.xw; ka.valid = a.valid; ka.grows1 = b.grows1; ka.N = a.N; ka.S = a.S;
+  ka.xw = a.sp.xw; ka.valid = a.valid; ka.N = a.N; ka.S = a.S;
   long maxcells = 0;
   for (int p = 0; p < 3; ++p) {
-    ka.W[p] = P->density.W[p]; ka.H[p] = P->density.H[p];
-    RDRF_CHECK(P->blending.W[p] == ka.W[p] && P->blending.H[p] == ka.H[p], -1, "sorted scatter: density and blending planes differ in size");
+    ka.W[p] = vm.W[p]; ka.H[p] = vm.H[p];
     const long c = (long)(ka.W[p] + 3) * (ka.H[p] + 3);
     maxcells = c > maxcells ? c : maxcells;
   }
@@ -2367,14 +2416,53 @@ static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const Rd
   hipLaunchKernelGGL(k_sort_counts, dim3(1), dim3(64), 0, stream, (const unsigned*)b.keys_out, (int)ns, kb, b.counts);
   rdrf_prof_end("scatter_sort", stream);
   RDRF_HIP(hipGetLastError());
+  return 0;
+}
+
+// appearance scatter of the dynamic field's ray path with the compacted samples grouped by plane cell: the same
+// per-quad device functions as the ray-tile kernel (k_scatter<12, 3, 27>), whose 18 M memory-side atomic requests per
+// launch (runs of 1-2 samples along a ray) were the largest share of the step's requests
+static int scatter_dyn_app_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDynamicParams* P, const RdrfDynamicParams* G,
+                                  hipStream_t stream) {
+  const size_t ns = (size_t)a.N * a.S;
+  SortKeyArgs ka;
+  memset(&ka, 0, sizeof(ka));
+  ka.list = a.sp.list; ka.count = &a.sp.hdr->count;
+  int rc = sorted_scatter_prepare(ka, P->app, a, b, stream);
+  if (rc) return rc;
+  SortedScatterArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.vm[0] = P->app; sa.gvm[0] = G->app;
+  sa.set_mask = 1; sa.dfs = b.dfa; sa.rec_floats = DFA_FLOATS; sa.list = a.sp.list; sa.xw = a.sp.xw; sa.dxw = b.dxw;
+  for (int p = 0; p < 3; ++p) {
+    sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
+    rc = p == 0 ? launch_scatter_sorted<0, 12, 3>(sa, (long)ns, stream)
+                : (p == 1 ? launch_scatter_sorted<1, 12, 3>(sa, (long)ns, stream) : launch_scatter_sorted<2, 12, 3>(sa, (long)ns, stream));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// density / blending scatter of the dynamic field's ray path, samples grouped by plane cell (see k_scatter_sorted)
+static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDynamicParams* P, const RdrfDynamicParams* G,
+                                      int set_mask, hipStream_t stream) {
+  const size_t ns = (size_t)a.N * a.S;
+  for (int p = 0; p < 3; ++p)
+    RDRF_CHECK(P->blending.W[p] == P->density.W[p] && P->blending.H[p] == P->density.H[p], -1,
+               "sorted scatter: density and blending planes differ in size");
+  SortKeyArgs ka;
+  memset(&ka, 0, sizeof(ka));
+  ka.grows1 = b.grows1;
+  int rc = sorted_scatter_prepare(ka, P->density, a, b, stream);
+  if (rc) return rc;
   SortedScatterArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.vm[1] = P->blending; sa.gvm[1] = G->blending;
-  sa.set_mask = set_mask; sa.dfs = b.dfs; sa.xw = a.sp.xw; sa.dxw = b.dxw;
+  sa.set_mask = set_mask; sa.dfs = b.dfs; sa.rec_floats = DFS_FLOATS; sa.xw = a.sp.xw; sa.dxw = b.dxw;
   for (int p = 0; p < 3; ++p) {
     sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
-    rc = p == 0 ? launch_scatter_sorted<0>(sa, (long)ns, stream)
-                : (p == 1 ? launch_scatter_sorted<1>(sa, (long)ns, stream) : launch_scatter_sorted<2>(sa, (long)ns, stream));
+    rc = p == 0 ? launch_scatter_sorted<0, 4, 1>(sa, (long)ns, stream)
+                : (p == 1 ? launch_scatter_sorted<1, 4, 1>(sa, (long)ns, stream) : launch_scatter_sorted<2, 4, 1>(sa, (long)ns, stream));
     if (rc) return rc;
   }
   return 0;
@@ -2555,8 +2643,16 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   D.n = 0;
   if (g_rgb != nullptr) {
     const Geo g = geo_for_units((long)t3);
-    RDRF_LAUNCH("dyn_app_bwd", k_dyn_app_bwd<false>, dim3(g.grid), dim3(g.block), stream, a, w, gw);
-    {
+    const int smode_app = scatter_mode(ns);
+    a.dfa = smode_app != 0 ? b.dfa : nullptr;   // sorted: k_dyn_app_bwd writes sample-major records instead of DA rows
+    if (smode_app != 0) RDRF_LAUNCH("dyn_app_bwd", (k_dyn_app_bwd<false, true>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    else RDRF_LAUNCH("dyn_app_bwd", (k_dyn_app_bwd<false, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
+    if (smode_app != 0) {
+      rdrf_prof_begin("scatter_dyn_app", stream);
+      rc = scatter_dyn_app_sorted(a, b, P, G, stream);
+      rdrf_prof_end("scatter_dyn_app", stream);
+      if (rc) return rc;
+    } else {
       ScatterArgs sa;
       fill_scatter_common(sa, a);
       sa.vm[0] = P->app; sa.gvm[0] = G->app; sa.nsets = 1;
