@@ -28,7 +28,9 @@ def frame(chunk):
         R.render_rays(tr.st, tr.dy, rays_f[c0:c0 + chunk], ts_f[c0:c0 + chunk], N_samples=cfg["n_samples"], ray_type=cfg["ray_type"])
 
 
-for chunk in (H * W, 4096, 512):
+which = [a for a in sys.argv[1:] if not a.startswith("--")]
+chunks = {"whole": (H * W,), "chunk512": (512,)}.get(which[0] if which else "", (H * W, 4096, 512))
+for chunk in chunks:
     frame(chunk)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -38,10 +40,20 @@ for chunk in (H * W, 4096, 512):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"chunk {chunk:6d}: {H * W / dt / 1e6:6.3f} Mpix/s  {dt * 1e3:7.3f} ms/frame")
+if 512 in chunks:   # the native chunk loop (rdrf_render_chunks_fwd), one stream and four
+    for ns in (1, 4):
+        R.render_chunks(tr.st, tr.dy, rays_f, ts_f, 512, N_samples=cfg["n_samples"], ray_type=cfg["ray_type"], streams=ns)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            R.render_chunks(tr.st, tr.dy, rays_f, ts_f, 512, N_samples=cfg["n_samples"], ray_type=cfg["ray_type"], streams=ns)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        print(f"native chunk loop, 512-ray chunks, {ns} stream(s): {H * W / dt / 1e6:6.3f} Mpix/s  {dt * 1e3:7.3f} ms/frame")
 L.lib.rdrf_prof_enable(1)
 L.lib.rdrf_prof_reset()
-frame(H * W)
-frame(512)
+for chunk in chunks:
+    frame(chunk)
 torch.cuda.synchronize()
 for k in ("sample_ndc", "static_density", "static_app", "time_branch", "dyn_density", "dyn_app", "composite", "render_fused"):
     ms, c = C.c_double(), C.c_int()
