@@ -44,11 +44,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak (~6.3 TB/s achievable)
 PEAK_L2_GBS = 34500.0                      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 L2_ATOMIC_REQ_PER_S = 20.8e9               # tools/ubench/atomics.hip: fp32 atomic requests the L2 retires
-PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r03")
+PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r04")
 
 
 def _profile_csv(name):
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
         fn = os.path.join(ROOT, "profiles", f"{tag}_{name}.csv")
         if os.path.exists(fn):
             return fn, tag
@@ -560,6 +560,16 @@ def main():
                    "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if trainer.opt.ex.active else ""),
                    "ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                    "exchange_bytes_per_step": trainer.opt.nbytes_exchanged() if trainer.opt.ex.active else 0,
+                   # what one iteration puts on RCCL (issued only for N > 1): the two flat gradient buffers (static first,
+                   # asynchronously under the dynamic backward), the loss-statistics all-reduces and the per-ray depth gathers
+                   "exchange_plan": {
+                       "mode": trainer.opt.mode, "ranks": world,
+                       "collectives": trainer.opt.ex.plan(["static_field", "dynamic_field"]) + (
+                           [dict(collective="all_reduce", buffer="loss statistics (sum w rho, sum w) per loss group", bytes=2 * 32 * 2 * 4, count=2),
+                            dict(collective="all_gather_into_tensor", buffer="per-ray depth / target / frame / mask of the per-frame depth loss",
+                                 bytes=rpg * world * (4 + 4 + 8 + 1), count=2 if cfg["optimize_poses"] else 1)]
+                           if not args.dp_per_shard_stats else []),
+                       "issued": bool(trainer.opt.ex.active)},
                    "loss_statistics": ("whole batch (all-reduced mask sums, gathered per-frame depth statistics)"
                                        if trainer._dp() is not None else "single process"),
                    "final_loss": loss_val,

@@ -119,6 +119,22 @@ class FlatExchange:
                     raise ValueError(f"flat buffer of {t} floats does not split into {self.world} 16-byte aligned shards")
         self._pending, self._g, self._shards = {}, {}, {}
 
+    def plan(self, names=None):
+        """the collectives one iteration issues on this exchange and what they move: a list of dicts (collective, buffer,
+        bytes = size of the buffer the collective covers, ring_bytes_per_rank = what one rank sends (= receives) over its
+        xGMI links on a ring: (G - 1) / G of the buffer for a reduce-scatter or an all-gather, twice that for an
+        all-reduce).  bench.py prints it so that the first multi-GPU run can be checked against it."""
+        out, G = [], max(self.world, 1)
+        for i, t in enumerate(self.totals):
+            nm = names[i] if names else f"buffer{i}"
+            b = t * 4
+            if self.mode == "zero1":
+                out.append(dict(collective="reduce_scatter_tensor", buffer=nm + ".grad", bytes=b, ring_bytes_per_rank=b * (G - 1) // G))
+                out.append(dict(collective="all_gather_into_tensor", buffer=nm + ".param", bytes=b, ring_bytes_per_rank=b * (G - 1) // G))
+            else:
+                out.append(dict(collective="all_reduce", buffer=nm + ".grad", bytes=b, ring_bytes_per_rank=2 * b * (G - 1) // G))
+        return out
+
     def slice(self, i):
         if self.mode == "zero1":
             n = self.totals[i] // self.world
