@@ -314,6 +314,7 @@ def test_full_size_batch_independence_and_gradient_additivity():
     for k, v in g_full.items():
         s = g_a[k] + g_b[k]
         rel = float((v - s).abs().max() / v.abs().max().clamp_min(1e-30))
+        record_margin(k + " additivity / 2e-4", rel / 2e-4)
         assert rel < 2e-4, (k, rel)
 
 
