@@ -154,7 +154,10 @@ int rdrf_sample_bwd(const float* rays, const float* z, int N, int S, int ray_typ
                     const float* grad_xyz, float* grad_rays, rdrf_stream_t stream);
 
 /* ---- TensorVMSplit.forward (models/tensorBase.py:704-850, models/tensoRF.py:118-196) ---------
- * outputs: rgb[N][S][3], sigma[N][S], weight[N][S], dists[N][S] (= dists*distance_scale). */
+ * outputs: rgb[N][S][3], sigma[N][S], weight[N][S], dists[N][S] (= dists*distance_scale).
+ * rgb may be NULL (rdrf_static_fwd and rdrf_dynamic_fwd): the caller does not consume the colours -- passes B-D of the
+ * trainer discard them (train.py:1166-1246, 1433-1625) -- and the appearance phase (gather, basis, RGB head) is not run;
+ * every other output is unchanged.  A later backward of such a call must not carry a gradient for rgb. */
 int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                     const float* ts, const float* xyz, const float* z, const uint8_t* valid, int N,
                     int S, float* rgb, float* sigma, float* weight, float* dists, void* saved,

@@ -274,11 +274,12 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     if (rc) return rc;
   }
   RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
-  RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
+  if (rgb != nullptr) RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
 #ifdef RDRF_DETERMINISTIC
   RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
 #endif
   RDRF_LAUNCH("static_density", k_static_density<false>, dim3(N), dim3(64), stream, a, w);
+  if (rgb == nullptr) return 0;   // the caller does not consume the colours: the appearance phase is not run
 #ifdef RDRF_DETERMINISTIC
   { int rc_ = rdrf_sort_ints_inplace(a.list, (unsigned)((size_t)N * S), stream); if (rc_) return rc_; }   // append order depends on wave timing
 #endif
@@ -322,7 +323,7 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
     if (rc) return rc;
   }
   RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
-  RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
+  if (rgb != nullptr) RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
   RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout);
   const Geo g1 = geo_for_units(N), g3 = geo_for_tiles(N, S);
 #ifdef RDRF_DETERMINISTIC
@@ -333,6 +334,7 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
 #ifdef RDRF_DETERMINISTIC
   { int rc_ = rdrf_sort_ints_inplace(a.list, (unsigned)((size_t)N * S), stream); if (rc_) return rc_; }
 #endif
+  if (rgb == nullptr) return 0;   // the caller does not consume the colours: the appearance phase is not run
   if (saved != nullptr) RDRF_LAUNCH("dyn_app", (k_dyn_app<false, true>), dim3(g3.grid), dim3(g3.block), stream, a, w);
   else RDRF_LAUNCH("dyn_app", (k_dyn_app<false, false>), dim3(g3.grid), dim3(g3.block), stream, a, w);
   return 0;

@@ -222,7 +222,10 @@ class _StaticFn(torch.autograd.Function):
         rays, ts, xyz, z, valid = _prep_inputs(rays, ts, xyz, z, valid)
         N, S = z.shape
         dev = z.device
-        rgb = torch.empty(N, S, 3, device=dev)
+        # ray_type "ndc" / "contract"; a trailing "-norgb" (forward(..., rgb=False)): the colours are not wanted
+        want_rgb = not ray_type.endswith("-norgb")
+        ray_type = ray_type.replace("-norgb", "")
+        rgb = torch.empty(N, S, 3, device=dev) if want_rgb else None
         sigma = torch.empty(N, S, device=dev)
         weight = torch.empty(N, S, device=dev)
         dists = torch.empty(N, S, device=dev)
@@ -236,13 +239,15 @@ class _StaticFn(torch.autograd.Function):
                                       L.ptr(weight), L.ptr(dists), L.ptr(saved), C.c_size_t(sbytes),
                                       L.ptr(ws), C.c_size_t(ws.numel()), L.stream_of(z)),
                 "rdrf_static_fwd")
-        ctx.field, ctx.ray_type, ctx.saved = field, ray_type, saved
+        ctx.field, ctx.ray_type, ctx.saved, ctx.want_rgb = field, ray_type, saved, want_rgb
         ctx.save_for_backward(rays, ts, xyz, z, valid, *params)
         return rgb, sigma, weight, dists
 
     @staticmethod
     def backward(ctx, g_rgb, g_sigma, g_weight, g_dists):
         rays, ts, xyz, z, valid, *params = ctx.saved_tensors
+        if g_rgb is not None and not ctx.want_rgb:
+            raise L.RdrfError("forward(..., rgb=False) did not run the appearance phase: no gradient can flow through rgb")
         need = ctx.needs_input_grad
         if g_rgb is None and g_sigma is None and g_weight is None and not (need[2] or need[5]):
             # only `dists` is consumed downstream: it depends on z_vals and |d| alone, no parameter
@@ -286,7 +291,9 @@ class _DynamicFn(torch.autograd.Function):
         rays, ts, xyz, z, valid = _prep_inputs(rays, ts, xyz, z, valid)
         N, S = z.shape
         dev = z.device
-        rgb = torch.empty(N, S, 3, device=dev)
+        want_rgb = not ray_type.endswith("-norgb")   # see _StaticFn
+        ray_type = ray_type.replace("-norgb", "")
+        rgb = torch.empty(N, S, 3, device=dev) if want_rgb else None
         xyz_prime = torch.empty(N, S, 3, device=dev)
         sigma, weight, dists, blending = (torch.empty(N, S, device=dev) for _ in range(4))
         saved, sbytes = _alloc_saved(ctx, 1, N, S, dev)
@@ -299,13 +306,15 @@ class _DynamicFn(torch.autograd.Function):
                                        L.ptr(xyz_prime), L.ptr(rgb), L.ptr(sigma), L.ptr(dists),
                                        L.ptr(saved), C.c_size_t(sbytes), L.ptr(ws),
                                        C.c_size_t(ws.numel()), L.stream_of(z)), "rdrf_dynamic_fwd")
-        ctx.field, ctx.ray_type, ctx.saved = field, ray_type, saved
+        ctx.field, ctx.ray_type, ctx.saved, ctx.want_rgb = field, ray_type, saved, want_rgb
         ctx.save_for_backward(rays, ts, xyz, z, valid, *params)
         return blending, weight, xyz_prime, rgb, sigma, dists
 
     @staticmethod
     def backward(ctx, g_blending, g_weight, g_xyz_prime, g_rgb, g_sigma, g_dists):
         rays, ts, xyz, z, valid, *params = ctx.saved_tensors
+        if g_rgb is not None and not ctx.want_rgb:
+            raise L.RdrfError("forward(..., rgb=False) did not run the appearance phase: no gradient can flow through rgb")
         need = ctx.needs_input_grad
         if all(g is None for g in (g_blending, g_weight, g_xyz_prime, g_rgb, g_sigma)) and not (need[2] or need[5]):
             # only `dists` is consumed (pass E of the trainer feeds the dynamic field's dists to the
@@ -843,11 +852,13 @@ class TensorVMSplit(TensorBase):
         return tv_family(self, reg, self.app_plane, self.app_line)
 
     def forward(self, rays_chunk, ts_chunk, timeembeddings_chunk, xyz_sampled, z_vals, ray_valid,
-                white_bg=True, is_train=False, ray_type="ndc", N_samples=-1):
+                white_bg=True, is_train=False, ray_type="ndc", N_samples=-1, rgb=True):
+        """rgb=False (extension): the caller does not consume the colours (entry 6 of the tuple is None) and the
+        appearance phase -- gather, basis, RGB head: ~70 % of this field's forward work -- is not run."""
         if timeembeddings_chunk is not None:
             raise NotImplementedError("timeembeddings_chunk is None at every reference call site")
-        rgb, sigma, weight, dists = _StaticFn.apply(self, ray_type, rays_chunk, ts_chunk, xyz_sampled,
-                                                    z_vals, ray_valid, *self._param_list())
+        rgb, sigma, weight, dists = _StaticFn.apply(self, ray_type if rgb else ray_type + "-norgb", rays_chunk, ts_chunk,
+                                                    xyz_sampled, z_vals, ray_valid, *self._param_list())
         return (None, None, None, xyz_sampled, weight, None, rgb, sigma, z_vals, dists)
 
     @torch.no_grad()
@@ -918,11 +929,13 @@ class TensorVMSplit_TimeEmbedding(TensorBase):
         return t
 
     def forward(self, rays_chunk, ts_chunk, timeembeddings_chunk, xyz_sampled, z_vals, ray_valid,
-                white_bg=True, is_train=False, ray_type="ndc", N_samples=-1):
+                white_bg=True, is_train=False, ray_type="ndc", N_samples=-1, rgb=True):
+        """rgb=False (extension): see TensorVMSplit.forward"""
         if timeembeddings_chunk is not None:
             raise NotImplementedError("timeembeddings_chunk is None at every reference call site")
         blending, weight, xyz_prime, rgb, sigma, dists = _DynamicFn.apply(
-            self, ray_type, rays_chunk, ts_chunk, xyz_sampled, z_vals, ray_valid, *self._param_list())
+            self, ray_type if rgb else ray_type + "-norgb", rays_chunk, ts_chunk, xyz_sampled, z_vals, ray_valid,
+            *self._param_list())
         return (None, None, blending, xyz_sampled, weight, xyz_prime, rgb, sigma, z_vals, dists)
 
     # models/tensoRF.py:378-416 (the reference's dynamic class has no vector_comp_diffs)

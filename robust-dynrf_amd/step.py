@@ -238,23 +238,31 @@ class StepRng:
 PASSES = collections.Counter()
 
 
-def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_grad=False, dynamic=True):
+def _rgb_or_zeros(rgb, like):
+    """the colours of a pass whose field ran with rgb=False: zeros (no map that depends on them is consumed)"""
+    return rgb if rgb is not None else torch.zeros(*like.shape, 3, device=like.device)
+
+
+def ray_pass(st, dy, rays, ts, n_samples, ray_type, rng, is_train=True, static_grad=False, dynamic=True, rgb_s=True,
+             rgb_d=True):
     """sampleXYZ -> static -> dynamic -> raw2outputs (one ray-pass).  The static field runs value-only unless
     `static_grad`; with dynamic=False (dead work of passes E / P3 / P4 skipped) zeros stand in for the dynamic
-    outputs, which the static maps do not depend on."""
+    outputs, which the static maps do not depend on; rgb_s / rgb_d = False: that field's colours are not consumed by
+    any loss of this pass (passes B-D, P1-P4) and its appearance phase is not run."""
     jit, jit_o = rng.jitter(n_samples, ray_type, rays.device) if is_train else (None, None)
     xyz, z, valid = sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=is_train, jitter=jit,
                               jitter_outer=jit_o)
     PASSES.update(static=1, static_grad=int(static_grad), dynamic=int(dynamic), dynamic_dead=int(dynamic and static_grad))
     if static_grad:
-        o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
+        o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type, rgb=rgb_s)
     else:
         with torch.no_grad():
-            o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
-    rgb_s, sigma_s = o_s[6], o_s[7]
+            o_s = st(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type, rgb=rgb_s)
+    sigma_s = o_s[7]
+    rgb_s = _rgb_or_zeros(o_s[6], sigma_s)
     if dynamic:   # in passes E / P3 / P4 this evaluation is dead work the reference performs (autograd graph and all)
-        o_d = dy(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type)
-        rgb_d, sigma_d, dists, blending, zv = o_d[6], o_d[7], o_d[9], o_d[2], o_d[8]
+        o_d = dy(rays, ts, None, xyz, z, valid, is_train=is_train, ray_type=ray_type, rgb=rgb_d)
+        rgb_d, sigma_d, dists, blending, zv = _rgb_or_zeros(o_d[6], o_d[7]), o_d[7], o_d[9], o_d[2], o_d[8]
     else:
         o_d = None
         rgb_d = torch.zeros_like(rgb_s)
@@ -281,30 +289,31 @@ def batch_groups(idxs, n_samples_per_pass):
     return [idxs[i:i + per] for i in range(0, len(idxs), per)]
 
 
-def batched_field(field, rays_list, ts_list, samples, idxs, ray_type, grad=True):
+def batched_field(field, rays_list, ts_list, samples, idxs, ray_type, grad=True, rgb=True):
     """`field` over the concatenated rays / samples of the passes `idxs` in ONE call; returns the 10-tuple of each pass
     (views of the batched outputs: unbind, whose backward stacks the per-pass gradients)"""
     if len(idxs) == 1:
         k = idxs[0]
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
-            return [field(rays_list[k], ts_list[k], None, *samples[k], is_train=True, ray_type=ray_type)]
+            return [field(rays_list[k], ts_list[k], None, *samples[k], is_train=True, ray_type=ray_type, rgb=rgb)]
     N = rays_list[idxs[0]].shape[0]
     cat = lambda ts: torch.cat([ts[k] for k in idxs])
     with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
         o = field(cat(rays_list), cat(ts_list), None, *(torch.cat([samples[k][i] for k in idxs]) for i in range(3)),
-                  is_train=True, ray_type=ray_type)
+                  is_train=True, ray_type=ray_type, rgb=rgb)
     parts = [None if t is None else t.view(len(idxs), N, *t.shape[1:]).unbind(0) for t in o]
     return [tuple(None if pt is None else pt[j] for pt in parts) for j in range(len(idxs))]
 
 
-def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
+def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups, rgb=None):
     """Several ray-passes whose inputs do not depend on each other's outputs (passes A-D of an iteration: the rays of
     C / D come from the data's optical flow, not from pass A), evaluated as ONE value-only static forward over all their
     rays and one dynamic forward per GROUP of passes (lists of consecutive pass indices with the same gradient
     liveness, so that a batched call prunes what each of its passes would).  Same arithmetic and the same draw order
     (jitter, coin per pass, in pass order) as one ray_pass per entry; the persistent MLP kernels see 3-4x the tiles per
     launch (tail quantisation: 2.4 -> 3 tile rounds per wave becomes 7.3 -> 8) and fill their LDS images once.
-    Calls are capped at BATCH_MAX_SAMPLES samples.
+    Calls are capped at BATCH_MAX_SAMPLES samples.  rgb (list of bool per pass, default all True): passes whose colours no
+    loss consumes run both fields without their appearance phase (the static call is then cut at the flag changes).
     Returns one (o_s, o_d, outs, xyz) per pass; the per-pass tensors are views (unbind) of the batched outputs."""
     P, N, dev = len(rays_list), rays_list[0].shape[0], rays_list[0].device
     PASSES.update(static=P, dynamic=P)
@@ -314,19 +323,28 @@ def ray_passes(st, dy, rays_list, ts_list, n_samples, ray_type, rng, groups):
         samples.append(sampleXYZ(dy, rays, n_samples, ray_type=ray_type, is_train=True, jitter=jit, jitter_outer=jit_o))
         coins.append(rng.coin())
     ns = N * samples[0][1].shape[1]
+    rgb = [True] * P if rgb is None else list(rgb)
     o_ss, o_ds = [None] * P, [None] * P
-    for g in batch_groups(range(P), ns):
-        for k, o in zip(g, batched_field(st, rays_list, ts_list, samples, g, ray_type, grad=False)):
-            o_ss[k] = o
+    runs, lo = [], 0   # maximal runs of passes with the same colour flag: one static call each
+    for p in range(1, P + 1):
+        if p == P or rgb[p] != rgb[lo]:
+            runs.append(list(range(lo, p)))
+            lo = p
+    for run in runs:
+        for g in batch_groups(run, ns):
+            for k, o in zip(g, batched_field(st, rays_list, ts_list, samples, g, ray_type, grad=False, rgb=rgb[run[0]])):
+                o_ss[k] = o
     for group in groups:
         assert list(group) == list(range(group[0], group[0] + len(group)))
+        assert all(rgb[k] == rgb[group[0]] for k in group), "a dynamic group must agree on its colour flag"
         for g in batch_groups(group, ns):
-            for k, o in zip(g, batched_field(dy, rays_list, ts_list, samples, g, ray_type)):
+            for k, o in zip(g, batched_field(dy, rays_list, ts_list, samples, g, ray_type, rgb=rgb[group[0]])):
                 o_ds[k] = o
     out = []
     for p in range(P):
         o_sp, o_d = o_ss[p], o_ds[p]
-        outs = raw2outputs(o_sp[6], o_sp[7], o_d[6], o_d[7], o_d[9], o_d[2], o_d[8], rays_list[p], is_train=True,
+        outs = raw2outputs(_rgb_or_zeros(o_sp[6], o_sp[7]), o_sp[7], _rgb_or_zeros(o_d[6], o_d[7]), o_d[7], o_d[9], o_d[2],
+                           o_d[8], rays_list[p], is_train=True,
                            ray_type=ray_type, add_white_bg=coins[p])
         out.append((o_sp, o_d, outs, samples[p][0]))
     return out
@@ -339,8 +357,9 @@ def masked_mean(x, m):
 class Trainer:
     def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False,
                  dp_mode="allreduce", lr_pose=3e-3, dp_exact_stats=False, batch_passes=None):
-        """dead_work: also run the dynamic-field forward of passes E / P3 / P4, which the reference computes
-        although nothing consumes it (SURVEY.md 3.1 liveness table); off = skipped, results identical.
+        """dead_work: also run what the reference computes although nothing consumes it (SURVEY.md 3.1 liveness table):
+        the dynamic-field forward of passes E / P3 / P4, and the appearance phase (colours) of both fields in passes B-D
+        and P1-P4, whose rgb maps no loss term reads; off = skipped, losses and gradients identical.
         dp_exact_stats (data-parallel runs): the batch statistics of the losses -- the mask sums of the masked means
         (train.py:1391-1394, 1522-1524, 1828-1832, 1277-1291) and the per-frame medians / deviations / ray counts of
         the monocular depth losses (train.py:797-807) -- are those of the WHOLE batch (one all-reduce of ~30 pairs of
@@ -474,8 +493,11 @@ class Trainer:
             # groups of equal gradient liveness: A (everything live) | B, C, D (no appearance gradient; before
             # upsamp_list[3] no blending gradient either -- later only B has the dynamicness terms)
             groups = [[0], [1, 2, 3]] if not late else [[0], [1], [2, 3]]
+            # passes B-D read depths, weights and the dynamicness only (train.py:1248-1312, 1515-1524): their colours are
+            # dead work the reference computes (self.dead_work keeps it)
             pA, pB, pC, pD = ray_passes(self.st, self.dy, [rays_d, rays_d, rays_n_of[1], rays_n_of[-1]],
-                                        [ts, b["ts_rand"], ts + dt, ts - dt], S, rt, rng, groups)
+                                        [ts, b["ts_rand"], ts + dt, ts - dt], S, rt, rng, groups,
+                                        rgb=[True] + [self.dead_work] * 3)
             osA, oA, outA, xyzA = pA
             batched = {"B": pB, 1: pC, -1: pD}
         else:
@@ -505,7 +527,8 @@ class Trainer:
         if w_dist > 0:   # mean over the rays of the per-ray loss (eff_distloss), weighted
             Ld.add(w_dist, "identity", distloss_rays(outA[11], oA[8].detach(), 1.0 / S))
         # ---- pass B (second random time)
-        _, oB, outB, _ = batched["B"] if batched else ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng)
+        _, oB, outB, _ = batched["B"] if batched else ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng,
+                                                               rgb_s=self.dead_work, rgb_d=self.dead_work)
         if late:
             Ld.add(0.01, "identity", skewed(outB[12]))                                  # :1248-1266
             Ld.add(0.01, "abs", outB[12])                                               # novel_view_time_mask_loss, :1267
@@ -534,7 +557,8 @@ class Trainer:
                 _, oN, outN, _ = batched[sgn]
             else:
                 rays_n = self.rays_for(ids, poses_d, focal_d, uv=grid + flow_t, view_shift=sgn)
-                _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts + sgn * dt, S, rt, rng)
+                _, oN, outN, _ = ray_pass(self.st, self.dy, rays_n, ts + sgn * dt, S, rt, rng, rgb_s=self.dead_work,
+                                          rgb_d=self.dead_work)
             _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], px, rays_n, ray_type=rt)
             Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
             if w_dist > 0:
@@ -588,8 +612,8 @@ class Trainer:
             ns = rays.shape[0] * smp[0][1].shape[1]
             o_P = [None] * 4
             for g in batch_groups(range(4), ns):
-                for k, o in zip(g, batched_field(self.st, rays_P, ts_P, smp, g, rt)):
-                    o_P[k] = o
+                for k, o in zip(g, batched_field(self.st, rays_P, ts_P, smp, g, rt, rgb=self.dead_work)):
+                    o_P[k] = o   # (P1-P4 read weights / depths only: train.py:1951-2311)
             d_P = [None, None]
             if self.dead_work:   # the dynamic forwards of P3 / P4: dead work the reference performs
                 PASSES.update(dynamic=2, dynamic_dead=2)
@@ -610,7 +634,7 @@ class Trainer:
                 jit, jit_o = rng.jitter(S, rt, rays.device)
                 xyz, z, valid = sampleXYZ(self.st, rays_n, S, ray_type=rt, is_train=True, jitter=jit, jitter_outer=jit_o)
                 PASSES.update(static=1, static_grad=1)
-                o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
+                o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt, rgb=self.dead_work)
             _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], xyz, px, rays_n, ray_type=rt)
             Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
@@ -623,13 +647,15 @@ class Trainer:
                 rays_n, o_s, o_d, z = batched[0][2 + k], batched[3][2 + k], batched[4][k], batched[1][2 + k][1]
                 if o_d is None:
                     zero = torch.zeros_like(o_s[7])
-                    dyn = (torch.zeros_like(o_s[6]), zero, o_s[9], zero, z)
+                    dyn = (_rgb_or_zeros(None, zero), zero, o_s[9], zero, z)
                 else:
-                    dyn = (o_d[6], o_d[7], o_d[9], o_d[2], o_d[8])
-                outN = raw2outputs(o_s[6], o_s[7], *dyn, rays_n, is_train=True, ray_type=rt, add_white_bg=batched[2][2 + k])
+                    dyn = (_rgb_or_zeros(o_d[6], o_d[7]), o_d[7], o_d[9], o_d[2], o_d[8])
+                outN = raw2outputs(_rgb_or_zeros(o_s[6], o_s[7]), o_s[7], *dyn, rays_n, is_train=True, ray_type=rt,
+                                   add_white_bg=batched[2][2 + k])
             else:
                 rays_n = self.rays_for(ids, poses, focal, uv=uv_n)
-                _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
+                _, _, outN, _ = ray_pass(self.st, self.dy, rays_n, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work,
+                                         rgb_s=self.dead_work)
             Ls.add(50.0 * temp_disp_tv, "square", inv_d, 1.0 / torch.clamp(outN[5], min=1e-6))  # :2293-2305
 
     def step(self, shard=None):

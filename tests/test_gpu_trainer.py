@@ -539,3 +539,30 @@ def test_trainer_step_matches_reference_trainer_iteration(name):
         check("fov", tr.fov.grad, torch.from_numpy(p["g.fov"]), g32["fov"], g64["fov"],
               max(float(np.abs(p["g.fov"]).max()), 1e-2 * ps), 1e-4)
     assert n > 60 and not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name,batched", [("nvidia", True), ("nvidia", False), ("nvidia_no_poses", True), ("davis", True)])
+def test_dead_work_pruning_changes_nothing(name, batched):
+    """Trainer(dead_work=False) (the default) skips what the reference computes and nothing consumes -- the dynamic forward
+    of passes E / P3 / P4 and the appearance phase (colours) of both fields in passes B-D and P1-P4 (forward(rgb=False)) --
+    against dead_work=True: the same draws, the same loss values, the same gradients (up to the order of the atomic
+    accumulation) for both fields, the pose table and the field of view."""
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    cfg = S_.scene_config(name, "stage0")
+    cfg.update(SMALL[name])
+    cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * 3.0 ** 0.5
+    dev = torch.device("cuda", 0)
+    got = {}
+    for dead in (True, False):
+        tr = S_.Trainer(dict(cfg), dev, dead_work=dead, batch_passes=batched)
+        tr.it = 30000   # every gate open, ramped weights non-zero
+        tr.step()
+        got[dead] = ([v.detach().clone() for v in tr.last.values()], [g.detach().clone() for g in tr.grad_flats],
+                     [tr.poses.grad.clone(), tr.fov.grad.clone()] if tr.optimize_poses else [])
+    for a, b in zip(got[True][0], got[False][0]):
+        assert_close(a, b, "loss", rtol=1e-6)
+    for a, b in zip(got[True][1] + got[True][2], got[False][1] + got[False][2]):
+        assert float(a.abs().max()) > 0
+        rel = float((a - b).norm() / a.norm())
+        record_margin("pruned vs executed dead work (rel. L2 / 1e-5)", rel / 1e-5)
+        assert rel < 1e-5, rel
