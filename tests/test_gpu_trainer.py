@@ -461,8 +461,8 @@ def test_batched_passes_match_one_pass_per_launch(name, stage, it, monkeypatch):
     for a, b_ in zip(got[True][2], got[False][2]):
         assert float(b_.abs().max()) > 0
         rel = float((a - b_).norm() / b_.norm())
-        record_margin("batched vs per-pass gradient (rel. L2 / 1e-5)", rel / 1e-5)
-        assert rel < 1e-5, rel
+        record_margin("batched vs per-pass gradient (rel. L2 / 2e-5)", rel / 2e-5)
+        assert rel < 2e-5, rel   # (order of the atomic accumulation; measured up to 0.94e-5 on the contracted-ray config)
         assert_close(a, b_, "batched vs per-pass gradient", rtol=2e-5)
 
 
