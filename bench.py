@@ -493,8 +493,9 @@ def main():
     ap.add_argument("--no-cpu-4096", action="store_true", help="skip the single 4096-ray CPU step (about one minute)")
     ap.add_argument("--render-chunk", type=int, default=0, help="rays per render call (default: a whole frame)")
     ap.add_argument("--exploit-liveness", action="store_true",
-                    help="skip the dynamic-field forward of passes E / P3 / P4, dead work the reference computes "
-                         "(SURVEY 3.1 liveness table); by default it is executed like the reference does")
+                    help="skip the work whose results nothing consumes (SURVEY 3.1 liveness table): the dynamic-field forward of "
+                         "passes E / P3 / P4 and the colours of both fields in passes B-D / P1-P4; by default it is executed like "
+                         "the reference does")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -578,8 +579,8 @@ def main():
                        "last": {"static": frs["end"][1], "dynamic": frs["end"][2]},
                        "note": "the appearance kernels' work follows these; they fall as the reference-initialised weights "
                                "train, so a 20-step window right after start-up times a heavier step than a 200-step one"},
-                   "dead_dynamic_forwards": "skipped (dead work, SURVEY 3.1)" if args.exploit_liveness
-                   else "executed (dead work the reference also computes)"},
+                   "dead_work": "skipped (SURVEY 3.1: pass E's dynamic forward, the colours of passes B-D)" if args.exploit_liveness
+                   else "executed (work the reference also computes although nothing consumes it)"},
     }
 
     if not args.exploit_liveness:
@@ -587,7 +588,10 @@ def main():
         trainer.dead_work = False
         dt2, _ = timed_steps(trainer, shard, max(10, args.steps // 4), 2, world, dev)
         out["liveness_exploited"] = {"value": cfg["batch_size"] / dt2, "unit": "rays/s", "ms_per_step": dt2 * 1e3,
-                                     "note": "dead dynamic forwards skipped (SURVEY 3.1: nothing consumes them)"}
+                                     "note": "the same iterations without the work whose results nothing consumes (SURVEY 3.1): the "
+                                             "dynamic forwards of pass E (P3 / P4) and the appearance phase (colours) of both fields in "
+                                             "passes B-D (P1-P4) -- Trainer(dead_work=False), forward(rgb=False); losses and gradients "
+                                             "identical (tests/test_gpu_trainer.py::test_dead_work_pruning_changes_nothing)"}
         trainer.dead_work = True
     if rf is not None and rank == 0:
         out["roofline"] = price_step(rf, ms, rpg)
