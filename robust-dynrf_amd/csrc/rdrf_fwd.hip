@@ -15,7 +15,7 @@
 // per-phase kernels: thin wrappers over the bodies of rdrf_fwd_dev.hpp
 // ------------------------------------------------------------------------------------------------
 template <bool FEAT>
-__global__ __launch_bounds__(64) void k_static_density(FieldArgs a, StaticW w) { static_density_body<FEAT>(a, w, grid_ctx()); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_static_density(FieldArgs a, StaticW w) { static_density_body<FEAT>(a, w, grid_ctx()); }
 
 template <int HEAD, bool FEAT, bool SAVE = true>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, StaticW w) {
@@ -32,11 +32,19 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app(FieldArgs a, DynW w)
   dyn_app_body<FEAT, SAVE>(a, w, nullptr, grid_ctx());
 }
 
+// `zero64`: 64 ints cleared on the way (the append counter of the density phase that follows on the same stream)
 __global__ __launch_bounds__(256) void k_time_branch(const float* __restrict__ ts, DynW w, int N,
-                                                     float* __restrict__ tout) {
+                                                     float* __restrict__ tout, int* __restrict__ zero64) {
   __shared__ float s_h[8 * 64];
+  if (zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0;
   time_branch_body(ts, w, N, tout, s_h, grid_ctx());
 }
+
+// inference: the density phase of the dynamic field at tile granularity + the per-ray scan (rdrf_fwd_dev.hpp)
+__global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_flat(FieldArgs a, DynW w) {
+  dyn_density_body<false, false, false, true>(a, w, nullptr, grid_ctx());
+}
+__global__ __launch_bounds__(512) void k_ray_scan(FieldArgs a) { ray_scan_body(a); }   // 16 rays per workgroup
 
 // ------------------------------------------------------------------------------------------------
 // scene flow MLP over all N*S samples (models/tensoRF.py:446-462)
@@ -273,12 +281,11 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     rc = pack_launch(J, (float*)a.pk, stream);
     if (rc) return rc;
   }
-  RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
-  if (rgb != nullptr) RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
+  RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));   // (the colours are zero-filled by k_static_density)
 #ifdef RDRF_DETERMINISTIC
   RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
 #endif
-  RDRF_LAUNCH("static_density", k_static_density<false>, dim3(N), dim3(64), stream, a, w);
+  RDRF_LAUNCH("static_density", k_static_density<false>, dim3((N + 3) / 4), dim3(256), stream, a, w);   // 4 rays per workgroup: one list append
   if (rgb == nullptr) return 0;   // the caller does not consume the colours: the appearance phase is not run
 #ifdef RDRF_DETERMINISTIC
   { int rc_ = rdrf_sort_ints_inplace(a.list, (unsigned)((size_t)N * S), stream); if (rc_) return rc_; }   // append order depends on wave timing
@@ -322,15 +329,22 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
     rc = pack_launch(J, (float*)a.pk, stream);
     if (rc) return rc;
   }
-  RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));
-  if (rgb != nullptr) RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));
-  RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout);
+  // inference calls run the density phase at tile granularity (k_dyn_density_flat + k_ray_scan): a 512-ray eval chunk
+  // fills the chip and no tile is padded to the end of its ray; training keeps the wave-per-ray kernel, whose saved rows
+  // the backward kernels address by (ray, tile)
+  static const int flat_env = RDRF_ENV("RDRF_FLAT") ? atoi(RDRF_ENV("RDRF_FLAT")) : 1;   // 0: wave per ray (tools build)
+  const bool flat = saved == nullptr && flat_env != 0;
+  if (!flat && rgb != nullptr) RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));   // flat: k_ray_scan
+  RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout, a.counter);
   const Geo g1 = geo_for_units(N), g3 = geo_for_tiles(N, S);
 #ifdef RDRF_DETERMINISTIC
   RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
 #endif
   if (saved != nullptr) RDRF_LAUNCH("dyn_density", (k_dyn_density<false, true>), dim3(g1.grid), dim3(g1.block), stream, a, w);
-  else RDRF_LAUNCH("dyn_density", (k_dyn_density<false, false>), dim3(g1.grid), dim3(g1.block), stream, a, w);
+  else if (flat) {
+    RDRF_LAUNCH("dyn_density", k_dyn_density_flat, dim3(g3.grid), dim3(g3.block), stream, a, w);
+    RDRF_LAUNCH("ray_scan", k_ray_scan, dim3((N + 15) / 16), dim3(512), stream, a);
+  } else RDRF_LAUNCH("dyn_density", (k_dyn_density<false, false>), dim3(g1.grid), dim3(g1.block), stream, a, w);
 #ifdef RDRF_DETERMINISTIC
   { int rc_ = rdrf_sort_ints_inplace(a.list, (unsigned)((size_t)N * S), stream); if (rc_) return rc_; }
 #endif
@@ -428,7 +442,7 @@ extern "C" int rdrf_dynamic_features_fwd(const RdrfDynamicParams* P, const RdrfF
     rc = pack_launch(J, (float*)a.pk, stream);
     if (rc) return rc;
   }
-  RDRF_LAUNCH("time_branch", k_time_branch, dim3((M + 7) / 8), dim3(256), stream, t, w, M, a.tout);
+  RDRF_LAUNCH("time_branch", k_time_branch, dim3((M + 7) / 8), dim3(256), stream, t, w, M, a.tout, (int*)nullptr);
   const Geo g = geo_for_units(Np);
   RDRF_LAUNCH("feat_dyn_density", k_dyn_density<true>, dim3(g.grid), dim3(g.block), stream, a, w);
   if (app != nullptr) RDRF_LAUNCH("feat_dyn_app", k_dyn_app<true>, dim3(g.grid), dim3(g.block), stream, a, w);

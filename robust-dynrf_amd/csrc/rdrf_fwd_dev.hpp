@@ -16,20 +16,57 @@ RDRF_D GridCtx grid_ctx() { return GridCtx{(int)blockIdx.x, (int)gridDim.x, (int
 #define GC_TID (FUSED ? gc.tid : (int)threadIdx.x)
 #define GC_NTHR (FUSED ? gc.nthr : (int)blockDim.x)
 
+// App-mask compaction (models/tensorBase.py:773-790): the masked samples are appended to one list through one counter -- an
+// atomic with return on ONE address for the whole chip (~3.6 ns each, serialised at the memory side: 65 k appends of a
+// 32 400-ray frame are 0.23 ms during which every appending wave waits).  So the density kernels count first, append once
+// per workgroup (here) or per ray (dyn_density_body), and write their entries in a second sweep over the stored weights.
+// cnt is wave-uniform; returns the wave's base in the list.  All threads of the workgroup must call it.
+RDRF_D int block_append_base(int* counter, int cnt, int* s_cnt, int tid, int nthr) {   // cnt: wave-uniform; returns the wave's base
+  const int wave = tid >> 6, nwaves = nthr >> 6;
+  __syncthreads();   // s_cnt may still be read by the previous use
+  if ((tid & 63) == 0) s_cnt[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      const int c = s_cnt[w];
+      s_cnt[w] = tot;
+      tot += c;
+    }
+    const int b = tot ? atomicAdd(counter, tot) : 0;
+    for (int w = 0; w < nwaves; ++w) s_cnt[w] += b;
+  }
+  __syncthreads();
+  return s_cnt[wave];
+}
+
 template <bool FEAT, bool FUSED = false>
 RDRF_D void static_density_body(const FieldArgs a, const StaticW w, const GridCtx gc) {
+  __shared__ int s_cnt[16];
   const int lane = GC_TID & 63;
   const int wave_ = GC_TID >> 6, nwaves_ = GC_NTHR >> 6;
-  for (int n = GC_BID * nwaves_ + wave_; n < a.N; n += GC_NBLK * nwaves_) {
+  for (int nb = GC_BID * nwaves_; nb < a.N; nb += GC_NBLK * nwaves_) {   // uniform over the workgroup (block_append_base syncs)
+  const bool ray = nb + wave_ < a.N;
+  const int n = ray ? nb + wave_ : 0;
   float vx, vy, vz;
   float nrm = 1.0f;
   if constexpr (!FEAT) nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
   float carry = 1.0f;
+  int cnt = 0;   // app-masked samples of the ray (wave-uniform)
   for (int j0 = 0; j0 < a.S; j0 += 64) {
     const int j = j0 + lane;
-    const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
+    const bool act = ray && j < a.S && (!FEAT || n * a.S + j < a.M);
     const int idx = n * a.S + (act ? j : 0);
     const bool vld = act && (FEAT || a.valid[idx] != 0);
+    if constexpr (!FEAT) {
+      if (ray && a.rgb != nullptr) {   // the appearance phase writes the masked samples only: zero the round's colours (coalesced)
+        float* r = a.rgb + ((size_t)n * a.S + j0) * 3 + lane;
+        const int lim = (a.S - j0 < 64 ? a.S - j0 : 64) * 3;
+        if (lane < lim) r[0] = 0.f;
+        if (lane + 64 < lim) r[64] = 0.f;
+        if (lane + 128 < lim) r[128] = 0.f;
+      }
+    }
     float f = 0.0f;
     if (vld) {
       float x0, x1, x2;
@@ -72,18 +109,25 @@ RDRF_D void static_density_body(const FieldArgs a, const StaticW w, const GridCt
       const float T = carry * excl;
       const float wt = alpha * T;
       carry *= __shfl(incl, 63, 64);
-      const bool m = act && wt > a.weight_thres;
       if (act) {
         a.sigma[idx] = sigma;
         a.weight[idx] = wt;
         a.dists[idx] = ds;
       }
-      const unsigned long long bal = __ballot(m);
-      if (bal) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
-        base = __shfl(base, 0, 64);
+      cnt += __popcll(__ballot(act && wt > a.weight_thres));
+    }
+  }
+  if constexpr (!FEAT) {
+    int base = block_append_base(a.counter, cnt, s_cnt, GC_TID, GC_NTHR);
+    if (cnt) {
+      for (int j0 = 0; j0 < a.S; j0 += 64) {
+        const int j = j0 + lane;
+        const bool act = ray && j < a.S;
+        const int idx = n * a.S + (act ? j : 0);
+        const bool m = act && a.weight[idx] > a.weight_thres;   // the lane's own store above
+        const unsigned long long bal = __ballot(m);
         if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
+        base += __popcll(bal);
       }
     }
   }
@@ -195,8 +239,14 @@ RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused
   }
 }
 
-template <bool FEAT, bool SAVE = true, bool FUSED = false>
+// FLAT (inference only): the unit of work is a 32-sample tile of the flattened [N * S] sample array instead of a ray, so a
+// 512-ray eval chunk is 1840 tiles for the 2048 resident waves instead of 512 rays, and no tile is padded to the ray's
+// end (S = 115: 3.6 tiles per ray instead of 4).  The per-ray constants (time, tout, PE8(t)) are fetched per lane through
+// the sample's ray index; sigma and blending are written per sample and the transmittance scan / app-mask compaction run
+// afterwards in ray_scan_body (same arithmetic in the same order: results are bit-identical to the wave-per-ray form).
+template <bool FEAT, bool SAVE = true, bool FUSED = false, bool FLAT = false>
 RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, const GridCtx gc) {
+  static_assert(!FLAT || (!FEAT && !SAVE && !FUSED), "the flat-tile form is the inference kernel");
   float* lds;
   if constexpr (FUSED) lds = lds_fused;
   else {   // the standalone kernel owns its image as a named LDS array (constant addresses in every ds_read)
@@ -207,11 +257,12 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
   const int lane = GC_TID & 63, h = lane >> 5, s = lane & 31;
   const int wave = GC_TID >> 6, nwaves = GC_NTHR >> 6;
   const float* pkw = lds;
-  for (int n = GC_BID * nwaves + wave; n < a.N; n += GC_NBLK * nwaves) {
+  const int nunits = FLAT ? (int)(((long)a.N * a.S + 31) >> 5) : a.N;
+  for (int n = GC_BID * nwaves + wave; n < nunits; n += GC_NBLK * nwaves) {
   float t = 0.f, nrm = 1.0f;
   float T[16];
   float X1[8];
-  if constexpr (!FEAT) {   // time is per ray: tout / PE8(t) are per-ray constants
+  if constexpr (!FEAT && !FLAT) {   // time is per ray: tout / PE8(t) are per-ray constants
     t = a.ts[n];
     float vx, vy, vz;
     nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
@@ -223,16 +274,26 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
     fill_x1(X1, t, h);
   }
   float carry = 1.0f;
-  for (int j0 = 0; j0 < a.S; j0 += 32) {
+  int nmask = 0;   // app-masked samples of the ray (wave-uniform)
+  for (int j0 = 0; j0 < (FLAT ? 32 : a.S); j0 += 32) {
     const int j = j0 + s;
-    const bool act = j < a.S && (!FEAT || n * a.S + j < a.M);
-    const int idx = n * a.S + (act ? j : 0);
+    bool act;
+    int idx;
+    if constexpr (FLAT) {   // n = tile of the flattened sample array
+      const long i = (long)n * 32 + s;
+      act = i < (long)a.N * a.S;
+      idx = act ? (int)i : 0;
+    } else {
+      act = j < a.S && (!FEAT || n * a.S + j < a.M);
+      idx = n * a.S + (act ? j : 0);
+    }
     const bool vld = act && (FEAT || a.valid[idx] != 0);
-    if constexpr (FEAT) {  // time is per point
-      t = a.ts[idx];
+    if constexpr (FEAT || FLAT) {  // time is per point (FEAT) / looked up through the sample's ray (FLAT)
+      const int ti = FLAT ? idx / a.S : idx;
+      t = a.ts[ti];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 v = ld4(a.tout + (size_t)idx * 32 + 8 * q + 4 * h);
+        f32x4 v = ld4(a.tout + (size_t)ti * 32 + 8 * q + 4 * h);
         T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
       }
       fill_x1(X1, t, h);
@@ -328,6 +389,11 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
         if (a.blending != nullptr) a.blending[idx] = fb;
         if (a.raw != nullptr) { a.raw[(size_t)idx * 2] = fd; a.raw[(size_t)idx * 2 + 1] = fb; }
       }
+    } else if constexpr (FLAT) {   // the scan and the compaction follow in ray_scan_body
+      if (act && h == 0) {
+        a.sigma[idx] = vld ? density_act(fd, a.act, a.density_shift) : 0.0f;
+        a.blending[idx] = vld ? sigmoidf_(fb) : 0.0f;
+      }
     } else {
     const float sigma = vld ? density_act(fd, a.act, a.density_shift) : 0.0f;
     const float blend = vld ? sigmoidf_(fb) : 0.0f;
@@ -350,16 +416,87 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
       a.blending[idx] = blend;
       if (SAVE && a.raw != nullptr) { a.raw[(size_t)idx * 2] = fd; a.raw[(size_t)idx * 2 + 1] = fb; }
     }
-    const unsigned long long bal = __ballot(m);
-    if (bal) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(a.counter, __popcll(bal));
-      base = __shfl(base, 0, 64);
-      if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
+    nmask += __popcll(__ballot(m));
     }
+  }
+  if constexpr (!FEAT && !FLAT) {
+    // app-mask compaction (models/tensorBase.py:773-790), ONE append per ray: every append is an atomic with return on the
+    // same address for the whole chip (~3.6 ns each, serialised at the memory side), so the ray's tiles count first and
+    // the entries are written in a second sweep over the weights just stored (same lane, program order)
+    if (nmask) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.counter, nmask);
+      base = __shfl(base, 0, 64);
+      for (int j0 = 0; j0 < a.S; j0 += 32) {
+        const int j = j0 + s;
+        const bool act = j < a.S && h == 0;
+        const int idx = n * a.S + (act ? j : 0);
+        const bool m = act && a.weight[idx] > a.weight_thres;
+        const unsigned long long bal = __ballot(m);
+        if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
+        base += __popcll(bal);
+      }
     }
   }
   }  // ray loop
+}
+
+// The per-ray half of the density phase for the flat-tile form: sigma -> alpha -> transmittance scan -> weight, dists, the
+// app-mask compaction (models/tensorBase.py:773-790) and the zero fill of the colours the appearance phase will not write.
+// A half-wave per ray (two rays per wave), 32 samples per round with the carry across rounds -- the expressions and the
+// order of the multiplications are those of dyn_density_body, so weight / dists / the mask come out bit-identical.
+// The compaction appends ONCE per workgroup (block_append_base).
+RDRF_D void ray_scan_body(const FieldArgs a) {
+  __shared__ int s_cnt[16];
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
+  const int n_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + h;
+  const bool ray = n_ < a.N;
+  const int n = ray ? n_ : 0;
+  float vx, vy, vz;
+  const float nrm = ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+  float carry = 1.0f;
+  int cnt = 0;
+  for (int j0 = 0; j0 < a.S; j0 += 32) {
+    const int j = j0 + s;
+    const bool act = ray && j < a.S;
+    const int idx = n * a.S + (act ? j : 0);
+    const float sigma = act ? a.sigma[idx] : 0.0f;
+    const float zj = act ? a.z[idx] : 0.f;
+    const float zn = (j + 1 < a.S) ? a.z[idx + 1] : zj;
+    const float ds = ((j + 1 < a.S) ? (zn - zj) : 0.0f) * nrm * a.distance_scale;
+    const float alpha = 1.0f - expf(-sigma * ds);
+    const float p = act ? one_minus_alpha_eps(alpha) : 1.0f;
+    const float incl = scan_mul32(p, s);
+    float excl = __shfl_up(incl, 1, 32);
+    if (s == 0) excl = 1.0f;
+    const float Tr = carry * excl;
+    const float wt = alpha * Tr;
+    carry *= __shfl(incl, 31, 32);
+    if (act) {
+      a.weight[idx] = wt;
+      a.dists[idx] = ds;
+    }
+    if (ray && a.rgb != nullptr) {   // zero the round's colours (coalesced; the appearance phase writes the masked samples)
+      float* r = a.rgb + ((size_t)n * a.S + j0) * 3 + s;
+      const int lim = (a.S - j0 < 32 ? a.S - j0 : 32) * 3;
+      if (s < lim) r[0] = 0.f;
+      if (s + 32 < lim) r[32] = 0.f;
+      if (s + 64 < lim) r[64] = 0.f;
+    }
+    cnt += __popcll(__ballot(act && wt > a.weight_thres));
+  }
+  int base = block_append_base(a.counter, cnt, s_cnt, threadIdx.x, blockDim.x);
+  if (cnt) {
+    for (int j0 = 0; j0 < a.S; j0 += 32) {
+      const int j = j0 + s;
+      const bool act = ray && j < a.S;
+      const int idx = n * a.S + (act ? j : 0);
+      const bool m = act && a.weight[idx] > a.weight_thres;   // the lane's own store above
+      const unsigned long long bal = __ballot(m);
+      if (m) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = idx;   // rank among the set lanes below
+      base += __popcll(bal);
+    }
+  }
 }
 
 template <bool FEAT, bool SAVE = true, bool FUSED = false>

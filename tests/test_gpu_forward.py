@@ -187,6 +187,32 @@ def test_fused_render_is_bit_identical_to_the_launch_sequence(case, N, S):
         assert_close(b[1], g["ce.depth_map_full"], "fused depth", atol=256.0 * 2.0 ** -22 if rt == "contract" else 0.0)
 
 
+@pytest.mark.parametrize("case,N,S", [("ndc_relu", 7, 13), ("ndc_relu", 513, 115), ("contract_relu_te", 300, 37), ("ndc_relu", 2100, 33)])
+def test_inference_forward_is_bit_identical_to_the_training_forward(case, N, S):
+    """Inference calls (no saved activations) run the dynamic field's density phase at tile granularity --
+    k_dyn_density_flat over 32-sample tiles of the flattened [N * S] array + k_ray_scan -- and let the density kernels
+    zero-fill the colours; training calls run the wave-per-ray kernel that also saves its activations.  Same arithmetic
+    in the same order: every output of both fields (TensorBase.forward, models/tensorBase.py:704-850) has the same bits,
+    for tiles that straddle rays (S not a multiple of 32), a last partial tile, and a batch smaller than one wave's share."""
+    import rodynrf
+    from _gpu_util import fields_from_case, make_rays
+    g, st, dy, _ = fields_from_case(case)
+    rt = str(g["meta.ray_type"])
+    rays, ts = (t.cuda() for t in make_rays(N, 11, rt))
+    with torch.no_grad():
+        xyz, z, valid = rodynrf.sampleXYZ(dy, rays, S, ray_type=rt, is_train=False)
+    for f in (st, dy):
+        for _ in range(2):   # twice: the counters and the colour fill are re-initialised by every call
+            with torch.no_grad():
+                a = f(rays, ts, None, xyz, z, valid, is_train=False, ray_type=rt, N_samples=S)
+            b = f(rays, ts, None, xyz, z, valid, is_train=False, ray_type=rt, N_samples=S)
+            assert any(v is not None and v.requires_grad for v in b), "the second call must be the training path"
+            for k, u, v in zip(FNAMES, a, b):
+                if u is None or k.startswith("_"):
+                    continue
+                assert torch.equal(u, v.detach()), f"{type(f).__name__}.{k}: inference and training forward differ"
+
+
 def test_render_frame_matches_oracle_pipeline():
     """whole-frame driver: device ray generation -> fused render, one launch sequence vs chunks of
     100 rays vs the oracle's generate_rays -> sampleXYZ -> fields -> raw2outputs on the CPU."""

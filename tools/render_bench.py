@@ -41,7 +41,7 @@ for chunk in chunks:
     dt = (time.perf_counter() - t0) / n
     print(f"chunk {chunk:6d}: {H * W / dt / 1e6:6.3f} Mpix/s  {dt * 1e3:7.3f} ms/frame")
 if 512 in chunks:   # the native chunk loop (rdrf_render_chunks_fwd), one stream and four
-    for ns in (1, 4):
+    for ns in (1, 4, 8):
         R.render_chunks(tr.st, tr.dy, rays_f, ts_f, 512, N_samples=cfg["n_samples"], ray_type=cfg["ray_type"], streams=ns)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -55,7 +55,7 @@ L.lib.rdrf_prof_reset()
 for chunk in chunks:
     frame(chunk)
 torch.cuda.synchronize()
-for k in ("sample_ndc", "static_density", "static_app", "time_branch", "dyn_density", "dyn_app", "composite", "render_fused"):
+for k in ("sample_ndc", "static_density", "static_app", "time_branch", "dyn_density", "ray_scan", "dyn_app", "composite", "render_fused"):
     ms, c = C.c_double(), C.c_int()
     L.lib.rdrf_prof_get(k.encode(), C.byref(ms), C.byref(c))
     if c.value:
