@@ -601,8 +601,9 @@ def main():
         H, W = cfg["H"], cfg["W"]
         out["render"] = render_leg(L, R, S_, trainer, cfg, dev, args.render_chunk or H * W)
         # the reference's eval chunk (renderer.py:732): sequential on one stream, and the same chunks issued round-robin on
-        # four HIP streams (independent chunks; one chunk fills 64-110 of the 256 CUs)
-        out["render_chunk512"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=2, streams=4)
+        # eight HIP streams (independent chunks; the MLP kernels of one chunk hold one workgroup per CU on a part of the
+        # chip, the small kernels of the other chunks run beside them)
+        out["render_chunk512"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=4, streams=8)
         out["render_chunk512_one_stream"] = render_leg(L, R, S_, trainer, cfg, dev, 512, frames=2, streams=1)
     if rank == 0 and world == 1 and not args.no_final_stage and args.config == "nvidia" and args.stage == "stage0":
         # 78 % of the reference's iterations run after the last upsampling (configs/Nvidia.txt: upsamp_list[-1] =

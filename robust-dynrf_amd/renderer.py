@@ -195,7 +195,7 @@ _stream_pool = {}
 
 
 @torch.no_grad()
-def render_chunks(tensorf_static, tensorf, rays, ts, chunk, N_samples=-1, ray_type="ndc", streams=4):
+def render_chunks(tensorf_static, tensorf, rays, ts, chunk, N_samples=-1, ray_type="ndc", streams=8):
     """The chunk loop of renderer.py:740-812 (`for chunk_idx in range(N_rays_all // chunk + ...)`, chunk = 512 at
     renderer.py:732) as ONE native call (rdrf_render_chunks_fwd): the chunks' launch sequences are issued from C,
     round-robin on `streams` HIP streams (0 / 1: all on the current stream).  Issued chunk by chunk from Python the loop

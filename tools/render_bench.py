@@ -41,7 +41,7 @@ for chunk in chunks:
     dt = (time.perf_counter() - t0) / n
     print(f"chunk {chunk:6d}: {H * W / dt / 1e6:6.3f} Mpix/s  {dt * 1e3:7.3f} ms/frame")
 if 512 in chunks:   # the native chunk loop (rdrf_render_chunks_fwd), one stream and four
-    for ns in (1, 4, 8):
+    for ns in (1, 4, 8, 16):
         R.render_chunks(tr.st, tr.dy, rays_f, ts_f, 512, N_samples=cfg["n_samples"], ray_type=cfg["ray_type"], streams=ns)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
