@@ -225,14 +225,26 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
     L.lib.rdrf_prof_enable(1)
     L.lib.rdrf_prof_reset()
     S_.PASSES.clear()
-    for _ in range(NP):
+    # the fractions are not monotonic over the first iterations (they rise to ~0.74 around iteration 10 before they
+    # fall), so they are probed about 20 times inside the window (HIP-event recording off around the probe forwards;
+    # the profiled pass is not timed by the wall clock) and averaged by the trapezoid rule
+    every = max(1, NP // 20)
+    probes = [fr0]
+    for i in range(NP):
         trainer.step(shard)
         trainer.finish_step()
+        if (i + 1) % every == 0 and i + 1 < NP:
+            torch.cuda.synchronize()
+            L.lib.rdrf_prof_enable(0)
+            probes.append(mask_fractions(S_, trainer, rays_per_gpu))
+            torch.cuda.synchronize()
+            L.lib.rdrf_prof_enable(1)
     torch.cuda.synchronize()
     L.lib.rdrf_prof_enable(0)
     fr1 = mask_fractions(S_, trainer, rays_per_gpu)
+    probes.append(fr1)
     # the window's mean fractions price the appearance work of the profiled steps
-    valid_frac, f_s, f_d = (0.5 * (a + b) for a, b in zip(fr0, fr1))
+    valid_frac, f_s, f_d = ((0.5 * (pr[0] + pr[-1]) + sum(pr[1:-1])) / (len(pr) - 1) for pr in zip(*probes))
     # ray-passes per step by kind: the algorithmic counts below are per PASS (4096 rays x S samples); a batched launch
     # (step.ray_passes) covers several
     np_stat, np_stat_g = S_.PASSES["static"] / NP, S_.PASSES["static_grad"] / NP
@@ -354,6 +366,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         "profiled_window": ("iterations warmup .. warmup + steps of a fresh trainer: the states of the timed region"
                             if window is not None else "3 iterations at the trainer's current state"),
         "fractions": {"valid": valid_frac, "app_mask_dynamic": f_d, "app_mask_static": f_s,
+                      "probes_in_window": len(probes), "max_in_window": {"app_mask_static": max(pr[1] for pr in probes), "app_mask_dynamic": max(pr[2] for pr in probes)},
                       "at_window_start": {"app_mask_static": fr0[1], "app_mask_dynamic": fr0[2]},
                       "at_window_end": {"app_mask_static": fr1[1], "app_mask_dynamic": fr1[2]}},
         # fp32-MFMA fraction of every MLP kernel of the profiled steps (algorithmic FLOP of the passes it ran / its HIP-event

@@ -219,9 +219,22 @@ RDRF_D void acc_bias(f32x16 (&acc)[NBO], const float* __restrict__ bpk, int h) {
 }
 
 // cooperative copy of one kernel's weight image into LDS
+// (121-159 KB per workgroup: 15-20 rounds of one 16-byte load per thread at 8 waves; issued one at a time each round is
+// an L2 round trip, ~15 us per launch -- a quarter of a 512-ray eval chunk's kernel -- so four are kept in flight)
 RDRF_D void lds_fill(float* __restrict__ lds, const float* __restrict__ src, int nfloats) {
-  for (int i = threadIdx.x * 4; i < nfloats; i += blockDim.x * 4)
-    *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
+  const int stride = blockDim.x * 4;
+  int i = threadIdx.x * 4;
+  for (; i + 3 * stride < nfloats; i += 4 * stride) {
+    const f32x4 v0 = *(const f32x4*)(src + i);
+    const f32x4 v1 = *(const f32x4*)(src + i + stride);
+    const f32x4 v2 = *(const f32x4*)(src + i + 2 * stride);
+    const f32x4 v3 = *(const f32x4*)(src + i + 3 * stride);
+    *(f32x4*)(lds + i) = v0;
+    *(f32x4*)(lds + i + stride) = v1;
+    *(f32x4*)(lds + i + 2 * stride) = v2;
+    *(f32x4*)(lds + i + 3 * stride) = v3;
+  }
+  for (; i < nfloats; i += stride) *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
   __syncthreads();
 }
 
