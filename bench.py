@@ -236,12 +236,18 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         if (i + 1) % every == 0 and i + 1 < NP:
             torch.cuda.synchronize()
             L.lib.rdrf_prof_enable(0)
+            counted = dict(S_.PASSES)   # the probe's own ray-pass is not part of the step
             probes.append(mask_fractions(S_, trainer, rays_per_gpu))
+            S_.PASSES.clear()
+            S_.PASSES.update(counted)
             torch.cuda.synchronize()
             L.lib.rdrf_prof_enable(1)
     torch.cuda.synchronize()
     L.lib.rdrf_prof_enable(0)
+    counted = dict(S_.PASSES)
     fr1 = mask_fractions(S_, trainer, rays_per_gpu)
+    S_.PASSES.clear()
+    S_.PASSES.update(counted)
     probes.append(fr1)
     # the window's mean fractions price the appearance work of the profiled steps
     valid_frac, f_s, f_d = ((0.5 * (pr[0] + pr[-1]) + sum(pr[1:-1])) / (len(pr) - 1) for pr in zip(*probes))

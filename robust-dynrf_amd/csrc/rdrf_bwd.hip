@@ -2045,6 +2045,9 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
     t = tn;
   }
   // write-out: C row i = (rr&3) + 8*(rr>>2) + 4*h (out neuron), column = li (input element)
+#ifdef RDRF_ABL_DW_NOFLUSH
+  if (ntiles >= 0) return;
+#endif
 #pragma unroll
   for (int p = 0; p < DW2_MAX_PROD; ++p) {
     if (p < np) {
