@@ -187,7 +187,7 @@ def test_fused_render_is_bit_identical_to_the_launch_sequence(case, N, S):
         assert_close(b[1], g["ce.depth_map_full"], "fused depth", atol=256.0 * 2.0 ** -22 if rt == "contract" else 0.0)
 
 
-@pytest.mark.parametrize("case,N,S", [("ndc_relu", 7, 13), ("ndc_relu", 513, 115), ("contract_relu_te", 300, 37), ("ndc_relu", 2100, 33)])
+@pytest.mark.parametrize("case,N,S", [("ndc_relu", 7, 13), ("ndc_relu", 513, 115), ("contract_relu_te", 300, 37), ("ndc_relu", 2100, 33), ("ndc_relu", 1, 1), ("contract_relu_te", 3, 1000), ("ndc_relu", 17, 32)])
 def test_inference_forward_is_bit_identical_to_the_training_forward(case, N, S):
     """Inference calls (no saved activations) run the dynamic field's density phase at tile granularity --
     k_dyn_density_flat over 32-sample tiles of the flattened [N * S] array + k_ray_scan -- and let the density kernels
