@@ -358,8 +358,25 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
                    "34.5 TB/s L2) are the physical figures; launches of >= 300 k samples take the sorted kernels "
                    "(~10x fewer requests)"}
     dom_e, oth_e = (sc_entry, dw_entry) if (not dw_keys or sc_ms >= dw_ms) else (dw_entry, sc_entry)
-    out = dict(dom_e)
+    dom_e = dict(dom_e)
+    dom_e["note"] = ("the kernel family with the most time per step; its `frac` is NOMINAL where the bytes are cache resident "
+                     "(see `limiter`): the physical figures are hbm_real, frac_l2 and l2_atomic_frac")
+    # The line's own roofline is the STEP against the fp32-MFMA peak: the path is MLP-bound
+    # once the gathers are cache resident (SURVEY 8d "which roofline"), `achieved` = algorithmic FLOP of the work the step
+    # executes (dead work included only when it runs) / the timed step; filled in by price_step() with the timed ms.
+    out = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+           "traffic": None, "kernel": "the whole training step (every MLP kernel's algorithmic FLOP / step time)"}
+    f_all, w_all = pmc_family_per_step("pmc_fetch", ("",), "FETCH_SIZE"), pmc_family_per_step("pmc_write", ("",), "WRITE_SIZE")
+    if f_all is not None and w_all is not None:   # HBM-side bytes of one whole step of the committed profile (all kernels)
+        out["traffic"] = f_all * 1024.0 * 2.0 + w_all * 1024.0
+        out["traffic_note"] = (f"2 FETCH_SIZE + WRITE_SIZE summed over every kernel of one step, profiles/{_profile_csv('pmc_fetch')[1]}_pmc_*.csv "
+                               "(committed rocprofv3 PMC passes of the driver's command; the guide's gfx950 correction), per STEP")
+    # what the training forward leaves in HBM for the backward (rows of 32 samples, csrc/rdrf_kernels.hpp namespace sv)
+    out["saved_bytes_per_sample"] = {
+        "dynamic_density_phase": L.lib.rdrf_saved_row_bytes(0), "dynamic_appearance_phase_per_masked_sample": L.lib.rdrf_saved_row_bytes(1),
+        "static_appearance_phase_per_masked_sample": L.lib.rdrf_saved_row_bytes(2)}
     out.update({
+        "dominant_kernel": dom_e,
         "second_kernel": oth_e,
         "step_algorithmic_tflop": step_flops / 1e12,
         "step_frac_of_peak": step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
@@ -407,6 +424,8 @@ def price_step(rf, ms, rays_per_gpu):
     """fill the fields of a roofline() result that depend on the timed region's ms/step (the profiled replay runs BEFORE the
     timed region: it doubles as the clock warm-up of the process, see main())"""
     rf["step_frac_of_peak"] = rf["step_algorithmic_tflop"] / (ms * 1e-3) / PEAK_F32_MFMA_TFLOPS
+    rf["achieved"] = rf["step_algorithmic_tflop"] / (ms * 1e-3)
+    rf["frac"] = rf["step_frac_of_peak"]
     sc = rf["survey_canonical"]
     t_meas = ms * 1e-3 / rays_per_gpu
     sc["frac_flop"] = sc["flop_per_training_ray"] / (PEAK_F32_MFMA_TFLOPS * 1e12 * t_meas)
@@ -490,8 +509,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="nvidia", choices=["nvidia", "nvidia_no_poses", "davis"])
-    ap.add_argument("--stage", default="stage0", choices=["stage0", "final", "huge"])
+    ap.add_argument("--config", default=None, choices=["nvidia", "nvidia_no_poses", "davis"],
+                    help="default: the BASELINE.json config quoted for this GPU count (see --baseline-config)")
+    ap.add_argument("--stage", default=None, choices=["stage0", "up1", "up2", "up3", "final", "huge"])
+    ap.add_argument("--baseline-config", default="auto", choices=["auto", "1", "2", "3", "4"],
+                    help="BASELINE.json configs[i] to run when --config / --stage are not given.  auto: N = 1, 2 -> configs[1] "
+                         "(Balloon1, Nvidia.txt, 4096 rays per GPU, stage 0); N = 4 -> configs[3] (DAVIS.txt, contracted rays, "
+                         "8192 rays GLOBAL = 2048 per rank, final grid 256^3); N = 8 -> configs[4] (640^3 grid, 32768 rays "
+                         "global = 4096 per rank); any other N -> configs[1]")
     ap.add_argument("--weights", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--rays-per-gpu", type=int, default=0, help="default: the config's batch size (4096; DAVIS 8192)")
     ap.add_argument("--dp", default="zero1", choices=["zero1", "allreduce"],
@@ -536,6 +561,22 @@ def main():
     R = importlib.import_module("robust-dynrf_amd.renderer")
 
     L.set_scatter_mode(args.scatter)
+    # which BASELINE.json configuration this GPU count is quoted on; explicit --config / --stage win
+    BASE = {"1": ("nvidia", "stage0", 0), "2": ("nvidia_no_poses", "stage0", 0), "3": ("davis", "final", 8192),
+            "4": ("nvidia_no_poses", "final", 32768)}
+    bsel = args.baseline_config
+    if bsel == "auto":
+        bsel = {4: "3", 8: "4"}.get(world, "1")
+    b_cfg, b_stage, b_global = BASE[bsel]
+    explicit = args.config is not None or args.stage is not None
+    if explicit:
+        args.config, args.stage = args.config or "nvidia", args.stage or "stage0"
+        bsel = {("nvidia", "stage0"): "1", ("nvidia_no_poses", "stage0"): "2", ("davis", "final"): "3",
+                ("nvidia_no_poses", "final"): "4"}.get((args.config, args.stage))
+    else:
+        args.config, args.stage = b_cfg, b_stage
+        if not args.rays_per_gpu and b_global and b_global % world == 0:
+            args.rays_per_gpu = b_global // world   # the config's GLOBAL batch split over the ranks it is quoted on
     cfg = S_.scene_config(args.config, args.stage)
     rpg = args.rays_per_gpu or cfg["batch_size"]
     cfg["batch_size"] = rpg * world   # weak scaling: fixed rays per GPU
@@ -564,8 +605,10 @@ def main():
     npass = "7 dynamic + 9 static" if cfg["optimize_poses"] else "5 dynamic + 5 static"
     workloads = {
         "nvidia": "BASELINE.json configs[1]: Nvidia Balloon1, configs/Nvidia.txt",
-        "nvidia_no_poses": "BASELINE.json configs[2]: Nvidia, configs/Nvidia_no_poses.txt, joint pose + focal optimisation",
-        "davis": "BASELINE.json configs[3]: DAVIS, configs/DAVIS.txt, contracted rays, flow + depth supervision"}
+        "nvidia_no_poses": ("BASELINE.json configs[4]: Nvidia, N_voxel_final = 640^3 (configs/Nvidia_no_poses.txt schedule), 32k rays/iter "
+                            "over 8 GPUs" if bsel == "4" else
+                            "BASELINE.json configs[2]: Nvidia, configs/Nvidia_no_poses.txt, joint pose + focal optimisation"),
+        "davis": "BASELINE.json configs[3]: DAVIS, configs/DAVIS.txt, contracted rays, flow + depth supervision, 8192 rays/iter over 4 GPUs"}
     out = {
         "metric": "training rays/sec (Nvidia Balloon1, configs/Nvidia.txt, static+dynamic TensorVMSplit)"
                   if args.config == "nvidia" else f"training rays/sec ({args.config})",
@@ -575,6 +618,12 @@ def main():
         "config": {"workload": f"{workloads[args.config]}, {rpg} rays/iter/GPU, 1xMI355X per rank, static+dynamic "
                                f"TensorVMSplit; one step = {npass} forward passes, scene-flow MLP, induced flow/disparity, "
                                "per-frame depth loss, distortion loss, compositor, factor regularisers, full backward, Adam",
+                   "baseline_config_index": None if bsel is None else int(bsel),
+                   "baseline_config_selected": "explicit --config / --stage" if explicit else f"--baseline-config {args.baseline_config} at {world} GPU(s)",
+                   "timed_region": ("preceded by a profiled REPLAY of the same window on a second trainer (iterations 0 .. warmup + steps, "
+                                    "same seeds): it yields the per-kernel table of exactly the timed iterations and warms the clocks; "
+                                    "then the driver's warmup + steps iterations run on the main trainer and `steps` of them are timed"
+                                    if not args.no_roofline else "warmup + steps iterations on a fresh trainer"),
                    "config": args.config, "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
                    "global_batch": cfg["batch_size"], "weights": args.weights,
                    "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if trainer.opt.ex.active else ""),
@@ -634,13 +683,38 @@ def main():
         fin = {"value": rpg / dtf, "unit": "rays/s", "ms_per_step": dtf * 1e3, "grid": cfg_f["grid"],
                "samples_per_ray": cfg_f["n_samples"], "steps": max(10, args.steps // 5)}
         if not args.no_roofline:
-            rf = roofline(L, S_, tr_f, cfg_f, shard, rpg, dtf * 1e3)
-            fin["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_step",
+            rf = price_step(roofline(L, S_, tr_f, cfg_f, shard, rpg, dtf * 1e3), dtf * 1e3, rpg)
+            fin["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                   "step_frac_of_peak", "kernel_ms_per_step", "fractions")}
+            fin["roofline"]["dominant_kernel"] = {k: rf["dominant_kernel"][k] for k in ("kernel", "bound", "achieved", "peak", "unit",
+                                                                                     "frac", "ms_per_step")}
         if not args.no_render:
             fin["render"] = render_leg(L, R, S_, tr_f, cfg_f, dev, cfg_f["H"] * cfg_f["W"], frames=3)
         out["final_stage"] = fin
         del tr_f
+        # time-weighted figure over the resolution schedule (configs/Nvidia.txt:14,19, train.py:937-947, 2582-2588): the
+        # three intermediate grids once each (short windows, no per-kernel table), every stage weighted by the share of the
+        # n_iters iterations it runs
+        per_stage = {"stage0": ms, "final": dtf * 1e3}
+        shapes = {"stage0": (cfg["grid"], cfg["n_samples"]), "final": (cfg_f["grid"], cfg_f["n_samples"])}
+        for stg in ("up1", "up2", "up3"):
+            cfg_i = S_.scene_config("nvidia", stg)
+            cfg_i["batch_size"] = rpg
+            tr_i = S_.Trainer(cfg_i, dev, weights=args.weights, dead_work=not args.exploit_liveness)
+            dti, _ = timed_steps(tr_i, shard, 8, 3, 1, dev)
+            per_stage[stg], shapes[stg] = dti * 1e3, (cfg_i["grid"], cfg_i["n_samples"])
+            del tr_i
+            torch.cuda.empty_cache()
+        sched = S_.resolution_schedule("nvidia")
+        n_it = float(sched[-1][2])
+        mean_ms = sum(per_stage[st] * (b - a) / n_it for st, a, b in sched)
+        out["schedule_weighted"] = {
+            "value": rpg / (mean_ms * 1e-3), "unit": "rays/s", "mean_ms_per_step": mean_ms,
+            "stages": [{"stage": st, "iterations": [a, b], "share": (b - a) / n_it, "grid": shapes[st][0],
+                        "samples_per_ray": shapes[st][1], "ms_per_step": per_stage[st]} for st, a, b in sched],
+            "note": "rays of a whole 100000-iteration Nvidia.txt run / its time: every stage of the resolution schedule measured "
+                    "at its own grid and sample count from reference-initialised weights (stage 0 = the headline window; up1-up3 "
+                    "8 timed steps after 3; final = the final_stage leg), weighted by its share of the iterations"}
     if rank == 0 and world == 1 and not args.no_sparse and args.weights == "dense":
         # SURVEY 8d W-sparse: the same step / render with trained-scene-like occupancy (app mask ~0.10 in both fields)
         tr_s = S_.Trainer(dict(cfg), dev, weights="sparse", dead_work=not args.exploit_liveness)
@@ -660,6 +734,19 @@ def main():
             out["cpu_baseline_4096"] = cpu_baseline(trainer, 4096, 1, dead_work=not args.exploit_liveness)
             out["cpu_baseline_4096"]["note"] = "the configs[0] batch size; one timed step after a 512-ray warm-up"
     if rank == 0:
+        # what a reader of the driver's `parsed` summary should see without opening nested keys
+        if "final_stage" in out:
+            out["final_stage_value"] = out["final_stage"]["value"]
+            out["final_stage_ms_per_step"] = out["final_stage"]["ms_per_step"]
+        if "schedule_weighted" in out:
+            out["schedule_weighted_value"] = out["schedule_weighted"]["value"]
+        if "liveness_exploited" in out:
+            out["liveness_exploited_value"] = out["liveness_exploited"]["value"]
+        if "render" in out:
+            out["render_mpix_per_s"] = out["render"]["value"]
+            out["render_chunk512_mpix_per_s"] = out["render_chunk512"]["value"]
+        if "roofline" in out:
+            out["step_frac_of_fp32_mfma_peak"] = out["roofline"]["frac"]
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()

@@ -117,6 +117,10 @@ size_t rdrf_forward_workspace_bytes(int N, int S);
  * 1 = dynamic field, 2 = scene flow) stores the activations its backward needs; the matching
  * *_bwd call must receive the same buffer untouched.  saved == NULL => inference, nothing kept. */
 size_t rdrf_saved_bytes(int kind, int N, int S);
+/* Bytes per sample of the activation rows inside that buffer (a measurement aid, bench.py `saved_bytes_per_sample`):
+ * phase 0 = dynamic field, density phase (every sample); 1 = dynamic field, appearance phase (per sample that passes the
+ * weight > 1e-4 mask, models/tensorBase.py:773-790); 2 = static field, appearance phase (per masked sample); 3 = scene flow. */
+size_t rdrf_saved_row_bytes(int phase);
 
 /* ---- ray generation: train.py:96-103 + dataLoader/ray_utils.py:53-140 + camera.py:8-15 -------
  * ids[N] int64 flat ray ids over (T,H,W); poses9[T][9] 6-D rotation + translation; focal scalar.

@@ -65,6 +65,8 @@ def _load():
     lib.rdrf_forward_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.rdrf_saved_bytes.restype = C.c_size_t
     lib.rdrf_saved_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.rdrf_saved_row_bytes.restype = C.c_size_t
+    lib.rdrf_saved_row_bytes.argtypes = [C.c_int]
     for name, args in (("rdrf_features_saved_bytes", [C.c_int, C.c_int]),
                        ("rdrf_features_workspace_bytes", [C.c_int]),
                        ("rdrf_features_bwd_workspace_bytes", [C.c_int])):
@@ -100,7 +102,7 @@ lib = _load()
 
 # every symbol include/rodynrf.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "rdrf_abi_version", "rdrf_last_error", "rdrf_workspace_bytes", "rdrf_forward_workspace_bytes", "rdrf_saved_bytes",
+    "rdrf_abi_version", "rdrf_last_error", "rdrf_workspace_bytes", "rdrf_forward_workspace_bytes", "rdrf_saved_bytes", "rdrf_saved_row_bytes",
     "rdrf_generate_rays",
     "rdrf_generate_rays_bwd", "rdrf_generate_rays_uv", "rdrf_generate_rays_uv_bwd", "rdrf_sample_ndc", "rdrf_sample_contract", "rdrf_sample_bwd",
     "rdrf_static_fwd", "rdrf_static_bwd", "rdrf_dynamic_fwd", "rdrf_dynamic_bwd",
@@ -169,18 +171,28 @@ def stream_of(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-_ws = {}
+_ws = {}          # (device, stream) -> scratch buffer, most recently used last
+_WS_MAX = 20      # the default stream + the 16 side streams of render_chunks + slack: older entries are dropped
 
 
 def workspace(device, nbytes):
     """scratch of the C entry points, one buffer per (device, stream): calls on different streams (render_chunks) must
-    not share scratch"""
+    not share scratch.  The cache is an LRU of _WS_MAX entries (a stream that is no longer used gives its buffer back to
+    the caching allocator, which keeps it ordered behind that stream's work); growing a buffer drops the old one first."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws.get(key)
+    buf = _ws.pop(key, None)
     if buf is None or buf.numel() < nbytes:
+        buf = None   # free before allocating: the peak is one buffer, not two
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-        _ws[key] = buf
+    _ws[key] = buf
+    while len(_ws) > _WS_MAX:
+        _ws.pop(next(iter(_ws)))
     return buf
+
+
+def release_workspaces():
+    """drop every cached scratch buffer (they return to torch's caching allocator)"""
+    _ws.clear()
 
 
 def zeros_like_many(tensors, want=None):

@@ -239,6 +239,10 @@ extern "C" size_t rdrf_saved_bytes(int kind, int N, int S) {
   return saved_bytes_field(kind == 1, N, S);
 }
 
+extern "C" size_t rdrf_saved_row_bytes(int phase) {
+  return (size_t)4 * (phase == 0 ? sv::K1_ROWS : phase == 1 ? sv::K3_ROWS : phase == 2 ? sv::S3_ROWS : sv::SF_ROWS);
+}
+
 // persistent launch geometry: one workgroup per CU (its LDS holds the kernel's weight image),
 // up to 8 waves per workgroup, each wave walking its own rays / tiles.
 struct Geo {

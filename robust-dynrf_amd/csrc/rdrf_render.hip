@@ -291,14 +291,24 @@ extern "C" int rdrf_render_chunks_fwd(const RdrfStaticParams* PS, const RdrfFiel
              "render_chunks: both packed weight images are required (rdrf_static_pack / rdrf_dynamic_pack)");
   RDRF_CHECK(nstreams >= 0 && nstreams <= 16 && (nstreams == 0 || streams != nullptr), -1, "render_chunks: 0..16 streams");
   hipStream_t main_stream = (hipStream_t)main_stream_;
+#ifdef RDRF_DETERMINISTIC
+  // the deterministic build sorts every compaction list through ONE process-wide scratch (rdrf_sort_ints_inplace): chunks
+  // on different streams would race on it (and it may be re-allocated under them), so this build runs the loop in order
+  // on the caller's stream -- same bits, no concurrency
+  nstreams = 0;
+#endif
   const int ns = nstreams < 1 ? 1 : nstreams;
   const size_t slice = (rdrf_render_workspace_bytes(chunk < N ? chunk : N, S) + 255) & ~(size_t)255;
   RDRF_CHECK(ws_bytes >= slice * ns, -3, "render_chunks: workspace too small: need %zu have %zu", slice * ns, ws_bytes);
   hipEvent_t ev_start = nullptr, ev_done[16];
   if (nstreams >= 1) {
     RDRF_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
-    RDRF_HIP(hipEventRecord(ev_start, main_stream));
-    for (int k = 0; k < nstreams; ++k) RDRF_HIP(hipStreamWaitEvent((hipStream_t)streams[k], ev_start, 0));
+    hipError_t e = hipEventRecord(ev_start, main_stream);
+    for (int k = 0; k < nstreams && e == hipSuccess; ++k) e = hipStreamWaitEvent((hipStream_t)streams[k], ev_start, 0);
+    if (e != hipSuccess) {   // nothing was issued on the side streams yet: release the event and report
+      (void)hipEventDestroy(ev_start);
+      RDRF_CHECK(false, -5, "render_chunks: fork onto the side streams failed: %s", hipGetErrorString(e));
+    }
   }
   int rc = 0, k = 0;
   for (int c0 = 0; c0 < N && rc == 0; c0 += chunk, ++k) {

@@ -93,6 +93,16 @@ def shard_bounds(n, rank, world):
     return rank * n // world, (rank + 1) * n // world
 
 
+def require_even_shards(batch_size, world):
+    """The exact-statistics exchange of the trainer (step.Trainer(dp_exact_stats=True)) gathers the per-ray depths of the
+    whole batch with all_gather_into_tensor, which needs equal shards on every rank: with a batch that does not divide by
+    the world size the ranks would post collectives of different sizes and hang.  Every rank evaluates the same two
+    integers, so every rank raises -- before any collective is issued."""
+    if world > 0 and batch_size % world != 0:
+        raise ValueError(f"dp_exact_stats needs batch_size ({batch_size}) divisible by the world size ({world}); "
+                         "use --dp-per-shard-stats or a divisible batch")
+
+
 class FlatExchange:
     """The data-parallel exchange of flat gradient buffers, separated from the optimiser
     arithmetic so that the choreography is testable on CPU tensors with gloo:

@@ -220,7 +220,9 @@ def render_chunks(tensorf_static, tensorf, rays, ts, chunk, N_samples=-1, ray_ty
     _attach_packed(tensorf, PD, pd_list, False, True)           # read-only by every side stream
     cs, cd = _cfg_struct(tensorf_static, ray_type), _cfg_struct(tensorf, ray_type)
     near, far = tensorf.near_far
-    pool = _stream_pool.setdefault((dev, ns), [torch.cuda.Stream(device=dev) for _ in range(ns)])
+    pool = _stream_pool.get((dev, ns))
+    if pool is None:
+        pool = _stream_pool[(dev, ns)] = [torch.cuda.Stream(device=dev) for _ in range(ns)]
     arr = (C.c_void_p * max(ns, 1))(*[st.cuda_stream for st in pool]) if ns else None
     L.check(L.lib.rdrf_render_chunks_fwd(C.byref(PS), C.byref(cs), C.byref(PD), C.byref(cd), L.ptr(rays), L.ptr(ts), N, S, chunk,
                                          C.c_float(near), C.c_float(far), L.ptr(rgb), L.ptr(depth), L.ptr(ws),

@@ -37,6 +37,7 @@ import torch.nn as nn
 
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
 from .optim import FlatAdam
+from .parallel import require_even_shards
 from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
 from .losses import LossTerms, frame_depth_loss
@@ -54,7 +55,10 @@ def scene_config(name="nvidia", stage="stage0"):
         cfg = dict(aabb=NDC_AABB, near_far=[0.0, 1.0], T=12, H=135, W=240, ray_type="ndc", batch_size=4096,
                    static_head="MLP_Fea", optimize_poses=False, tv_density=1.0, tv_app=1.0, dist_static=0.0,
                    dist_dynamic=0.01, l1_weight=0.0)
-        stages = {"stage0": ([141, 157, 94], 115), "final": ([331, 368, 220], 270), "huge": ([706, 786, 471], 578)}
+        # up1..up3: the intermediate grids of the resolution schedule (train.py:937-947: N_voxel_list linear in log
+        # space between N_voxel_init = 128^3 and N_voxel_final = 300^3, utils.py:58-65 N_to_reso / cal_n_samples)
+        stages = {"stage0": ([141, 157, 94], 115), "up1": ([174, 194, 116], 142), "up2": ([216, 240, 144], 176),
+                  "up3": ([267, 298, 178], 218), "final": ([331, 368, 220], 270), "huge": ([706, 786, 471], 578)}
     elif name == "nvidia_no_poses":
         cfg = dict(aabb=NDC_AABB, near_far=[0.0, 1.0], T=12, H=135, W=240, ray_type="ndc", batch_size=4096,
                    static_head="MLP_Fea", optimize_poses=True, tv_density=0.0, tv_app=0.0, dist_static=0.01,
@@ -76,8 +80,20 @@ def scene_config(name="nvidia", stage="stage0"):
                upsamp_list=[8000, 12000, 16000, 22000] if name == "nvidia" else [2000, 4000, 6000, 8000, 12000, 16000, 22000])
     # the iteration a run of this stage starts at (train.py:2582-2588: grids change at upsamp_list)
     cfg["start_iteration"] = 0 if stage == "stage0" else cfg["upsamp_list"][-1]
+    if stage in ("up1", "up2", "up3"):
+        cfg["start_iteration"] = cfg["upsamp_list"][int(stage[2]) - 1]
     cfg["focal"] = max(cfg["H"], cfg["W"]) / 2.0 * math.sqrt(3.0)
     return cfg
+
+
+def resolution_schedule(name="nvidia"):
+    """[(stage, first iteration, last iteration)] of a config's resolution schedule (train.py:2582-2588: the grids change
+    at the iterations of upsamp_list; configs/Nvidia.txt:14,19): the share of the n_iters iterations each stage runs."""
+    if name != "nvidia":
+        raise ValueError("resolution_schedule: only the Nvidia.txt schedule is tabulated")
+    cfg = scene_config(name, "stage0")
+    edges = [0] + cfg["upsamp_list"] + [cfg["n_iters"]]
+    return [(st, edges[i], edges[i + 1]) for i, st in enumerate(["stage0", "up1", "up2", "up3", "final"])]
 
 
 def balloon1_config(stage="stage0"):
@@ -662,10 +678,9 @@ class Trainer:
         """One iteration on this rank's shard of the batch: forward of every pass, two-phase backward (static
         group first; its gradient exchange starts while the dynamic group is still differentiating).
         Returns the loss tensor (device, no sync)."""
-        if shard is not None and self.dp_exact_stats and self.cfg["batch_size"] % shard[1] != 0:
+        if shard is not None and self.dp_exact_stats:
             # the exact-statistics exchange all-gathers the per-ray depths with all_gather_into_tensor: equal shards only
-            raise ValueError(f"dp_exact_stats needs batch_size ({self.cfg['batch_size']}) divisible by the world size "
-                             f"({shard[1]}); use --dp-per-shard-stats or a divisible batch")
+            require_even_shards(self.cfg["batch_size"], shard[1])
         b = self.data.make_batch(self.it, self.cfg["batch_size"], shard)
         loss_d, loss_s = self.losses(b)
         c = self.cfg

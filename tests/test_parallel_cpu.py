@@ -140,3 +140,65 @@ def test_flat_exchange_zero1_equals_allreduce_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def _worker_world4(rank, world, port, q):
+    """world 4: the FlatExchange round trip of _worker_exchange, then a batch that does not divide by the world size: every
+    rank must raise BEFORE a collective is posted (ADVICE r3 #2: no hang), and a barrier afterwards must still complete"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    P = importlib.import_module("robust-dynrf_amd.parallel")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    P.init_distributed("gloo")
+    ok = True
+    try:
+        P.require_even_shards(8190, world)   # 8190 = 2 * 4095: divides by 2, not by 4
+        ok = False
+    except ValueError as e:
+        ok = ok and "divisible" in str(e)
+    P.require_even_shards(8192, world)
+    try:   # a flat buffer whose shards would not be 16-byte aligned is refused at construction, on every rank
+        P.FlatExchange([4096 + 8], "zero1")
+        ok = False
+    except ValueError:
+        pass
+    dist.barrier()   # nothing is left pending on the group
+    # uneven ray shards without the exact statistics are legal: shard_bounds covers the batch exactly once
+    lo, hi = P.shard_bounds(8190, rank, world)
+    cover = torch.zeros(8190)
+    cover[lo:hi] = 1
+    dist.all_reduce(cover)
+    ok = ok and bool((cover == 1).all())
+    totals = [4096, 8192]
+    gen = torch.Generator().manual_seed(1)
+    grads = [[torch.randn(t, generator=gen) for t in totals] for _ in range(world)]
+    for mode in ("zero1", "allreduce"):
+        ex = P.FlatExchange(totals, mode)
+        plan = ex.plan(["static_field", "dynamic_field"])
+        ok = ok and len(plan) == (4 if mode == "zero1" else 2)
+        ok = ok and plan[0]["ring_bytes_per_rank"] == (totals[0] * 4 * 3 // 4) * (1 if mode == "zero1" else 2)
+        for i in range(2):
+            g, lo, n = ex.grads(i, grads[rank][i].clone())
+            want = sum(grads[r][i] for r in range(world))[lo: lo + n]
+            ok = ok and n == (totals[i] // world if mode == "zero1" else totals[i]) and torch.allclose(g, want, rtol=1e-5, atol=1e-6)
+            p = torch.zeros(totals[i])
+            p[lo: lo + n] = rank + 1.0
+            w = ex.gather(i, p)
+            if w is not None:
+                w.wait()
+                ok = ok and all(bool((p[r * n:(r + 1) * n] == r + 1.0).all()) for r in range(world))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_flat_exchange_world4_and_uneven_batch_raises():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_world4, args=(r, 4, 29751, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(4)]
+    for p in procs:
+        p.join(60)
+    assert len(res) == 4 and all(ok for _, ok in res), res
