@@ -247,24 +247,36 @@ RDRF_D bool nz4(f32x4 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w 
 // when they fit they are accumulated in LDS (ds_add_f32) by the whole workgroup and flushed to
 // global memory once per block: `ll` = LDS accumulator of this factor set or nullptr.
 struct LdsLines {
-  float* base;   // LDS accumulator (nullptr: scatter straight to global memory)
-  int off[3];    // float offset of line 0/1/2 inside it
+  float* base;   // LDS accumulator (nullptr: scatter straight to global memory); holds doubles when f64 != 0
+  int off[3];    // ELEMENT offset of line 0/1/2 inside it
+  int f64;       // element type of the accumulator: 1 = double (ds_add_f64), 0 = float (ds_add_f32)
+  int direct;    // 1: every live lane adds its own line taps (no run reduction): the sorted passes, where the line index of
+                 //    consecutive entries is random and a ds_add_f64 costs less than the DPP scan that would precede it
 };
-// LDS accumulator layout: entry l of a line with C components starts at l*(C+4): with the natural
+// Element type.  ds_add_f32 is the slowest LDS atomic of gfx950 by an order of magnitude (tools/micro/lds_atomic_rate.hip,
+// the access pattern below, 24 waves per CU): 193 cycles per 64-lane instruction = 0.33 lane-updates per clock and CU,
+// against 17.9 cycles for ds_add_f64 (3.6 / clk), 10.9 for ds_add_u64, 9.1 for ds_add_u32 and 11.6 for a plain
+// ds_write_b32.  So the accumulators are DOUBLES whenever they fit (twice the LDS, 11 x the update rate, and the line
+// sums of ~1e5 terms are formed in fp64 before their one conversion to fp32 at the flush); fp32 accumulators remain for
+// lines too long for that (final-stage appearance lines in the ray-tile kernel).
+// LDS accumulator layout: entry l of a line with C components starts at element l*(C+4): with the natural
 // stride (16 floats for C=16) every entry maps to the same two banks and a z-line update (32 distinct
 // entries per half-wave) serialises ~16-fold; stride 20 (and 52 for C=48) walks all eight 4-bank
 // sets.  Updates use the same quad transposition as the global atomics (4 adjacent lanes = 4
 // adjacent banks).
 RDRF_D int lds_stride(int C) { return C + 4; }
 template <int K>
-RDRF_D void lds_quad_k(float* base, int addr, float val, int c) {
+RDRF_D void lds_quad_k(float* base, int f64, int addr, float val, int c) {
   constexpr int QP = K * 0x55;
   const int ad = dppi<QP>(addr);
   if (__ballot(ad >= 0) == 0ull) return;
-  if (ad >= 0) atomicAdd(base + ad + c, val);
+  if (ad >= 0) {
+    if (f64) __hip_atomic_fetch_add(reinterpret_cast<double*>(base) + ad + c, (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(base + ad + c, val);
+  }
 }
-// all lanes of the wave must call; `addr` = float offset of the lane's quad inside `base`
-RDRF_D void lds_add4(float* base, int addr, f32x4 v, bool ok) {
+// all lanes of the wave must call; `addr` = ELEMENT offset of the lane's quad inside the accumulator `ll`
+RDRF_D void lds_add4(const LdsLines& ll, int addr, f32x4 v, bool ok) {
 #if defined(RDRF_ABL_NOATOM) || defined(RDRF_ABL_NOLDS)
   return;
 #endif
@@ -277,39 +289,45 @@ RDRF_D void lds_add4(float* base, int addr, f32x4 v, bool ok) {
   const float q0 = dppf<0x4E>(n0), q1 = dppf<0x4E>(n1), q2 = dppf<0x4E>(n2), q3 = dppf<0x4E>(n3);
   const float t0 = b ? q2 : n0, t1 = b ? q3 : n1, t2 = b ? n2 : q0, t3 = b ? n3 : q1;
   const int ad = ok ? addr : -1;
-  lds_quad_k<0>(base, ad, t0, c);
-  lds_quad_k<1>(base, ad, t1, c);
-  lds_quad_k<2>(base, ad, t2, c);
-  lds_quad_k<3>(base, ad, t3, c);
+  lds_quad_k<0>(ll.base, ll.f64, ad, t0, c);
+  lds_quad_k<1>(ll.base, ll.f64, ad, t1, c);
+  lds_quad_k<2>(ll.base, ll.f64, ad, t2, c);
+  lds_quad_k<3>(ll.base, ll.f64, ad, t3, c);
 }
 RDRF_D int lines_floats(const RdrfVM& vm) {
   return vm.L[0] * lds_stride(vm.C[0]) + vm.L[1] * lds_stride(vm.C[1]) + vm.L[2] * lds_stride(vm.C[2]);
 }
-RDRF_D LdsLines make_lds_lines(float* base, const RdrfVM& vm) {
+// all three lines of a factor set, starting at element `first` of the accumulator (ray-tile kernel)
+RDRF_D LdsLines make_lds_lines(float* base, int first, int f64, const RdrfVM& vm) {
   LdsLines l;
   l.base = base;
-  l.off[0] = 0;
-  l.off[1] = vm.L[0] * lds_stride(vm.C[0]);
+  l.f64 = f64;
+  l.direct = 0;
+  l.off[0] = first;
+  l.off[1] = first + vm.L[0] * lds_stride(vm.C[0]);
   l.off[2] = l.off[1] + vm.L[1] * lds_stride(vm.C[1]);
   return l;
 }
-RDRF_D void flush_lds_lines(const float* acc, const RdrfVM& vm, const RdrfVM& gvm) {
-  int base = 0;
+// flush `n_entries` x C components of one line (accumulator elements first ..) into its global gradient
+RDRF_D void flush_lds_line(const float* acc, int f64, int first, int L, int C, float* __restrict__ gline) {
+  const int st = lds_stride(C), n = L * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int l = i / C, c = i - l * C;
+    const float v = f64 ? (float)reinterpret_cast<const double*>(acc)[first + l * st + c] : acc[first + l * st + c];
+    if (v != 0.f) grad_add(gline + i, v);
+  }
+}
+RDRF_D void flush_lds_lines(const float* acc, int f64, int first, const RdrfVM& vm, const RdrfVM& gvm) {
   for (int li = 0; li < 3; ++li) {
-    const int C = vm.C[li], st = lds_stride(C), n = vm.L[li] * C;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const int l = i / C, c = i - l * C;
-      const float v = acc[base + l * st + c];
-      if (v != 0.f) grad_add(gvm.line[li] + i, v);
-    }
-    base += vm.L[li] * st;
+    flush_lds_line(acc, f64, first, vm.L[li], vm.C[li], gvm.line[li]);
+    first += vm.L[li] * lds_stride(vm.C[li]);
   }
 }
 
 template <int C0Q, int C1Q, int MODE>
 RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
                             float x2, f32x4 dq, bool live, int s, float& dx0, float& dx1,
-                            float& dx2, const LdsLines ll = LdsLines{nullptr, {0, 0, 0}}) {
+                            float& dx2, const LdsLines ll = LdsLines{nullptr, {0, 0, 0}, 0, 0}) {
 #ifdef RDRF_ABL_NOGBWD
   dx0 += dq.x; return;
 #endif
@@ -444,17 +462,18 @@ RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0
     }
     f32x4 r;
     const Run lr = run_of(tl.i0 + 4, s);
-    float* LL = ll.base ? ll.base + (pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2])) : nullptr;
+    const bool LL = ll.base != nullptr;
+    const int lo_ = pi == 0 ? ll.off[0] : (pi == 1 ? ll.off[1] : ll.off[2]);
     const int lst = lds_stride(C);
     r = run_scan4(m0 ? dl * tl.w0 : zero, lr.start, s);
     {
       const bool okl = lr.tail && tl.ok0 && nz4(r);
-      if (LL) lds_add4(LL, (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL, l0, r, okl);
+      if (LL) lds_add4(ll, lo_ + (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL, l0, r, okl);
     }
     r = run_scan4(m1 ? dl * tl.w1 : zero, lr.start, s);
     {
       const bool okl = lr.tail && tl.ok1 && nz4(r);
-      if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, l1, r, okl);
+      if (LL) lds_add4(ll, lo_ + ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, l1, r, okl);
     }
   }
   // plane 0 = (x, y | z), 1 = (x, z | y), 2 = (y, z | x).  Selects, not branches: pi differs between the lane
@@ -591,14 +610,20 @@ RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, 
   }
   {
     const Run lr = run_of16(tl.i0 + 4, s16);
-    float* LL = ll.base ? ll.base + ll.off[0] : nullptr;
+    const bool LL = ll.base != nullptr;
     const int lst = lds_stride(C);
+    if (LL && ll.direct) {
+      const f32x4 r0 = m0 ? dl * tl.w0 : zero, r1 = m1 ? dl * tl.w1 : zero;
+      lds_add4(ll, ll.off[0] + (tl.i0 << lv) * lst + qo, r0, m0 && nz4(r0));
+      lds_add4(ll, ll.off[0] + ((tl.i0 + 1) << lv) * lst + qo, r1, m1 && nz4(r1));
+    } else {
     f32x4 r = run_scan4_16(m0 ? dl * tl.w0 : zero, lr.start, s16);
     bool okl = lr.tail && tl.ok0 && nz4(r);
-    if (LL) lds_add4(LL, (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)(tl.i0 << lv) * C + qo, r, okl);
+    if (LL) lds_add4(ll, ll.off[0] + (tl.i0 << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)(tl.i0 << lv) * C + qo, r, okl);
     r = run_scan4_16(m1 ? dl * tl.w1 : zero, lr.start, s16);
     okl = lr.tail && tl.ok1 && nz4(r);
-    if (LL) lds_add4(LL, ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)((tl.i0 + 1) << lv) * C + qo, r, okl);
+    if (LL) lds_add4(ll, ll.off[0] + ((tl.i0 + 1) << lv) * lst + qo, r, okl); else atomic_add4(GL, (size_t)((tl.i0 + 1) << lv) * C + qo, r, okl);
+    }
   }
   if (q_is_owner) { dx0 += gcx; dx1 += gcy; dx2 += gcl; }
 }
@@ -675,13 +700,17 @@ RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, 
   atomic_add4(GP, o0, r0, pr.tail && g0 && nz4(r0));
   atomic_add4(GP, o1, r1, pr.tail && up_ok && g1 && nz4(r1));
   // line tap h
-  {
+  if (ll.base && ll.direct) {
+    const bool okl = live && (h ? tl.ok1 : tl.ok0);
+    const f32x4 r = okl ? dl * (h ? tl.w1 : tl.w0) : zero;
+    lds_add4(ll, (pi == 1 ? ll.off[1] : ll.off[2]) + ((tl.i0 + h) << lv) * lds_stride(C) + qo, r, okl && nz4(r));
+  } else {
     const Run lr = run_of(tl.i0 + 4, s);
     const bool okl = h ? tl.ok1 : tl.ok0;
     const f32x4 r = run_scan4((live && okl) ? dl * (h ? tl.w1 : tl.w0) : zero, lr.start, s);
     const bool doit = lr.tail && okl && nz4(r);
     const int li = tl.i0 + h;
-    if (ll.base) lds_add4(ll.base + (pi == 1 ? ll.off[1] : ll.off[2]), (li << lv) * lds_stride(C) + qo, r, doit);
+    if (ll.base) lds_add4(ll, (pi == 1 ? ll.off[1] : ll.off[2]) + (li << lv) * lds_stride(C) + qo, r, doit);
     else atomic_add4(GL, (size_t)(li << lv) * C + qo, r, doit);
   }
   dx0 += pi == 1 ? gcx : gcl;   // plane 1 = (x, z | y), 2 = (y, z | x)
@@ -1101,17 +1130,18 @@ struct ScatterArgs {
   int dxw_accumulate;
   float* g_xyz;        // static field: g_xyz += dw * inv (nullable)
   int lds_bytes;       // dynamic LDS for the line accumulators (0: lines go to global memory)
+  int lds_f64;         // the accumulators are doubles (ds_add_f64: 11 x the update rate of ds_add_f32) / floats
   int bcast;           // 1: every component's gradient is row 0 of the tile (static density: the
                        //    feature is the plain sum of the 24 products)
 };
 
 template <int C0Q, int C1Q, int NQ>
 __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
-  extern __shared__ float lacc[];
+  extern __shared__ __attribute__((aligned(16))) float lacc[];
   const int nl0 = lines_floats(a.vm[0]), nl1 = a.nsets > 1 ? lines_floats(a.vm[1]) : 0;
-  const bool use_lacc = a.lds_bytes > 0;   // host: (nl0 + nl1) * 4 if it fits SC_LINES_MAX_BYTES, else 0
+  const bool use_lacc = a.lds_bytes > 0;   // host: (nl0 + nl1) elements of 8 (lds_f64) or 4 bytes if they fit SC_LINES_MAX_BYTES, else 0
   if (use_lacc)
-    for (int i = threadIdx.x; i < nl0 + nl1; i += blockDim.x) lacc[i] = 0.f;
+    for (int i = threadIdx.x; i < (nl0 + nl1) * (a.lds_f64 ? 2 : 1); i += blockDim.x) lacc[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -1148,7 +1178,7 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
     float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
     for (int set = 0; set < a.nsets; ++set) {
       const float* rb = a.rows + ((size_t)t * a.stride + a.row0[set]) * 32;
-      const LdsLines ll = make_lds_lines(use_lacc ? lacc + (set ? nl0 : 0) : nullptr, a.vm[set]);
+      const LdsLines ll = make_lds_lines(use_lacc ? lacc : nullptr, set ? nl0 : 0, a.lds_f64, a.vm[set]);
 #ifndef RDRF_SC_UNROLL
 #define RDRF_SC_UNROLL 1
 #endif
@@ -1217,8 +1247,8 @@ __global__ __launch_bounds__(512, 3) void k_scatter(ScatterArgs a) {
   }
   if (use_lacc) {
     __syncthreads();
-    flush_lds_lines(lacc, a.vm[0], a.gvm[0]);
-    if (a.nsets > 1) flush_lds_lines(lacc + nl0, a.vm[1], a.gvm[1]);
+    flush_lds_lines(lacc, a.lds_f64, 0, a.vm[0], a.gvm[0]);
+    if (a.nsets > 1) flush_lds_lines(lacc, a.lds_f64, nl0, a.vm[1], a.gvm[1]);
   }
 }
 
@@ -1300,6 +1330,9 @@ __global__ void k_sort_counts(const unsigned* __restrict__ keys_sorted, int NS, 
   counts[p] = lo;
 }
 
+#ifndef RDRF_LINE_DIRECT_DEFAULT
+#define RDRF_LINE_DIRECT_DEFAULT 1   // measured: -0.1 ms / step on top of the double accumulators (profiles/r05_ab_lds_f64.txt)
+#endif
 struct SortedScatterArgs {
   RdrfVM vm[2], gvm[2];
   int set_mask;            // bit k: set k has a gradient
@@ -1311,18 +1344,20 @@ struct SortedScatterArgs {
   const int* list;         // appearance: entry e is compacted sample e, its sample id is list[e]; nullptr: entry = sample id
   const float* xw;
   float* dxw;              // += coordinate gradients
-  int lds_bytes;
+  int lds_bytes, lds_f64;  // line accumulator of this pass in LDS: bytes (0: global atomics), doubles / floats
+  int line_direct;         // no run reduction in front of the LDS line updates (see LdsLines::direct)
 };
 
 // C0Q / C1Q: quads of an XY / XZ-YZ texel: <4, 1> density and blending ({16,4,4} components, two sets per record),
 // <12, 3> appearance ({48,12,12}, one set, entries = the compacted list)
 template <int PLANE, int C0Q, int C1Q>
 __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) {
-  extern __shared__ float lacc[];
-  const int nl0 = lines_floats(a.vm[0]), nl1 = lines_floats(a.vm[1]);
+  extern __shared__ __attribute__((aligned(16))) float lacc[];
+  // pass PLANE touches line PLANE only (the partner of its plane): one line per factor set in the accumulator
+  const int nl0 = a.vm[0].L[PLANE] * lds_stride(a.vm[0].C[PLANE]), nl1 = a.vm[1].L[PLANE] * lds_stride(a.vm[1].C[PLANE]);
   const bool use_lacc = a.lds_bytes > 0;
   if (use_lacc)
-    for (int i = threadIdx.x; i < nl0 + nl1; i += blockDim.x) lacc[i] = 0.f;
+    for (int i = threadIdx.x; i < (nl0 + nl1) * (a.lds_f64 ? 2 : 1); i += blockDim.x) lacc[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31, q = lane >> 4, s16 = lane & 15;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -1341,7 +1376,8 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
 #pragma unroll 1
     for (int set = 0; set < 2; ++set) {
       if (!((a.set_mask >> set) & 1)) continue;
-      const LdsLines ll = make_lds_lines(use_lacc ? lacc + (set ? nl0 : 0) : nullptr, a.vm[set]);
+      const int first = set ? nl0 : 0;
+      const LdsLines ll = LdsLines{use_lacc ? lacc : nullptr, {first, first, first}, a.lds_f64, a.line_direct};
       const float* rec = a.dfs + (size_t)ent * a.rec_floats + set * SETF;
 #pragma unroll 1
       for (int lv = 0; lv < 3; ++lv) {
@@ -1371,8 +1407,8 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
   }
   if (use_lacc) {
     __syncthreads();
-    flush_lds_lines(lacc, a.vm[0], a.gvm[0]);
-    flush_lds_lines(lacc + nl0, a.vm[1], a.gvm[1]);
+    if (a.set_mask & 1) flush_lds_line(lacc, a.lds_f64, 0, a.vm[0].L[PLANE], a.vm[0].C[PLANE], a.gvm[0].line[PLANE]);
+    if (a.set_mask & 2) flush_lds_line(lacc, a.lds_f64, nl0, a.vm[1].L[PLANE], a.vm[1].C[PLANE], a.gvm[1].line[PLANE]);
   }
 }
 
@@ -2316,9 +2352,21 @@ static int lines_floats_host(const RdrfVM& vm) {
 // dynamic LDS (the attribute call is needed above 64 KB and is idempotent)
 template <typename K>
 static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles, hipStream_t stream) {
-  const long bytes = 4L * (lines_floats_host(sa.vm[0]) + (sa.nsets > 1 ? lines_floats_host(sa.vm[1]) : 0));
-  if (sa.nsets == 2 && bytes > SC_LINES_MAX_BYTES && 4L * lines_floats_host(sa.vm[0]) <= SC_LINES_MAX_BYTES &&
-      4L * lines_floats_host(sa.vm[1]) <= SC_LINES_MAX_BYTES) {
+  const long n0 = lines_floats_host(sa.vm[0]), n1 = sa.nsets > 1 ? lines_floats_host(sa.vm[1]) : 0;
+  // element type of the accumulators: doubles when they fit (ds_add_f64 retires 11 x the updates of ds_add_f32, see
+  // LdsLines), also at the price of one launch per factor set; floats for lines too long for that; else global atomics
+  static const int f64_env = RDRF_ENV("RDRF_LDS_F64") ? atoi(RDRF_ENV("RDRF_LDS_F64")) : 1;   // 0: floats (tools build, A/B)
+  int esz = 0;
+  bool split = false;
+  for (int e = f64_env ? 8 : 4; e >= 4 && !esz; e -= 4) {
+    if (e * (n0 + n1) <= SC_LINES_MAX_BYTES) esz = e;
+    else if (sa.nsets == 2 && e * n0 <= SC_LINES_MAX_BYTES && e * n1 <= SC_LINES_MAX_BYTES) { esz = e; split = true; }
+  }
+#ifdef RDRF_DETERMINISTIC
+  esz = 0;   // the LDS accumulators add in wave-arrival order: the line gradients go straight to the fixed-point shadow
+  split = false;
+#endif
+  if (split) {
     // the two factor sets do not fit the LDS together but each does alone: one launch per set
     ScatterArgs s0 = sa, s1 = sa;
     s0.nsets = 1;
@@ -2328,17 +2376,19 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
     int rc = launch_scatter(name, kern, s0, ntiles, stream);
     return rc ? rc : launch_scatter(name, kern, s1, ntiles, stream);
   }
-  sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
-#ifdef RDRF_DETERMINISTIC
-  sa.lds_bytes = 0;   // the fp32 LDS accumulators add in wave-arrival order: the line gradients go straight to the shadow
-#endif
+  sa.lds_bytes = (int)(esz * (n0 + n1));
+  sa.lds_f64 = esz == 8;
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
-  const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;   // one big workgroup per CU vs. two or three
+  // workgroups per CU that the accumulators leave room for (160 KB of LDS): one big workgroup, or two / three of 256
+  // threads; the grid never exceeds what is resident at once (the tile loop is a static stride: a workgroup that starts
+  // after the others have finished would run its share alone)
+  const int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : (sa.lds_bytes > 53 * 1024 ? 2 : 3);
+  const int threads = per_cu == 1 ? 512 : 256;
   const int wpb = threads / 64;
   long g = (ntiles + wpb - 1) / wpb;
   static const long cap_env = RDRF_ENV("RDRF_SC_CAP") ? atol(RDRF_ENV("RDRF_SC_CAP")) : 0;   // experiments (tools build)
-  const long cap = threads == 512 ? 256 : (cap_env > 0 ? cap_env : 768);
+  const long cap = per_cu == 1 ? 256 : (cap_env > 0 ? cap_env : 256 * per_cu);
   g = g < 1 ? 1 : (g > cap ? cap : g);
   rdrf_prof_begin(name, stream);
   hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(threads), (size_t)sa.lds_bytes, stream, sa);
@@ -2371,18 +2421,28 @@ static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
 
 template <int PLANE, int C0Q, int C1Q>
 static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStream_t stream) {
-  const long bytes = 4L * (lines_floats_host(sa.vm[0]) + lines_floats_host(sa.vm[1]));
-  sa.lds_bytes = bytes <= SC_LINES_MAX_BYTES ? (int)bytes : 0;
+  // pass PLANE accumulates line PLANE only: L x (C + 4) elements per factor set, doubles when they fit (see LdsLines)
+  const long n = (long)sa.vm[0].L[PLANE] * (sa.vm[0].C[PLANE] + 4) + (long)sa.vm[1].L[PLANE] * (sa.vm[1].C[PLANE] + 4);
+  static const int f64_env = RDRF_ENV("RDRF_LDS_F64") ? atoi(RDRF_ENV("RDRF_LDS_F64")) : 1;   // 0: floats (tools build, A/B)
+  const int esz = (f64_env && 8 * n <= SC_LINES_MAX_BYTES) ? 8 : (4 * n <= SC_LINES_MAX_BYTES ? 4 : 0);
+  sa.lds_bytes = (int)(esz * n);
+  sa.lds_f64 = esz == 8;
+  static const int direct_env = RDRF_ENV("RDRF_LINE_DIRECT") ? atoi(RDRF_ENV("RDRF_LINE_DIRECT")) : RDRF_LINE_DIRECT_DEFAULT;
+  sa.line_direct = sa.lds_f64 && direct_env;
 #ifdef RDRF_DETERMINISTIC
   sa.lds_bytes = 0;
 #endif
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_sorted<PLANE, C0Q, C1Q>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
-  const int threads = sa.lds_bytes > 80 * 1024 ? 512 : 256;
+  int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : (sa.lds_bytes > 53 * 1024 ? 2 : 3);   // see launch_scatter
+  int threads = per_cu == 1 ? 512 : 256;
+  static const int thr_env = RDRF_ENV("RDRF_SS_THREADS") ? atoi(RDRF_ENV("RDRF_SS_THREADS")) : 0;   // experiments (tools build)
+  static const int pcu_env = RDRF_ENV("RDRF_SS_PER_CU") ? atoi(RDRF_ENV("RDRF_SS_PER_CU")) : 0;
+  if (thr_env > 0 && pcu_env > 0 && (long)pcu_env * sa.lds_bytes <= 160 * 1024) { threads = thr_env; per_cu = pcu_env; }
   const int wpb = threads / 64;
   const long ntiles = (max_samples + (PLANE == 0 ? 15 : 31)) / (PLANE == 0 ? 16 : 32);
   long g = (ntiles + wpb - 1) / wpb;
-  const long cap = threads == 512 ? 256 : 768;
+  const long cap = 256 * per_cu;
   g = g < 1 ? 1 : (g > cap ? cap : g);
   static const char* names[3] = {"scatter_sorted_xy", "scatter_sorted_xz", "scatter_sorted_yz"};
   rdrf_prof_begin(names[PLANE], stream);
