@@ -324,6 +324,40 @@ RDRF_D void flush_lds_lines(const float* acc, int f64, int first, const RdrfVM& 
   }
 }
 
+// LDS tile of one factor set's gradient PLANE for the chunk of plane cells a workgroup of the tiled sorted scatter is
+// working on (k_scatter_tiled): per stride level a small window [y0, y0 + ny) x [x0, x0 + nx) of that level's sub-grid,
+// `C` doubles per texel.  A tap inside the window is a ds_add_f64 (18 cycles per 64-lane instruction); a tap outside it
+// (entries whose key was clamped, float rounding at a window edge) takes the global atomic as before -- the window only
+// decides WHERE a sum is formed, never whether.  geo (LDS, written once per chunk): [lv][0..4] = x0, y0, nx, ny, element
+// offset of the level's window inside `base`.
+struct PlaneTile {
+  float* base;      // LDS, holds doubles (nullptr: no tile)
+  const int* geo;   // LDS
+  int C;
+};
+RDRF_D void lds_add4_f64(float* base, int addr, f32x4 v, bool ok) {
+  LdsLines l;
+  l.base = base; l.f64 = 1; l.direct = 0; l.off[0] = l.off[1] = l.off[2] = 0;
+  lds_add4(l, addr, v, ok);
+}
+template <bool TILED>
+RDRF_D void plane_add4(const PlaneTile& T, int lv, int ixs, int iys, int qo, float* GP, size_t goff, f32x4 v, bool ok) {
+  if constexpr (!TILED) {
+    atomic_add4(GP, goff, v, ok);
+  } else {
+    // the window of this level: five wave-uniform ints, moved to scalar registers (a VGPR copy per tap would wait for the
+    // LDS atomics in front of it: lgkmcnt is in-order)
+    const int* g = T.geo + lv * 8;
+    const int gx0 = __builtin_amdgcn_readfirstlane(g[0]), gy0 = __builtin_amdgcn_readfirstlane(g[1]);
+    const int gnx = __builtin_amdgcn_readfirstlane(g[2]), gny = __builtin_amdgcn_readfirstlane(g[3]);
+    const int gof = __builtin_amdgcn_readfirstlane(g[4]);
+    const int dx = ixs - gx0, dy = iys - gy0;
+    const bool in = ok && (unsigned)dx < (unsigned)gnx && (unsigned)dy < (unsigned)gny;
+    lds_add4_f64(T.base, gof + (dy * gnx + dx) * T.C + qo, v, in);
+    atomic_add4(GP, goff, v, ok && !in);
+  }
+}
+
 template <int C0Q, int C1Q, int MODE>
 RDRF_D void gather_quad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, float x0, float x1,
                             float x2, f32x4 dq, bool live, int s, float& dx0, float& dx1,
@@ -524,10 +558,10 @@ RDRF_D f32x4 shfl4_row(f32x4 v, int src_lane) {
   r.z = __shfl(v.z, src_lane, 64); r.w = __shfl(v.w, src_lane, 64);
   return r;
 }
-template <int C0Q, int C1Q>
+template <int C0Q, int C1Q, bool TILED = false>
 RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, float x0, float x1, float x2,
                            f32x4 dq, bool live, bool q_is_owner, float& dx0, float& dx1, float& dx2,
-                           const LdsLines ll) {
+                           const LdsLines ll, const PlaneTile T = PlaneTile{nullptr, nullptr, 0}) {
   const int lane = threadIdx.x & 63, s16 = lane & 15, rowbase = lane & ~15;
   const float* P = vm.plane[0];
   const float* Lp = vm.line[0];
@@ -603,10 +637,10 @@ RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, 
     else if (din == -65536) { r10 = r10 + pA; r11 = r11 + pB; }
     else if (din == 1) { r00 = r00 + pA; r10 = r10 + pB; }
     else if (din == -1) { r01 = r01 + pA; r11 = r11 + pB; }
-    atomic_add4(GP, o00, r00, pr.tail && g00 && nz4(r00) && !(skip_out & 1));
-    atomic_add4(GP, o01, r01, pr.tail && g01 && nz4(r01) && !(skip_out & 2));
-    atomic_add4(GP, o10, r10, pr.tail && g10 && nz4(r10) && !(skip_out & 4));
-    atomic_add4(GP, o11, r11, pr.tail && g11 && nz4(r11) && !(skip_out & 8));
+    plane_add4<TILED>(T, lv, tx.i0, ty.i0, qo, GP, o00, r00, pr.tail && g00 && nz4(r00) && !(skip_out & 1));
+    plane_add4<TILED>(T, lv, tx.i0 + 1, ty.i0, qo, GP, o01, r01, pr.tail && g01 && nz4(r01) && !(skip_out & 2));
+    plane_add4<TILED>(T, lv, tx.i0, ty.i0 + 1, qo, GP, o10, r10, pr.tail && g10 && nz4(r10) && !(skip_out & 4));
+    plane_add4<TILED>(T, lv, tx.i0 + 1, ty.i0 + 1, qo, GP, o11, r11, pr.tail && g11 && nz4(r11) && !(skip_out & 8));
   }
   {
     const Run lr = run_of16(tl.i0 + 4, s16);
@@ -636,10 +670,10 @@ RDRF_D void gather_xy4_bwd(const RdrfVM& vm, const RdrfVM& gvm, int lv, int q4, 
 // the whole wave, tools/ubench/atomics.hip kernels G/H) makes ONE request of them -- half the atomic
 // requests of the XZ / YZ planes, which were ~1/3 of the density scatter's time.
 // Coordinate gradients are computed by both halves and halved (x*0.5 + x*0.5 is exact).
-template <int C0Q, int C1Q>
+template <int C0Q, int C1Q, bool TILED = false>
 RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, float x0, float x1, float x2,
                              f32x4 dq, bool live, int s, float& dx0, float& dx1, float& dx2,
-                             const LdsLines ll) {
+                             const LdsLines ll, const PlaneTile T = PlaneTile{nullptr, nullptr, 0}) {
   QuadSel<C0Q, C1Q> sl = quad_sel<C0Q, C1Q>(g);
   const int pi = sl.pi;   // 1 or 2 (wave-uniform)
   const float cx = pi == 2 ? x1 : x0;
@@ -697,8 +731,8 @@ RDRF_D void gather_zquad_bwd(const RdrfVM& vm, const RdrfVM& gvm, int g, int h, 
   if (chain_prev) { r0.x += ux; r0.y += uy; r0.z += uz; r0.w += uw; }
   const int nk = dppi<0x130>(pkey);
   const bool up_ok = !(s < 31 && nk == pkey + (1 << 16));
-  atomic_add4(GP, o0, r0, pr.tail && g0 && nz4(r0));
-  atomic_add4(GP, o1, r1, pr.tail && up_ok && g1 && nz4(r1));
+  plane_add4<TILED>(T, lv, ixc, ty.i0, qo, GP, o0, r0, pr.tail && g0 && nz4(r0));
+  plane_add4<TILED>(T, lv, ixc, ty.i0 + 1, qo, GP, o1, r1, pr.tail && up_ok && g1 && nz4(r1));
   // line tap h
   if (ll.base && ll.direct) {
     const bool okl = live && (h ? tl.ok1 : tl.ok0);
@@ -1346,6 +1380,10 @@ struct SortedScatterArgs {
   float* dxw;              // += coordinate gradients
   int lds_bytes, lds_f64;  // line accumulator of this pass in LDS: bytes (0: global atomics), doubles / floats
   int line_direct;         // no run reduction in front of the LDS line updates (see LdsLines::direct)
+  // k_scatter_tiled: the sorted keys of this plane (a slice's window is anchored at its first key), bits of the cell part
+  // of a key, key-space row length W + 3, window width in cells, wave steps per slice, windows allocated (factor sets)
+  const unsigned* keys;
+  int kb, Wk, tw, slice_steps, tile_sets;
 };
 
 // C0Q / C1Q: quads of an XY / XZ-YZ texel: <4, 1> density and blending ({16,4,4} components, two sets per record),
@@ -1410,6 +1448,131 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
     if (a.set_mask & 1) flush_lds_line(lacc, a.lds_f64, 0, a.vm[0].L[PLANE], a.vm[0].C[PLANE], a.gvm[0].line[PLANE]);
     if (a.set_mask & 2) flush_lds_line(lacc, a.lds_f64, nl0, a.vm[1].L[PLANE], a.vm[1].C[PLANE], a.gvm[1].line[PLANE]);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TILED sorted scatter.  After the LDS line accumulators became doubles (ds_add_f64), what was left of the sorted passes
+// was their memory-side plane atomics: 1.08 of 1.85 ms per step for the density / blending scatter (ablation builds,
+// profiles/r05_scatter_ablation.txt) although the sort had already cut the REQUESTS tenfold -- every run tail still pays a
+// round trip to the memory side, and vmcnt is one in-order counter, so the next gathers wait behind it.  Neighbouring
+// plane cells are neighbours in the sorted array, so a SLICE of consecutive sorted entries (slice_steps wave steps of
+// one workgroup) touches a window of ~(tw + 1) x 2 texels per stride level, anchored at the slice's first cell: the
+// window lives in LDS as doubles, the run tails add into it with ds_add_f64, and the workgroup flushes it with one
+// coalesced sweep (64-byte texels = one request per 16 lanes).  Slices have equal size (static stride over the workgroups:
+// the load is balanced by construction; windows by CELL ranges with a dynamic queue were 2 x slower than the untiled
+// kernel, the ray density per cell varies too much).  Everything per entry (taps, run reduction, cross-run merge,
+// coordinate gradients, line updates) is the code of k_scatter_sorted; only the destination of a plane sum differs
+// (plane_add4), and a tap outside the window (the slice ran into the next key row, a sparse region, a clamped key)
+// still goes to global memory, so the result is the same sum in a different order.
+// ------------------------------------------------------------------------------------------------
+RDRF_HD int tile_texels(int tw) { return (tw + 1) * 2 + (tw / 2 + 3) * 3 + (tw / 4 + 3) * 3; }
+
+template <int PLANE, int C0Q, int C1Q>
+__global__ __launch_bounds__(512, 4) void k_scatter_tiled(SortedScatterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lacc[];   // doubles: [line set 0 | line set 1 | tile set 0 | tile set 1]
+  __shared__ int s_geo[24];
+  constexpr int CT = PLANE == 0 ? 4 * C0Q : 4 * C1Q;   // components per texel of this plane
+  const int nl0 = a.vm[0].L[PLANE] * lds_stride(a.vm[0].C[PLANE]), nl1 = a.vm[1].L[PLANE] * lds_stride(a.vm[1].C[PLANE]);
+  const int tile_elems = tile_texels(a.tw) * CT;
+  for (int i = threadIdx.x; i < (nl0 + nl1 + a.tile_sets * tile_elems) * 2; i += blockDim.x) lacc[i] = 0.f;
+  const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31, q = lane >> 4, s16 = lane & 15;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = *a.count;
+  constexpr int SPT = PLANE == 0 ? 16 : 32;
+  constexpr int XYF = 4 * C0Q, ZF = 4 * C1Q, SETF = 3 * XYF + 6 * ZF, QPL = C0Q + 2 * C1Q;
+  const int W = a.vm[0].W[PLANE], H = a.vm[0].H[PLANE];
+  const unsigned cmask = (1u << a.kb) - 1u;
+  const int E = a.slice_steps * SPT;   // entries per slice
+  for (int sl = blockIdx.x; (long)sl * E < count; sl += gridDim.x) {
+    __syncthreads();   // (first pass: the zero fill; later: the previous slice's flush has read s_geo)
+    const int e_lo = sl * E, e_hi = min(e_lo + E, count);
+    if (threadIdx.x == 0) {   // the slice's windows, one per stride level (PlaneTile), anchored at its first (= smallest) cell
+      const int cell = (int)(a.keys[e_lo] & cmask), r = cell / a.Wk, kx = cell - r * a.Wk;
+      const int ix_lo = kx - 2, ix_hi = min(kx + a.tw, a.Wk) - 3, iy = r - 2;
+      int off = 0;
+      for (int lv = 0; lv < 3; ++lv) {
+        const int st = 1 << lv, Ws = (W + st - 1) >> lv, Hs = (H + st - 1) >> lv;
+        int x0, x1, y0, y1;
+        if (lv == 0) {
+          x0 = max(ix_lo, 0); x1 = min(ix_hi + 1, Ws - 1); y0 = max(iy, 0); y1 = min(iy + 1, Hs - 1);
+        } else {   // f_lv = f_0 (Ws - 1) / (W - 1): the taps of f_0 in [i, j + 1) are floor(i rho) .. floor((j + 1) rho) + 1
+          const float rx = W > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.f, ry = H > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.f;
+          x0 = max((int)floorf((float)ix_lo * rx), 0); x1 = min((int)floorf((float)(ix_hi + 1) * rx) + 1, Ws - 1);
+          y0 = max((int)floorf((float)iy * ry), 0); y1 = min((int)floorf((float)(iy + 1) * ry) + 1, Hs - 1);
+        }
+        const int nxcap = lv == 0 ? a.tw + 1 : (a.tw >> lv) + 3, nycap = lv == 0 ? 2 : 3;
+        const int nx = min(max(x1 - x0 + 1, 0), nxcap), ny = min(max(y1 - y0 + 1, 0), nycap);
+        s_geo[lv * 8 + 0] = x0; s_geo[lv * 8 + 1] = y0; s_geo[lv * 8 + 2] = nx; s_geo[lv * 8 + 3] = ny; s_geo[lv * 8 + 4] = off;
+        off += nx * ny * CT;
+      }
+    }
+    __syncthreads();
+    for (int t = wave; t * SPT < e_hi - e_lo; t += nwaves) {
+      const int pos = e_lo + t * SPT + (PLANE == 0 ? s16 : s);
+      const bool live = pos < e_hi;
+      const int ent = live ? (int)(a.order[pos] - a.base) : 0;
+      const int idx = a.list ? a.list[ent] : ent;
+      const float x0 = a.xw[(size_t)idx * 3 + 0], x1 = a.xw[(size_t)idx * 3 + 1], x2 = a.xw[(size_t)idx * 3 + 2];
+      float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+#pragma unroll 1
+      for (int set = 0; set < 2; ++set) {
+        if (!((a.set_mask >> set) & 1)) continue;
+        const int first = set ? nl0 : 0;
+        const LdsLines ll = LdsLines{lacc, {first, first, first}, 1, a.line_direct};
+        const PlaneTile T = PlaneTile{lacc + 2 * (nl0 + nl1 + set * tile_elems), s_geo, CT};
+        const float* rec = a.dfs + (size_t)ent * a.rec_floats + set * SETF;
+#pragma unroll 1
+        for (int lv = 0; lv < 3; ++lv) {
+          if constexpr (PLANE == 0) {
+#pragma unroll 1
+            for (int grp = 0; grp < C0Q / 4; ++grp) {
+              const f32x4 dq = live ? ld4(rec + lv * XYF + grp * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+              gather_xy4_bwd<C0Q, C1Q, true>(a.vm[set], a.gvm[set], lv, 4 * grp + q, x0, x1, x2, dq, live, q == 0, dw0, dw1, dw2, ll, T);
+            }
+          } else {
+#pragma unroll 1
+            for (int zq = 0; zq < C1Q; ++zq) {
+              const f32x4 dq = live ? ld4(rec + 3 * XYF + (PLANE - 1) * 3 * ZF + lv * ZF + 4 * zq) : f32x4{0.f, 0.f, 0.f, 0.f};
+              gather_zquad_bwd<C0Q, C1Q, true>(a.vm[set], a.gvm[set], lv * QPL + C0Q + (PLANE - 1) * C1Q + zq, h, x0, x1, x2, dq, live, s,
+                                               dw0, dw1, dw2, ll, T);
+            }
+          }
+        }
+      }
+      if constexpr (PLANE != 0) {
+        dw0 += __shfl_xor(dw0, 32, 64); dw1 += __shfl_xor(dw1, 32, 64); dw2 += __shfl_xor(dw2, 32, 64);
+      }
+      if (live && (PLANE == 0 ? q == 0 : h == 0)) {
+        float* d = a.dxw + (size_t)idx * 3;
+        d[0] += dw0; d[1] += dw1; d[2] += dw2;
+      }
+    }
+    __syncthreads();
+    // flush the windows: component fastest, so 16 consecutive lanes cover one 64-byte texel (one request); the slots are
+    // left zeroed for the next chunk
+#pragma unroll 1
+    for (int set = 0; set < 2; ++set) {
+      if (!((a.set_mask >> set) & 1)) continue;
+      double* tile = reinterpret_cast<double*>(lacc) + nl0 + nl1 + set * tile_elems;
+      float* GP = a.gvm[set].plane[PLANE];
+      const int sH = a.vm[set].sH[PLANE], sW = a.vm[set].sW[PLANE];
+      for (int lv = 0; lv < 3; ++lv) {
+        const int gx0 = s_geo[lv * 8 + 0], gy0 = s_geo[lv * 8 + 1], nx = s_geo[lv * 8 + 2], ny = s_geo[lv * 8 + 3], off = s_geo[lv * 8 + 4];
+        const int n = nx * ny * CT;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+          const double v = tile[off + i];
+          if (v != 0.0) {
+            tile[off + i] = 0.0;
+            const int t = i / CT, cc = i - t * CT, ty = t / nx, tx = t - ty * nx;
+            grad_add(GP + (size_t)(((gy0 + ty) << lv) * sH + ((gx0 + tx) << lv) * sW) + cc, (float)v);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.set_mask & 1) flush_lds_line(lacc, 1, 0, a.vm[0].L[PLANE], a.vm[0].C[PLANE], a.gvm[0].line[PLANE]);
+  if (a.set_mask & 2) flush_lds_line(lacc, 1, nl0, a.vm[1].L[PLANE], a.vm[1].C[PLANE], a.gvm[1].line[PLANE]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2434,8 +2597,10 @@ static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStr
 #endif
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_sorted<PLANE, C0Q, C1Q>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
-  int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : (sa.lds_bytes > 53 * 1024 ? 2 : 3);   // see launch_scatter
-  int threads = per_cu == 1 ? 512 : 256;
+  // 512 threads x 2 workgroups per CU = 4 waves per SIMD (the kernels need <= 116 VGPRs): 12.16 -> 11.98 ms / step against
+  // 256 x 3 (profiles/r05_ab_sorted_occupancy.txt); one workgroup per CU when the accumulators take more than half the LDS
+  int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : 2;
+  int threads = 512;
   static const int thr_env = RDRF_ENV("RDRF_SS_THREADS") ? atoi(RDRF_ENV("RDRF_SS_THREADS")) : 0;   // experiments (tools build)
   static const int pcu_env = RDRF_ENV("RDRF_SS_PER_CU") ? atoi(RDRF_ENV("RDRF_SS_PER_CU")) : 0;
   if (thr_env > 0 && pcu_env > 0 && (long)pcu_env * sa.lds_bytes <= 160 * 1024) { threads = thr_env; per_cu = pcu_env; }
@@ -2450,6 +2615,51 @@ static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStr
   rdrf_prof_end(names[PLANE], stream);
   RDRF_HIP(hipGetLastError());
   return 0;
+}
+
+// the tiled form of pass PLANE (k_scatter_tiled) when its line accumulators and plane windows fit the LDS as doubles;
+// returns 1 if it was launched, 0 if the caller should take k_scatter_sorted, < 0 on error
+#ifndef RDRF_SS_TILED_DEFAULT
+#define RDRF_SS_TILED_DEFAULT 1
+#endif
+template <int PLANE, int C0Q, int C1Q>
+static int launch_scatter_tiled(SortedScatterArgs& sa, const unsigned* keys_sorted, int kb, long max_samples, hipStream_t stream) {
+#ifdef RDRF_DETERMINISTIC
+  return 0;   // LDS sums form in wave-arrival order
+#endif
+  static const int tiled_env = RDRF_ENV("RDRF_SS_TILED") ? atoi(RDRF_ENV("RDRF_SS_TILED")) : RDRF_SS_TILED_DEFAULT;
+  if (!tiled_env) return 0;
+  static const int tw_env = RDRF_ENV("RDRF_SS_TW") ? atoi(RDRF_ENV("RDRF_SS_TW")) : 0;
+  static const int steps_env = RDRF_ENV("RDRF_SS_STEPS") ? atoi(RDRF_ENV("RDRF_SS_STEPS")) : 0;
+  constexpr int CT = PLANE == 0 ? 4 * C0Q : 4 * C1Q;
+  int tw = tw_env > 0 ? tw_env : (CT > 16 ? 16 : 32);   // 48-component texels: narrower windows keep two workgroups per CU
+  tw = (tw < 8 ? 8 : (tw > 128 ? 128 : tw)) & ~3;
+  const long n = (long)sa.vm[0].L[PLANE] * (sa.vm[0].C[PLANE] + 4) + (long)sa.vm[1].L[PLANE] * (sa.vm[1].C[PLANE] + 4);
+  sa.tile_sets = (sa.set_mask & 2) ? 2 : 1;
+  const long bytes = 8L * (n + (long)sa.tile_sets * tile_texels(tw) * CT);
+  // only where two 512-thread workgroups per CU still fit (at the final grids the z lines of two factor sets alone take
+  // 70 KB: one workgroup per CU lost more than the windows gained, 3.46 -> 3.97 ms) and for the 16- / 4-component texels
+  // of the density / blending sets (the 48-component appearance windows gained nothing: 0.71 -> 0.71 ms)
+  static const long max_env = RDRF_ENV("RDRF_SS_TILED_MAXB") ? atol(RDRF_ENV("RDRF_SS_TILED_MAXB")) : 80 * 1024;
+  if (bytes > max_env || (C0Q > 4 && tiled_env < 2)) return 0;
+  sa.lds_bytes = (int)bytes; sa.lds_f64 = 1;
+  static const int direct_env = RDRF_ENV("RDRF_LINE_DIRECT") ? atoi(RDRF_ENV("RDRF_LINE_DIRECT")) : RDRF_LINE_DIRECT_DEFAULT;
+  sa.line_direct = direct_env;
+  sa.keys = keys_sorted; sa.kb = kb; sa.tw = tw;
+  sa.slice_steps = steps_env > 0 ? steps_env : 16;   // 2 steps for each of the 8 waves (16: 1.51, 32: 1.55, 64: 1.68 ms / step)
+  sa.Wk = sa.vm[0].W[PLANE] + 3;
+  if (sa.lds_bytes > 48 * 1024)
+    RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_tiled<PLANE, C0Q, C1Q>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
+  const int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : 2;   // 512-thread workgroups, 4 waves per SIMD (__launch_bounds__(512, 4): HIP counts waves per SIMD)
+  const long nslices = (max_samples + (long)sa.slice_steps * (PLANE == 0 ? 16 : 32) - 1) / ((long)sa.slice_steps * (PLANE == 0 ? 16 : 32));
+  long g = nslices < 256L * per_cu ? nslices : 256L * per_cu;
+  g = g < 1 ? 1 : g;
+  static const char* names[3] = {"scatter_tiled_xy", "scatter_tiled_xz", "scatter_tiled_yz"};
+  rdrf_prof_begin(names[PLANE], stream);
+  hipLaunchKernelGGL((k_scatter_tiled<PLANE, C0Q, C1Q>), dim3((unsigned)g), dim3(512), (size_t)sa.lds_bytes, stream, sa);
+  rdrf_prof_end(names[PLANE], stream);
+  RDRF_HIP(hipGetLastError());
+  return 1;
 }
 
 // keys of the entries (all samples, or the compacted list), stable sort by (plane | cell), live counts per plane
@@ -2499,6 +2709,12 @@ static int scatter_dyn_app_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDy
   sa.set_mask = 1; sa.dfs = b.dfa; sa.rec_floats = DFA_FLOATS; sa.list = a.sp.list; sa.xw = a.sp.xw; sa.dxw = b.dxw;
   for (int p = 0; p < 3; ++p) {
     sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
+    const unsigned* ks = b.keys_out + (size_t)p * ns;
+    rc = p == 0 ? launch_scatter_tiled<0, 12, 3>(sa, ks, ka.kb, (long)ns, stream)
+                : (p == 1 ? launch_scatter_tiled<1, 12, 3>(sa, ks, ka.kb, (long)ns, stream)
+                          : launch_scatter_tiled<2, 12, 3>(sa, ks, ka.kb, (long)ns, stream));
+    if (rc < 0) return rc;
+    if (rc == 1) continue;
     rc = p == 0 ? launch_scatter_sorted<0, 12, 3>(sa, (long)ns, stream)
                 : (p == 1 ? launch_scatter_sorted<1, 12, 3>(sa, (long)ns, stream) : launch_scatter_sorted<2, 12, 3>(sa, (long)ns, stream));
     if (rc) return rc;
@@ -2524,6 +2740,12 @@ static int scatter_dyn_density_sorted(const BwdArgs& a, const BwdWs& b, const Rd
   sa.set_mask = set_mask; sa.dfs = b.dfs; sa.rec_floats = DFS_FLOATS; sa.xw = a.sp.xw; sa.dxw = b.dxw;
   for (int p = 0; p < 3; ++p) {
     sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
+    const unsigned* ks = b.keys_out + (size_t)p * ns;
+    rc = p == 0 ? launch_scatter_tiled<0, 4, 1>(sa, ks, ka.kb, (long)ns, stream)
+                : (p == 1 ? launch_scatter_tiled<1, 4, 1>(sa, ks, ka.kb, (long)ns, stream)
+                          : launch_scatter_tiled<2, 4, 1>(sa, ks, ka.kb, (long)ns, stream));
+    if (rc < 0) return rc;
+    if (rc == 1) continue;
     rc = p == 0 ? launch_scatter_sorted<0, 4, 1>(sa, (long)ns, stream)
                 : (p == 1 ? launch_scatter_sorted<1, 4, 1>(sa, (long)ns, stream) : launch_scatter_sorted<2, 4, 1>(sa, (long)ns, stream));
     if (rc) return rc;
