@@ -44,11 +44,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak (~6.3 TB/s achievable)
 PEAK_L2_GBS = 34500.0                      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 L2_ATOMIC_REQ_PER_S = 20.8e9               # tools/ubench/atomics.hip: fp32 atomic requests the L2 retires
-PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r04")
+PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r05")
 
 
 def _profile_csv(name):
-    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
+    for tag in (PROFILE_TAG, "r04", "r03", "r02", "r01"):
         fn = os.path.join(ROOT, "profiles", f"{tag}_{name}.csv")
         if os.path.exists(fn):
             return fn, tag
@@ -331,7 +331,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
     sc_b = sum(sc_step_bytes[k] for k in sc_keys)
     # PMC figures of the whole k_scatter family (ray-tile and sorted kernels, all factor sets) per step of the committed
     # profile, set against this run's family time
-    fam = ("void k_scatter<", "void k_scatter_sorted<")
+    fam = ("void k_scatter<", "void k_scatter_sorted<", "void k_scatter_tiled<")
     f_, w_ = pmc_family_per_step("pmc_fetch", fam, "FETCH_SIZE"), pmc_family_per_step("pmc_write", fam, "WRITE_SIZE")
     tr_step = None if (f_ is None or w_ is None) else f_ * 1024.0 * 2.0 + w_ * 1024.0
     atom = pmc_family_per_step("sq_counters", fam, "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
@@ -342,7 +342,8 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         "l2_atomic_frac": None if atom is None else atom / (sc_ms * 1e-3) / L2_ATOMIC_REQ_PER_S,
         "kernel": "k_scatter", "ms_per_step": sc_ms, "kernel_avg_us": sc_ms / sc_launch * 1e3,
         "launches_per_step": sc_launch, "algorithmic_bytes_per_launch": sc_b / sc_launch,
-        "bound_physical": "memory-side fp32 atomic requests + LDS line atomics (not HBM: the gathered bytes are cache resident)",
+        "bound_physical": "gather latency + the in-register run reduction; plane sums form in LDS windows (ds_add_f64) and reach the memory "
+                          "side once per window, line sums in LDS doubles (not HBM: the gathered bytes are cache resident)",
         "frac_l2": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_L2_GBS,
         # the same time priced with round 2's byte count (both factor sets of the dynamic field in every pass, whether
         # or not the blending head receives a gradient): comparable with BENCH_r02's frac
@@ -351,12 +352,12 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         "source": {"achieved / ms_per_step / kernel_avg_us": "HIP events, this run",
                    "traffic / hbm_real / l2_atomic_frac": f"profiles/{_profile_csv('pmc_fetch')[1]}_*.csv (committed rocprofv3 PMC "
                                                           "summaries of the same command, not re-measured in this run)"},
-        "limiter": "memory-side fp32-atomic request rate (~20.8 G requests/s, tools/ubench/atomics.hip) and ds_add_f32 "
-                   "(~150 cycles per wave instruction): `frac` is NOMINAL (algorithmic bytes / time against the HBM peak; "
-                   "the contract offers hbm | mfma); hbm_real = PMC bytes / time, l2_atomic_frac = atomic requests / "
-                   "time / 20.8 G/s, both over all launches of the k_scatter family in a step, and frac_l2 (against the "
-                   "34.5 TB/s L2) are the physical figures; launches of >= 300 k samples take the sorted kernels "
-                   "(~10x fewer requests)"}
+        "limiter": "`frac` is NOMINAL (algorithmic bytes / time against the HBM peak; the contract offers hbm | mfma): the bytes are "
+                   "L2 / MALL resident.  Physical figures: hbm_real = PMC bytes / time, l2_atomic_frac = memory-side atomic requests "
+                   "/ time / 20.8 G/s, both over all launches of the k_scatter family in a step of the committed profile, frac_l2 against "
+                   "the 34.5 TB/s L2.  Launches of >= 300 k samples take the sorted kernels; their density / blending passes form the "
+                   "plane sums in LDS windows of doubles (k_scatter_tiled), every LDS accumulator is a double (ds_add_f64: 11 x the "
+                   "update rate of ds_add_f32, tools/micro/lds_atomic_rate.hip)"}
     dom_e, oth_e = (sc_entry, dw_entry) if (not dw_keys or sc_ms >= dw_ms) else (dw_entry, sc_entry)
     dom_e = dict(dom_e)
     dom_e["note"] = ("the kernel family with the most time per step; its `frac` is NOMINAL where the bytes are cache resident "

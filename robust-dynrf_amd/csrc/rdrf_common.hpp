@@ -182,6 +182,9 @@ RDRF_D void mfma_seg(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __r
   f32x4 wc[NBO], wn[NBO];
 #pragma unroll
   for (int nb = 0; nb < NBO; ++nb) wc[nb] = *(const f32x4*)(wp + (((nb * K4) * 64 + lane) << 2));
+#ifdef RDRF_MFMA_PRIO
+  __builtin_amdgcn_s_setprio(RDRF_MFMA_PRIO);   // experiment: the wave in its MFMA chain wins the issue arbitration
+#endif
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) {
     if (k4 + 1 < K4) {
@@ -203,6 +206,9 @@ RDRF_D void mfma_seg(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __r
       for (int nb = 0; nb < NBO; ++nb) wc[nb] = wn[nb];
     }
   }
+#ifdef RDRF_MFMA_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // accumulator init from a PACKED bias ([2 halves][NBO*16] in canonical order; nullptr = zero)
