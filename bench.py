@@ -268,7 +268,8 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         msk, n = prof_get(L, k)
         if n:
             table[k] = {"ms_per_step": msk / NP, "launches_per_step": n / NP, "avg_us": msk / n * 1e3}
-            tot_ms += msk / NP
+            if k != "sort":   # the radix sort runs INSIDE the scatter_dyn_* ranges (csrc: sorted_scatter_prepare): listed, not added twice
+                tot_ms += msk / NP
     # passes per step each kernel family processes (its launches unless step.ray_passes batches them)
     mult = {k: v["launches_per_step"] for k, v in table.items()}
     for k in ("static_density", "static_app"):
@@ -386,6 +387,10 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         "ray_passes_per_step": {"static": np_stat, "static_with_grad": np_stat_g, "dynamic": np_dyn,
                                 "dynamic_with_grad": np_dyn_bwd},
         "sum_kernel_ms_per_step": tot_ms,
+        # the scatter family as one figure: every scatter_* range (the dynamic field's ranges contain their key generation
+        # and radix sort, reported once more as `sort` for reference)
+        "scatter_family_ms_per_step": sum(v["ms_per_step"] for k, v in table.items() if k.startswith("scatter_")),
+        "sort_ms_per_step_nested_in_scatter": table.get("sort", {}).get("ms_per_step", 0.0),
         "profiled_steps": NP,
         "profiled_window": ("iterations warmup .. warmup + steps of a fresh trainer: the states of the timed region"
                             if window is not None else "3 iterations at the trainer's current state"),

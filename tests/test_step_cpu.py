@@ -54,13 +54,13 @@ def test_bench_reads_the_committed_pmc_summaries():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    fam = ("void k_scatter<", "void k_scatter_sorted<")
+    fam = ("void k_scatter<", "void k_scatter_sorted<", "void k_scatter_tiled<")
     fetch = bench.pmc_family_per_step("pmc_fetch", fam, "FETCH_SIZE")
     write = bench.pmc_family_per_step("pmc_write", fam, "WRITE_SIZE")
     atom = bench.pmc_family_per_step("sq_counters", fam, "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
     assert fetch and write and atom
     assert 1e5 < fetch < 1e7 and 1e5 < write < 1e7          # KB per training step
-    assert 1e7 < atom < 1e8                                 # memory-side atomic requests per training step
+    assert 1e6 < atom < 1e8                                 # memory-side atomic requests per training step (r05: 6.8 M)
     dw = bench.pmc_traffic("k_dw2")
     assert dw and 1e8 < dw < 1e10                           # bytes per launch
     assert bench._profile_csv("pmc_fetch")[1] == bench.PROFILE_TAG
