@@ -1392,7 +1392,8 @@ template <int PLANE, int C0Q, int C1Q>
 __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lacc[];
   // pass PLANE touches line PLANE only (the partner of its plane): one line per factor set in the accumulator
-  const int nl0 = a.vm[0].L[PLANE] * lds_stride(a.vm[0].C[PLANE]), nl1 = a.vm[1].L[PLANE] * lds_stride(a.vm[1].C[PLANE]);
+  const int nl0 = (a.set_mask & 1) ? a.vm[0].L[PLANE] * lds_stride(a.vm[0].C[PLANE]) : 0;   // (no accumulator for a factor set
+  const int nl1 = (a.set_mask & 2) ? a.vm[1].L[PLANE] * lds_stride(a.vm[1].C[PLANE]) : 0;   //  without a gradient in this launch)
   const bool use_lacc = a.lds_bytes > 0;
   if (use_lacc)
     for (int i = threadIdx.x; i < (nl0 + nl1) * (a.lds_f64 ? 2 : 1); i += blockDim.x) lacc[i] = 0.f;
@@ -1472,7 +1473,9 @@ __global__ __launch_bounds__(512, 4) void k_scatter_tiled(SortedScatterArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lacc[];   // doubles: [line set 0 | line set 1 | tile set 0 | tile set 1]
   __shared__ int s_geo[24];
   constexpr int CT = PLANE == 0 ? 4 * C0Q : 4 * C1Q;   // components per texel of this plane
-  const int nl0 = a.vm[0].L[PLANE] * lds_stride(a.vm[0].C[PLANE]), nl1 = a.vm[1].L[PLANE] * lds_stride(a.vm[1].C[PLANE]);
+  // (a factor set without a gradient in this launch gets no accumulator)
+  const int nl0 = (a.set_mask & 1) ? a.vm[0].L[PLANE] * lds_stride(a.vm[0].C[PLANE]) : 0;
+  const int nl1 = (a.set_mask & 2) ? a.vm[1].L[PLANE] * lds_stride(a.vm[1].C[PLANE]) : 0;
   const int tile_elems = tile_texels(a.tw) * CT;
   for (int i = threadIdx.x; i < (nl0 + nl1 + a.tile_sets * tile_elems) * 2; i += blockDim.x) lacc[i] = 0.f;
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31, q = lane >> 4, s16 = lane & 15;
@@ -1519,7 +1522,8 @@ __global__ __launch_bounds__(512, 4) void k_scatter_tiled(SortedScatterArgs a) {
         if (!((a.set_mask >> set) & 1)) continue;
         const int first = set ? nl0 : 0;
         const LdsLines ll = LdsLines{lacc, {first, first, first}, 1, a.line_direct};
-        const PlaneTile T = PlaneTile{lacc + 2 * (nl0 + nl1 + set * tile_elems), s_geo, CT};
+        const int tslot = set == 1 && (a.set_mask & 1) ? 1 : 0;   // windows are allocated for the live sets only
+        const PlaneTile T = PlaneTile{lacc + 2 * (nl0 + nl1 + tslot * tile_elems), s_geo, CT};
         const float* rec = a.dfs + (size_t)ent * a.rec_floats + set * SETF;
 #pragma unroll 1
         for (int lv = 0; lv < 3; ++lv) {
@@ -1553,7 +1557,7 @@ __global__ __launch_bounds__(512, 4) void k_scatter_tiled(SortedScatterArgs a) {
 #pragma unroll 1
     for (int set = 0; set < 2; ++set) {
       if (!((a.set_mask >> set) & 1)) continue;
-      double* tile = reinterpret_cast<double*>(lacc) + nl0 + nl1 + set * tile_elems;
+      double* tile = reinterpret_cast<double*>(lacc) + nl0 + nl1 + (set == 1 && (a.set_mask & 1) ? 1 : 0) * tile_elems;
       float* GP = a.gvm[set].plane[PLANE];
       const int sH = a.vm[set].sH[PLANE], sW = a.vm[set].sW[PLANE];
       for (int lv = 0; lv < 3; ++lv) {
@@ -2585,7 +2589,8 @@ static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
 template <int PLANE, int C0Q, int C1Q>
 static int launch_scatter_sorted(SortedScatterArgs& sa, long max_samples, hipStream_t stream) {
   // pass PLANE accumulates line PLANE only: L x (C + 4) elements per factor set, doubles when they fit (see LdsLines)
-  const long n = (long)sa.vm[0].L[PLANE] * (sa.vm[0].C[PLANE] + 4) + (long)sa.vm[1].L[PLANE] * (sa.vm[1].C[PLANE] + 4);
+  const long n = ((sa.set_mask & 1) ? (long)sa.vm[0].L[PLANE] * (sa.vm[0].C[PLANE] + 4) : 0) +
+                 ((sa.set_mask & 2) ? (long)sa.vm[1].L[PLANE] * (sa.vm[1].C[PLANE] + 4) : 0);
   static const int f64_env = RDRF_ENV("RDRF_LDS_F64") ? atoi(RDRF_ENV("RDRF_LDS_F64")) : 1;   // 0: floats (tools build, A/B)
   const int esz = (f64_env && 8 * n <= SC_LINES_MAX_BYTES) ? 8 : (4 * n <= SC_LINES_MAX_BYTES ? 4 : 0);
   sa.lds_bytes = (int)(esz * n);
@@ -2634,14 +2639,31 @@ static int launch_scatter_tiled(SortedScatterArgs& sa, const unsigned* keys_sort
   constexpr int CT = PLANE == 0 ? 4 * C0Q : 4 * C1Q;
   int tw = tw_env > 0 ? tw_env : (CT > 16 ? 16 : 32);   // 48-component texels: narrower windows keep two workgroups per CU
   tw = (tw < 8 ? 8 : (tw > 128 ? 128 : tw)) & ~3;
-  const long n = (long)sa.vm[0].L[PLANE] * (sa.vm[0].C[PLANE] + 4) + (long)sa.vm[1].L[PLANE] * (sa.vm[1].C[PLANE] + 4);
-  sa.tile_sets = (sa.set_mask & 2) ? 2 : 1;
+  const long n0 = (sa.set_mask & 1) ? (long)sa.vm[0].L[PLANE] * (sa.vm[0].C[PLANE] + 4) : 0;
+  const long n1 = (sa.set_mask & 2) ? (long)sa.vm[1].L[PLANE] * (sa.vm[1].C[PLANE] + 4) : 0;
+  const long n = n0 + n1;
+  sa.tile_sets = sa.set_mask == 3 ? 2 : 1;
   const long bytes = 8L * (n + (long)sa.tile_sets * tile_texels(tw) * CT);
   // only where two 512-thread workgroups per CU still fit (at the final grids the z lines of two factor sets alone take
   // 70 KB: one workgroup per CU lost more than the windows gained, 3.46 -> 3.97 ms) and for the 16- / 4-component texels
   // of the density / blending sets (the 48-component appearance windows gained nothing: 0.71 -> 0.71 ms)
   static const long max_env = RDRF_ENV("RDRF_SS_TILED_MAXB") ? atol(RDRF_ENV("RDRF_SS_TILED_MAXB")) : 80 * 1024;
-  if (bytes > max_env || (C0Q > 4 && tiled_env < 2)) return 0;
+  if (C0Q > 4 && tiled_env < 2) return 0;
+  if (bytes > max_env) {
+    // both factor sets together do not leave room for two workgroups per CU, each alone does (final grids: 35 KB of z
+    // line + 20 KB of windows per set).  One tiled launch per set was measured and LOSES to the untiled two-set kernel
+    // (final stage, scatter_dyn_density 3.08 -> 3.24 ms / step, profiles/r05_ab_tiled_scatter.txt: every entry's taps and
+    // run structure are formed twice), so it stays an experiment switch of the tools build and the caller falls back
+    static const int split_env = RDRF_ENV("RDRF_SS_SPLIT") ? atoi(RDRF_ENV("RDRF_SS_SPLIT")) : 0;
+    const long one = 8L * ((n0 > n1 ? n0 : n1) + (long)tile_texels(tw) * CT);
+    if (sa.set_mask != 3 || one > max_env || !split_env) return 0;
+    SortedScatterArgs s0 = sa, s1 = sa;
+    s0.set_mask = 1; s1.set_mask = 2;
+    int rc = launch_scatter_tiled<PLANE, C0Q, C1Q>(s0, keys_sorted, kb, max_samples, stream);
+    if (rc != 1) return rc;
+    rc = launch_scatter_tiled<PLANE, C0Q, C1Q>(s1, keys_sorted, kb, max_samples, stream);
+    return rc == 0 ? -5 : rc;   // (cannot happen: the same size test passed for the larger of the two)
+  }
   sa.lds_bytes = (int)bytes; sa.lds_f64 = 1;
   static const int direct_env = RDRF_ENV("RDRF_LINE_DIRECT") ? atoi(RDRF_ENV("RDRF_LINE_DIRECT")) : RDRF_LINE_DIRECT_DEFAULT;
   sa.line_direct = direct_env;
