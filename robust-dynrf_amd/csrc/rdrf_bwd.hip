@@ -2517,6 +2517,9 @@ static int lines_floats_host(const RdrfVM& vm) {
 }
 // LDS line accumulators when both factor sets' lines fit SC_LINES_MAX_BYTES; launches with that much
 // dynamic LDS (the attribute call is needed above 64 KB and is idempotent)
+#ifndef RDRF_SC_THREADS2_DEFAULT
+#define RDRF_SC_THREADS2_DEFAULT 256
+#endif
 template <typename K>
 static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles, hipStream_t stream) {
   const long n0 = lines_floats_host(sa.vm[0]), n1 = sa.nsets > 1 ? lines_floats_host(sa.vm[1]) : 0;
@@ -2551,7 +2554,8 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
   // threads; the grid never exceeds what is resident at once (the tile loop is a static stride: a workgroup that starts
   // after the others have finished would run its share alone)
   const int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : (sa.lds_bytes > 53 * 1024 ? 2 : 3);
-  const int threads = per_cu == 1 ? 512 : 256;
+  static const int thr2_env = RDRF_ENV("RDRF_SC_THREADS2") ? atoi(RDRF_ENV("RDRF_SC_THREADS2")) : RDRF_SC_THREADS2_DEFAULT;
+  const int threads = per_cu == 1 ? 512 : (per_cu == 2 ? thr2_env : 256);   // two workgroups per CU: 512 threads each = 4 waves per SIMD
   const int wpb = threads / 64;
   long g = (ntiles + wpb - 1) / wpb;
   static const long cap_env = RDRF_ENV("RDRF_SC_CAP") ? atol(RDRF_ENV("RDRF_SC_CAP")) : 0;   // experiments (tools build)
