@@ -248,13 +248,21 @@ extern "C" size_t rdrf_saved_row_bytes(int phase) {
 struct Geo {
   int grid, block;
 };
+#ifndef RDRF_GEO_TPW_DEFAULT
+#define RDRF_GEO_TPW_DEFAULT 1
+#endif
 static Geo geo_for_units(long units) {
   Geo g;
   const int ncu = 256;
   int waves = (int)((units + ncu - 1) / ncu);
   waves = waves < 1 ? 1 : (waves > RDRF_MAXW ? RDRF_MAXW : waves);
   g.block = waves * 64;
-  long blocks = (units + waves - 1) / waves;
+  // small launches (a 512-ray eval chunk = 1840 tiles): RDRF_GEO_TPW tiles per wave instead of one, on proportionally
+  // fewer CUs -- every workgroup pays the 121-159 KB LDS fill of its weight image once per launch, and independent
+  // launches on other streams find free CUs (rdrf_render_chunks_fwd)
+  static const int tpw_env = RDRF_ENV("RDRF_GEO_TPW") ? atoi(RDRF_ENV("RDRF_GEO_TPW")) : RDRF_GEO_TPW_DEFAULT;
+  const long per_block = (long)waves * (tpw_env < 1 ? 1 : tpw_env);
+  long blocks = (units + per_block - 1) / per_block;
   g.grid = (int)(blocks < 1 ? 1 : (blocks > ncu ? ncu : blocks));
   return g;
 }
