@@ -39,12 +39,12 @@ def test_deterministic_build_is_bit_reproducible_and_matches_the_atomic_build(tm
         err = float((x - z).abs().max())
         rel = float((x - z).norm() / x.norm())
         record_margin("deterministic vs atomic build (max-norm / 2e-5)", err / (2e-5 * scale))
-        record_margin("deterministic vs atomic build (rel. L2 / 5e-6)", rel / 5e-6)
+        record_margin("deterministic vs atomic build (rel. L2 / 2e-6)", rel / 2e-6)
         # the atomic build's own order noise (fp32 sums of up to ~1e5 terms): run-to-run spread of one path at the benchmark
         # shape 7.6e-7 max-norm / 3.7e-7 rel. L2 (tools/noise_spread.py, profiles/r05_noise_spread_*.txt), up to 6.5e-6 /
         # 5.0e-6 where ~1e5 terms meet in one texel (16^3 grids)
         assert err <= 2e-5 * scale, (err, scale)
-        assert rel < 5e-6, rel
+        assert rel < 2e-6, rel   # measured <= 5.2e-7 at these shapes (profiles/r05_parity_margins.txt): 4 x headroom
 
 
 def test_product_build_refuses_the_deterministic_entry_points():
