@@ -447,7 +447,8 @@ def test_z_vals_gradient_matches_oracle(rt):
 
 def test_sorted_scatter_passes_the_same_parity_tests():
     """rdrf_set_scatter_mode(RDRF_SCATTER_SORTED) (samples grouped by plane cell first, csrc/rdrf_bwd.hip k_scatter_sorted;
-    the automatic choice from 800 k samples per launch): the golden-gradient, mid-size oracle gradient, pruning and
+    the automatic choice from 300 k samples per launch; from there the density / blending passes also take
+    their LDS-window form, k_scatter_tiled): the golden-gradient, mid-size oracle gradient, pruning and
     fused-accumulation tests are re-run with the sorted path forced at their small sizes."""
     import importlib
     L = importlib.import_module("robust-dynrf_amd._lib")

@@ -247,8 +247,8 @@ def test_render_frame_matches_oracle_pipeline():
 
 @pytest.mark.parametrize("rt", ["ndc", "contract"])
 def test_render_chunks_on_hip_streams_is_bit_identical(rt):
-    """render_chunks: the 512-ray eval chunks of renderer.py:732-812 issued round-robin on 4 HIP streams (own scratch and
-    own packed weight image per stream) give the same bits as the sequential loop and as one call over all rays; repeated,
+    """render_chunks: the 512-ray eval chunks of renderer.py:732-812 issued round-robin on 4 HIP streams (own scratch per
+    stream, ONE packed weight image per field shared read-only by every stream) give the same bits as the sequential loop and as one call over all rays; repeated,
     with a weight update in between (the per-stream packed images must follow it)."""
     import rodynrf
     from _gpu_util import fields_from_case, make_rays
@@ -262,7 +262,7 @@ def test_render_chunks_on_hip_streams_is_bit_identical(rt):
         torch.cuda.synchronize()
         for a, b in ((whole, seq), (whole, par)):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        with torch.no_grad():   # change the weights: every stream's image is re-packed before its next chunk
+        with torch.no_grad():   # change the weights: the shared images are re-packed (on the main stream) before the next call's chunks
             dy.renderModule.mlp[0].weight.mul_(1.01)
             st.basis_mat.weight.mul_(0.99)
 
