@@ -530,7 +530,7 @@ def main():
     ap.add_argument("--dp-per-shard-stats", action="store_true",
                     help="N > 1: normalise the masked-mean / per-frame depth losses by each rank's own batch statistics "
                          "instead of all-reducing them (default: exact single-process statistics, SURVEY 8e)")
-    ap.add_argument("--scatter", default="auto", choices=["auto", "ray", "sorted"],
+    ap.add_argument("--scatter", default="auto", choices=["auto", "ray", "sorted", "sorted_plain"],
                     help="density / blending scatter of the dynamic field (rdrf_set_scatter_mode); auto = sorted from 300 k "
                          "samples per launch")
     ap.add_argument("--cpu-rays", type=int, default=512)

@@ -47,7 +47,7 @@ typedef void* rdrf_stream_t; /* hipStream_t */
 enum { RDRF_RAY_NDC = 0, RDRF_RAY_CONTRACT = 1, RDRF_RAY_OTHER = 2 };
 enum { RDRF_ACT_RELU = 0, RDRF_ACT_SOFTPLUS = 1 };
 enum { RDRF_HEAD_MLP_FEA = 0, RDRF_HEAD_MLP_FEA_TIMEEMBEDDING = 1 };
-enum { RDRF_SCATTER_RAY = 0, RDRF_SCATTER_SORTED = 1, RDRF_SCATTER_AUTO = 2 };
+enum { RDRF_SCATTER_RAY = 0, RDRF_SCATTER_SORTED = 1, RDRF_SCATTER_AUTO = 2, RDRF_SCATTER_SORTED_PLAIN = 3 };
 
 /* One vector-matrix factor set (3 planes + 3 lines).  Components are always contiguous (channel
  * stride 1); the texel strides are explicit so that the planes containing the ray-marching axis can
@@ -436,7 +436,10 @@ int rdrf_render_chunks_fwd(const RdrfStaticParams* PS, const RdrfFieldCfg* cfg_s
 /* ---- process-wide choice of the density / blending scatter of the dynamic field's backward (models/tensoRF.py:646-811,
  * grid_sampler_2d_backward semantics either way): RDRF_SCATTER_RAY = ray tiles, RDRF_SCATTER_SORTED = samples grouped by
  * plane cell first (about 10x fewer memory-side atomic requests, a fixed grouping cost per launch), RDRF_SCATTER_AUTO
- * (default) = sorted from 300 k samples per launch.  Returns 0, or -1 for an unknown mode. */
+ * (default) = sorted from 300 k samples per launch.  The sorted density / blending passes form their plane sums in LDS
+ * windows (k_scatter_tiled) wherever those fit beside two workgroups per CU; RDRF_SCATTER_SORTED_PLAIN forces the sorted
+ * path WITHOUT the windows (every run tail goes to global memory: the form large grids fall back to), so that both forms
+ * can be held to the same parity tests at any size.  Returns 0, or -1 for an unknown mode. */
 int rdrf_set_scatter_mode(int mode);
 
 /* ---- deterministic debugging build (librodynrf_det.so = the same sources with -DRDRF_DETERMINISTIC) ----------------

@@ -122,11 +122,12 @@ SYMBOLS = [
 ]
 
 
-SCATTER_MODES = {"ray": 0, "sorted": 1, "auto": 2}
+SCATTER_MODES = {"ray": 0, "sorted": 1, "auto": 2, "sorted_plain": 3}
 
 
 def set_scatter_mode(mode):
-    """rdrf_set_scatter_mode: "auto" (default: sorted from 300 k samples per launch) | "ray" | "sorted" """
+    """rdrf_set_scatter_mode: "auto" (default: sorted from 300 k samples per launch) | "ray" | "sorted" | "sorted_plain"
+    (sorted without the LDS plane windows of k_scatter_tiled) """
     check(lib.rdrf_set_scatter_mode(SCATTER_MODES[mode]), "rdrf_set_scatter_mode")
 
 

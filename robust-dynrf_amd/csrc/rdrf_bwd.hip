@@ -2575,8 +2575,8 @@ static int launch_scatter(const char* name, K kern, ScatterArgs& sa, long ntiles
 // whose request count does not depend on the warp field's smoothness, and the parity tests run both at every size.
 static int g_scatter_mode = RDRF_SCATTER_AUTO;
 extern "C" int rdrf_set_scatter_mode(int mode) {
-  RDRF_CHECK(mode == RDRF_SCATTER_AUTO || mode == RDRF_SCATTER_RAY || mode == RDRF_SCATTER_SORTED, -1,
-             "rdrf_set_scatter_mode: mode must be RDRF_SCATTER_AUTO, _RAY or _SORTED");
+  RDRF_CHECK(mode == RDRF_SCATTER_AUTO || mode == RDRF_SCATTER_RAY || mode == RDRF_SCATTER_SORTED || mode == RDRF_SCATTER_SORTED_PLAIN, -1,
+             "rdrf_set_scatter_mode: mode must be RDRF_SCATTER_AUTO, _RAY, _SORTED or _SORTED_PLAIN");
   g_scatter_mode = mode;
   return 0;
 }
@@ -2587,7 +2587,7 @@ static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
   // Balloon1 stage-0 pass (4096 x 115 = 471 k samples: 12.57 vs 12.72 ms/step, interleaved A/B on one box) upwards, and
   // sends a tenth of the atomic requests; below ~300 k samples the fixed cost of its seven extra launches dominates
   if (m == RDRF_SCATTER_AUTO) return ns >= (size_t)300000 ? 1 : 0;
-  return m == RDRF_SCATTER_SORTED ? 1 : 0;
+  return (m == RDRF_SCATTER_SORTED || m == RDRF_SCATTER_SORTED_PLAIN) ? 1 : 0;
 }
 
 template <int PLANE, int C0Q, int C1Q>
@@ -2637,7 +2637,7 @@ static int launch_scatter_tiled(SortedScatterArgs& sa, const unsigned* keys_sort
   return 0;   // LDS sums form in wave-arrival order
 #endif
   static const int tiled_env = RDRF_ENV("RDRF_SS_TILED") ? atoi(RDRF_ENV("RDRF_SS_TILED")) : RDRF_SS_TILED_DEFAULT;
-  if (!tiled_env) return 0;
+  if (!tiled_env || g_scatter_mode == RDRF_SCATTER_SORTED_PLAIN) return 0;
   static const int tw_env = RDRF_ENV("RDRF_SS_TW") ? atoi(RDRF_ENV("RDRF_SS_TW")) : 0;
   static const int steps_env = RDRF_ENV("RDRF_SS_STEPS") ? atoi(RDRF_ENV("RDRF_SS_STEPS")) : 0;
   constexpr int CT = PLANE == 0 ? 4 * C0Q : 4 * C1Q;

@@ -452,14 +452,15 @@ def test_sorted_scatter_passes_the_same_parity_tests():
     fused-accumulation tests are re-run with the sorted path forced at their small sizes."""
     import importlib
     L = importlib.import_module("robust-dynrf_amd._lib")
-    L.set_scatter_mode("sorted")
     try:
-        for case in CASES:
-            test_golden_gradients(case)
-        for seed in (5, 6, 7):
-            test_oracle_gradients_midsize(seed)
-        test_oracle_gradients_midsize_contract(5)
-        test_pruned_branches_match_autograd()
-        test_fused_grad_accumulation_matches_autograd()
+        for mode in ("sorted", "sorted_plain"):   # with the LDS plane windows, and the form large grids fall back to
+            L.set_scatter_mode(mode)
+            for case in CASES:
+                test_golden_gradients(case)
+            for seed in ((5, 6, 7) if mode == "sorted" else (5,)):
+                test_oracle_gradients_midsize(seed)
+            test_oracle_gradients_midsize_contract(5)
+            test_pruned_branches_match_autograd()
+            test_fused_grad_accumulation_matches_autograd()
     finally:
         L.set_scatter_mode("auto")
