@@ -134,6 +134,30 @@ def cpu_baseline(trainer, n_rays, repeats, dead_work=True):
                        f"1 warm-up, {med:.1f} s per step (the CPU throughput grows with the batch)")
 
 
+def select_baseline_config(args, world):
+    """Which BASELINE.json configuration this GPU count is quoted on; fills args.config / args.stage /
+    args.rays_per_gpu when they were not given and returns (configs index as a string or None, explicit?).
+    configs[1]: Balloon1, Nvidia.txt, 4096 rays per GPU, stage 0 (N = 1, 2 and any N without an entry of its own);
+    configs[2]: Nvidia_no_poses.txt; configs[3]: DAVIS.txt, final grid 256^3, 8192 rays GLOBAL (quoted on 4 GPUs: 2048 per
+    rank); configs[4]: the 640^3 grid, 32768 rays global (quoted on 8 GPUs: 4096 per rank).  Explicit --config / --stage win."""
+    BASE = {"1": ("nvidia", "stage0", 0), "2": ("nvidia_no_poses", "stage0", 0), "3": ("davis", "final", 8192),
+            "4": ("nvidia_no_poses", "final", 32768)}
+    bsel = args.baseline_config
+    if bsel == "auto":
+        bsel = {4: "3", 8: "4"}.get(world, "1")
+    b_cfg, b_stage, b_global = BASE[bsel]
+    explicit = args.config is not None or args.stage is not None
+    if explicit:
+        args.config, args.stage = args.config or "nvidia", args.stage or "stage0"
+        bsel = {("nvidia", "stage0"): "1", ("nvidia_no_poses", "stage0"): "2", ("davis", "final"): "3",
+                ("nvidia_no_poses", "final"): "4"}.get((args.config, args.stage))
+    else:
+        args.config, args.stage = b_cfg, b_stage
+        if not args.rays_per_gpu and b_global and b_global % world == 0:
+            args.rays_per_gpu = b_global // world   # the config's GLOBAL batch split over the ranks it is quoted on
+    return bsel, explicit
+
+
 def self_spawn(args):
     """python bench.py --gpus N without a torch.distributed environment: one rank per GPU through
     torch.distributed.run (the driver's own launch line)."""
@@ -567,22 +591,7 @@ def main():
     R = importlib.import_module("robust-dynrf_amd.renderer")
 
     L.set_scatter_mode(args.scatter)
-    # which BASELINE.json configuration this GPU count is quoted on; explicit --config / --stage win
-    BASE = {"1": ("nvidia", "stage0", 0), "2": ("nvidia_no_poses", "stage0", 0), "3": ("davis", "final", 8192),
-            "4": ("nvidia_no_poses", "final", 32768)}
-    bsel = args.baseline_config
-    if bsel == "auto":
-        bsel = {4: "3", 8: "4"}.get(world, "1")
-    b_cfg, b_stage, b_global = BASE[bsel]
-    explicit = args.config is not None or args.stage is not None
-    if explicit:
-        args.config, args.stage = args.config or "nvidia", args.stage or "stage0"
-        bsel = {("nvidia", "stage0"): "1", ("nvidia_no_poses", "stage0"): "2", ("davis", "final"): "3",
-                ("nvidia_no_poses", "final"): "4"}.get((args.config, args.stage))
-    else:
-        args.config, args.stage = b_cfg, b_stage
-        if not args.rays_per_gpu and b_global and b_global % world == 0:
-            args.rays_per_gpu = b_global // world   # the config's GLOBAL batch split over the ranks it is quoted on
+    bsel, explicit = select_baseline_config(args, world)
     cfg = S_.scene_config(args.config, args.stage)
     rpg = args.rays_per_gpu or cfg["batch_size"]
     cfg["batch_size"] = rpg * world   # weak scaling: fixed rays per GPU
