@@ -134,9 +134,15 @@ def cpu_baseline(trainer, n_rays, repeats, dead_work=True):
                        f"1 warm-up, {med:.1f} s per step (the CPU throughput grows with the batch)")
 
 
+def quoted_baseline_config(world):
+    """the BASELINE.json configs index quoted for this GPU count (configs[3]: 4 GPUs, configs[4]: 8 GPUs, else configs[1])"""
+    return {4: "3", 8: "4"}.get(world, "1")
+
+
 def select_baseline_config(args, world):
-    """Which BASELINE.json configuration this GPU count is quoted on; fills args.config / args.stage /
-    args.rays_per_gpu when they were not given and returns (configs index as a string or None, explicit?).
+    """Which BASELINE.json configuration the line is for; fills args.config / args.stage /
+    args.rays_per_gpu when they were not given and returns (configs index as a string or None, explicit?).  Default: configs[1]
+    at every GPU count (the metric is quoted on Balloon1 @1/2/4/8); --baseline-config quoted: the one quoted for this count.
     configs[1]: Balloon1, Nvidia.txt, 4096 rays per GPU, stage 0 (N = 1, 2 and any N without an entry of its own);
     configs[2]: Nvidia_no_poses.txt; configs[3]: DAVIS.txt, final grid 256^3, 8192 rays GLOBAL (quoted on 4 GPUs: 2048 per
     rank); configs[4]: the 640^3 grid, 32768 rays global (quoted on 8 GPUs: 4096 per rank).  Explicit --config / --stage win."""
@@ -144,7 +150,9 @@ def select_baseline_config(args, world):
             "4": ("nvidia_no_poses", "final", 32768)}
     bsel = args.baseline_config
     if bsel == "auto":
-        bsel = {4: "3", 8: "4"}.get(world, "1")
+        bsel = "1"
+    elif bsel == "quoted":
+        bsel = quoted_baseline_config(world)
     b_cfg, b_stage, b_global = BASE[bsel]
     explicit = args.config is not None or args.stage is not None
     if explicit:
@@ -542,11 +550,13 @@ def main():
     ap.add_argument("--config", default=None, choices=["nvidia", "nvidia_no_poses", "davis"],
                     help="default: the BASELINE.json config quoted for this GPU count (see --baseline-config)")
     ap.add_argument("--stage", default=None, choices=["stage0", "up1", "up2", "up3", "final", "huge"])
-    ap.add_argument("--baseline-config", default="auto", choices=["auto", "1", "2", "3", "4"],
-                    help="BASELINE.json configs[i] to run when --config / --stage are not given.  auto: N = 1, 2 -> configs[1] "
-                         "(Balloon1, Nvidia.txt, 4096 rays per GPU, stage 0); N = 4 -> configs[3] (DAVIS.txt, contracted rays, "
-                         "8192 rays GLOBAL = 2048 per rank, final grid 256^3); N = 8 -> configs[4] (640^3 grid, 32768 rays "
-                         "global = 4096 per rank); any other N -> configs[1]")
+    ap.add_argument("--baseline-config", default="auto", choices=["auto", "quoted", "1", "2", "3", "4"],
+                    help="BASELINE.json configs[i] to run when --config / --stage are not given.  auto (default): configs[1] at "
+                         "every GPU count -- BASELINE.json's metric is 'Nvidia Balloon1 @1/2/4/8 MI355X', 4096 rays per GPU "
+                         "(weak scaling: the driver's efficiency figures compare like with like).  quoted: the configuration "
+                         "BASELINE.json quotes for THIS GPU count -- N = 4 -> configs[3] (DAVIS.txt, contracted rays, 8192 rays "
+                         "GLOBAL = 2048 per rank, final grid 256^3); N = 8 -> configs[4] (640^3 grid, 32768 rays global = 4096 "
+                         "per rank); other N -> configs[1].  The line names both (config.baseline_config_*)")
     ap.add_argument("--weights", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--rays-per-gpu", type=int, default=0, help="default: the config's batch size (4096; DAVIS 8192)")
     ap.add_argument("--dp", default="zero1", choices=["zero1", "allreduce"],
@@ -635,6 +645,12 @@ def main():
                                "per-frame depth loss, distortion loss, compositor, factor regularisers, full backward, Adam",
                    "baseline_config_index": None if bsel is None else int(bsel),
                    "baseline_config_selected": "explicit --config / --stage" if explicit else f"--baseline-config {args.baseline_config} at {world} GPU(s)",
+                   "baseline_config_quoted_for_this_gpu_count": {
+                       "index": int(quoted_baseline_config(world)),
+                       "command": f"python bench.py --gpus {world} --baseline-config quoted",
+                       "note": "BASELINE.json's metric is Balloon1 (configs[1]) at 1/2/4/8 GPUs, which is what the default runs at every "
+                               "GPU count (weak scaling, 4096 rays per GPU); configs[3] (DAVIS, 8192 rays over 4 GPUs) and configs[4] "
+                               "(640^3 grid, 32768 rays over 8 GPUs) are selected with --baseline-config quoted"},
                    "timed_region": ("preceded by a profiled REPLAY of the same window on a second trainer (iterations 0 .. warmup + steps, "
                                     "same seeds): it yields the per-kernel table of exactly the timed iterations and warms the clocks; "
                                     "then the driver's warmup + steps iterations run on the main trainer and `steps` of them are timed"
