@@ -39,7 +39,8 @@ extern "C" {
  * 3: sorted scatter workspace + fused render entry points (round 3);
  * 4: rdrf_set_scatter_mode replaces the RDRF_SCATTER / RDRF_RENDER environment switches -- no entry point reads the
  *    caller's environment any more; rdrf_render_chunks_fwd (round 4).  A binding built against another version must refuse to load: the structs
- *    are passed by pointer and read to their full length. */
+ *    are passed by pointer and read to their full length.
+ *    Round 5 added, without changing any struct or signature: rdrf_saved_row_bytes, RDRF_SCATTER_SORTED_PLAIN. */
 #define RDRF_ABI_VERSION 4
 
 typedef void* rdrf_stream_t; /* hipStream_t */
