@@ -161,8 +161,13 @@ def select_baseline_config(args, world):
                 ("nvidia_no_poses", "final"): "4"}.get((args.config, args.stage))
     else:
         args.config, args.stage = b_cfg, b_stage
-        if not args.rays_per_gpu and b_global and b_global % world == 0:
+        if not args.rays_per_gpu and b_global:
+            if b_global % world:
+                raise SystemExit(f"bench.py: configs[{bsel}] quotes a GLOBAL batch of {b_global} rays, which {world} ranks cannot "
+                                 "split evenly; give --rays-per-gpu (the line then carries baseline_config_index null)")
             args.rays_per_gpu = b_global // world   # the config's GLOBAL batch split over the ranks it is quoted on
+        elif args.rays_per_gpu and b_global and args.rays_per_gpu * world != b_global:
+            bsel = None                             # not the quoted global batch: do not label the line with the config
     return bsel, explicit
 
 
@@ -334,7 +339,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
                      "dw_static": 864 * t3s * 128.0 * table.get("dw_static", {}).get("launches_per_step", 0.0),
                      "dw_sf": 480 * t1 * 128.0 * table.get("dw_sf", {}).get("launches_per_step", 0.0)}
     dw_keys = [k for k in dw_step_bytes if k in table]
-    out = {}
+    out, dw_entry, dw_ms = {}, None, 0.0
     if dw_keys:
         dw_launch = sum(table[k]["launches_per_step"] for k in dw_keys)
         dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
@@ -346,7 +351,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
             "frac": dw_b / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": tr,
             "hbm_real": None if tr is None else tr / (dw_ms / dw_launch * 1e-3) / 1e9,
             "source": {"traffic / hbm_real": f"profiles/{_profile_csv('pmc_fetch')[1]}_pmc_*.csv (committed, not re-measured here)"},
-            "kernel": "k_dw2", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
+            "kernel": "k_dw2 (dw_dyn + dw_static + dw_sf launches)", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
             "launches_per_step": dw_launch, "algorithmic_bytes_per_launch": dw_b / dw_launch,
             "mfma": {"achieved_tflops": dw_f / (dw_ms * 1e-3) / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
                      "frac": dw_f / (dw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
@@ -368,33 +373,43 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
     f_, w_ = pmc_family_per_step("pmc_fetch", fam, "FETCH_SIZE"), pmc_family_per_step("pmc_write", fam, "WRITE_SIZE")
     tr_step = None if (f_ is None or w_ is None) else f_ * 1024.0 * 2.0 + w_ * 1024.0
     atom = pmc_family_per_step("sq_counters", fam, "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum")
+    # `achieved` / `frac` of the scatter family are PHYSICAL: HBM-side bytes of the family's launches
+    # (2 FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this command) / this run's family time.  The algorithmic byte
+    # model above prices the unsorted atomic scatter of round 2; the sorted / tiled kernels merge same-cell updates in
+    # registers and LDS windows, so it stays in the detail record as `nominal_*` and is not a fraction of anything.
+    hbm_real = None if tr_step is None else tr_step / (sc_ms * 1e-3) / 1e9
     sc_entry = {
-        "bound": "hbm", "achieved": sc_b / (sc_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-        "frac": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None if tr_step is None else tr_step / sc_launch,
-        "hbm_real": None if tr_step is None else tr_step / (sc_ms * 1e-3) / 1e9,
+        "bound": "hbm", "achieved": hbm_real, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": None if hbm_real is None else hbm_real / PEAK_HBM_GBS, "traffic": None if tr_step is None else tr_step / sc_launch,
         "l2_atomic_frac": None if atom is None else atom / (sc_ms * 1e-3) / L2_ATOMIC_REQ_PER_S,
-        "kernel": "k_scatter", "ms_per_step": sc_ms, "kernel_avg_us": sc_ms / sc_launch * 1e3,
-        "launches_per_step": sc_launch, "algorithmic_bytes_per_launch": sc_b / sc_launch,
-        "bound_physical": "gather latency + the in-register run reduction; plane sums form in LDS windows (ds_add_f64) and reach the memory "
-                          "side once per window, line sums in LDS doubles (not HBM: the gathered bytes are cache resident)",
-        "frac_l2": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_L2_GBS,
-        # the same time priced with round 2's byte count (both factor sets of the dynamic field in every pass, whether
-        # or not the blending head receives a gradient): comparable with BENCH_r02's frac
-        "frac_round2_accounting": (sc_b + (n_sc * 2 - (n_both * 2 + (n_sc - min(n_sc, n_both)))) * ns * valid_frac
-                                   * (3 * 1728 + 288.0)) / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-        "source": {"achieved / ms_per_step / kernel_avg_us": "HIP events, this run",
-                   "traffic / hbm_real / l2_atomic_frac": f"profiles/{_profile_csv('pmc_fetch')[1]}_*.csv (committed rocprofv3 PMC "
-                                                          "summaries of the same command, not re-measured in this run)"},
-        "limiter": "`frac` is NOMINAL (algorithmic bytes / time against the HBM peak; the contract offers hbm | mfma): the bytes are "
-                   "L2 / MALL resident.  Physical figures: hbm_real = PMC bytes / time, l2_atomic_frac = memory-side atomic requests "
-                   "/ time / 20.8 G/s, both over all launches of the k_scatter family in a step of the committed profile, frac_l2 against "
-                   "the 34.5 TB/s L2.  Launches of >= 300 k samples take the sorted kernels; their density / blending passes form the "
-                   "plane sums in LDS windows of doubles (k_scatter_tiled), every LDS accumulator is a double (ds_add_f64: 11 x the "
-                   "update rate of ds_add_f32, tools/micro/lds_atomic_rate.hip)"}
-    dom_e, oth_e = (sc_entry, dw_entry) if (not dw_keys or sc_ms >= dw_ms) else (dw_entry, sc_entry)
-    dom_e = dict(dom_e)
-    dom_e["note"] = ("the kernel family with the most time per step; its `frac` is NOMINAL where the bytes are cache resident "
-                     "(see `limiter`): the physical figures are hbm_real, frac_l2 and l2_atomic_frac")
+        "kernel": "k_scatter family (k_scatter, k_scatter_sorted, k_scatter_tiled + key generation and radix sort)",
+        "ms_per_step": sc_ms, "kernel_avg_us": sc_ms / sc_launch * 1e3, "launches_per_step": sc_launch,
+        "nominal_bytes_per_launch_round2_model": sc_b / sc_launch,
+        "nominal_gbs_round2_model": sc_b / (sc_ms * 1e-3) / 1e9,
+        "nominal_frac_of_l2": sc_b / (sc_ms * 1e-3) / 1e9 / PEAK_L2_GBS,
+        "bound_physical": "latency: gather round trips + the in-register run reduction; no roof nearby (HBM frac and memory-side "
+                          "atomic fraction both < 0.25): plane sums form in LDS windows (ds_add_f64), line sums in LDS doubles",
+        "source": {"ms_per_step / kernel_avg_us": "HIP events, this run",
+                   "achieved / frac / traffic / l2_atomic_frac": f"profiles/{_profile_csv('pmc_fetch')[1]}_*.csv (committed rocprofv3 PMC "
+                                                                 "summaries of the same command) over this run's family time"}}
+    # forward / backward MLP families against the fp32-MFMA peak (useful = algorithmic FLOP of the samples they ran)
+    def mlp_family(name, keys):
+        ks = [k for k in keys if k in table and k in flops]
+        if not ks:
+            return None
+        ms_f = sum(table[k]["ms_per_step"] for k in ks)
+        fl = sum(flops[k] * mult[k] for k in ks)
+        return {"bound": "mfma", "achieved": fl / (ms_f * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / (ms_f * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": name, "ms_per_step": ms_f,
+                "members_ms_per_step": {k: round(table[k]["ms_per_step"], 4) for k in ks}}
+    fwd_entry = mlp_family("forward MLP kernels (k_dyn_density, k_dyn_app, k_static_app, k_scene_flow)",
+                           ("dyn_density", "dyn_app", "static_app", "scene_flow"))
+    bwd_entry = mlp_family("backward-data MLP kernels (k_dyn_heads_bwd, k_dyn_warp_bwd, k_dyn_app_bwd, k_static_app_bwd, k_scene_flow_bwd)",
+                           ("dyn_heads_bwd", "dyn_warp_bwd", "dyn_app_bwd", "static_app_bwd", "scene_flow_bwd"))
+    fams = [e for e in (fwd_entry, bwd_entry, sc_entry, dw_entry if dw_keys else None) if e]
+    fams.sort(key=lambda e: -e["ms_per_step"])
+    dom_e, oth_e = dict(fams[0]), (fams[1] if len(fams) > 1 else None)
+    dom_e["note"] = "the kernel family with the most time per step; every `frac` here is physical (<= 1)"
     # The line's own roofline is the STEP against the fp32-MFMA peak: the path is MLP-bound
     # once the gathers are cache resident (SURVEY 8d "which roofline"), `achieved` = algorithmic FLOP of the work the step
     # executes (dead work included only when it runs) / the timed step; filled in by price_step() with the timed ms.
@@ -412,6 +427,10 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
     out.update({
         "dominant_kernel": dom_e,
         "second_kernel": oth_e,
+        "families": fams,
+        "forward_mlp_ms_per_step": fwd_entry["ms_per_step"] if fwd_entry else None,
+        "dw_ms_per_step": dw_ms if dw_keys else None,
+        "launches_per_step": sum(v["launches_per_step"] for k, v in table.items() if k != "sort"),
         "step_algorithmic_tflop": step_flops / 1e12,
         "step_frac_of_peak": step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
         "kernel_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in table.items()},
@@ -542,6 +561,74 @@ def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5, streams=1):
     return out
 
 
+LINE_LIMIT = 8192   # bytes: the driver parses the LAST stdout line; r05's 21.5 KB line came back `parsed: null`
+SCHEMA = 6          # r06: compact line + bench_detail.json; every `frac` of the line is a physical fraction (<= 1)
+
+
+def _num(x, nd=5):
+    """floats rounded to `nd` significant digits (the line is for reading; bench_detail.json keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline` and the promoted
+    scalars -- a few KB.  Everything else (per-kernel tables, exchange plan, stage list, sparse leg, notes) is written to
+    bench_detail.json beside this file (write_detail).  tests/test_bench_line_cpu.py asserts len < LINE_LIMIT."""
+    cfg = out.get("config", {})
+    line = {k: _num(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["schema"] = SCHEMA
+    line["config"] = {k: cfg[k] for k in ("workload", "baseline_config_index", "config", "stage", "grid", "samples_per_ray",
+                                          "global_batch", "rays_per_gpu", "parallelism", "backend", "timed_region", "dead_work")
+                      if k in cfg}
+    rf = out.get("roofline")
+    if rf:
+        r = {k: _num(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
+        for name in ("dominant_kernel", "second_kernel"):
+            if rf.get(name):
+                r[name] = {k: _num(rf[name].get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                               "ms_per_step")}
+        r["mfma_frac"] = {k: _num(v) for k, v in rf.get("mfma_frac", {}).items()
+                          if k in ("dyn_density", "dyn_app", "static_app", "dw_dyn", "dw_static")}
+        for k in ("sum_kernel_ms_per_step", "scatter_family_ms_per_step", "forward_mlp_ms_per_step", "dw_ms_per_step",
+                  "launches_per_step", "pmc_profile"):
+            if k in rf:
+                r[k] = _num(rf[k])
+        line["roofline"] = r
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {k: _num(out["cpu_baseline"][k]) for k in ("value", "unit", "cores", "kind", "sample")}
+    if "cpu_baseline_4096" in out:
+        line["cpu_baseline_4096_value"] = _num(out["cpu_baseline_4096"]["value"])
+    for k in ("final_stage_value", "final_stage_ms_per_step", "final_stage_frac_of_fp32_mfma_peak", "schedule_weighted_value",
+              "liveness_exploited_value", "render_mpix_per_s", "render_final_stage_mpix_per_s", "render_chunk512_mpix_per_s",
+              "step_frac_of_fp32_mfma_peak", "hbm_roofline_640"):
+        if k in out:
+            line[k] = _num(out[k]) if not isinstance(out[k], dict) else {a: _num(b) for a, b in out[k].items()}
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:   # never hand the driver a line it cannot parse: shed the optional objects
+        for k in ("hbm_roofline_640", "cpu_baseline_4096_value"):
+            line.pop(k, None)
+        line.get("roofline", {}).pop("second_kernel", None)
+        line["config"] = {"workload": cfg.get("workload", "")[:300]}
+        text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(out):
+    """the full record (what rounds 1-5 printed on the line) next to bench.py and, on a gpurun box, under gpurun_out/"""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -656,7 +743,7 @@ def main():
                                     "then the driver's warmup + steps iterations run on the main trainer and `steps` of them are timed"
                                     if not args.no_roofline else "warmup + steps iterations on a fresh trainer"),
                    "config": args.config, "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
-                   "global_batch": cfg["batch_size"], "weights": args.weights,
+                   "global_batch": cfg["batch_size"], "rays_per_gpu": rpg, "weights": args.weights,
                    "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if trainer.opt.ex.active else ""),
                    "ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                    "exchange_bytes_per_step": trainer.opt.nbytes_exchanged() if trainer.opt.ex.active else 0,
@@ -709,16 +796,23 @@ def main():
         # 22000 of 100000): the same step at the final resolution
         cfg_f = S_.scene_config("nvidia", "final")
         cfg_f["batch_size"] = rpg
-        tr_f = S_.Trainer(cfg_f, dev, weights=args.weights, dead_work=not args.exploit_liveness)
-        dtf, _ = timed_steps(tr_f, shard, max(10, args.steps // 5), 3, 1, dev)
+        def make_trainer_f():
+            return S_.Trainer(dict(cfg_f), dev, weights=args.weights, dead_work=not args.exploit_liveness)
+        n_f, w_f = max(10, args.steps // 5), 3
+        rf_f = None
+        if not args.no_roofline:   # profiled replay of iterations w_f .. w_f + n_f FIRST (as at stage 0): the kernel table
+            rf_f = roofline(L, S_, None, cfg_f, shard, rpg, 1.0, window=(make_trainer_f, w_f, n_f))   # of the timed iterations
+        tr_f = make_trainer_f()
+        dtf, _ = timed_steps(tr_f, shard, n_f, w_f, 1, dev)
         fin = {"value": rpg / dtf, "unit": "rays/s", "ms_per_step": dtf * 1e3, "grid": cfg_f["grid"],
-               "samples_per_ray": cfg_f["n_samples"], "steps": max(10, args.steps // 5)}
-        if not args.no_roofline:
-            rf = price_step(roofline(L, S_, tr_f, cfg_f, shard, rpg, dtf * 1e3), dtf * 1e3, rpg)
-            fin["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
-                                                  "step_frac_of_peak", "kernel_ms_per_step", "fractions")}
-            fin["roofline"]["dominant_kernel"] = {k: rf["dominant_kernel"][k] for k in ("kernel", "bound", "achieved", "peak", "unit",
-                                                                                     "frac", "ms_per_step")}
+               "samples_per_ray": cfg_f["n_samples"], "steps": n_f, "warmup": w_f}
+        if rf_f is not None:
+            rf_f = price_step(rf_f, dtf * 1e3, rpg)
+            fin["roofline"] = {k: rf_f[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "step_frac_of_peak",
+                                                    "kernel_ms_per_step", "sum_kernel_ms_per_step", "ms_per_step_minus_kernel_sum",
+                                                    "fractions", "mfma_frac", "families", "profiled_window")}
+            fin["roofline"]["dominant_kernel"] = {k: rf_f["dominant_kernel"].get(k) for k in ("kernel", "bound", "achieved", "peak",
+                                                                                             "unit", "frac", "ms_per_step")}
         if not args.no_render:
             fin["render"] = render_leg(L, R, S_, tr_f, cfg_f, dev, cfg_f["H"] * cfg_f["W"], frames=3)
         out["final_stage"] = fin
@@ -778,7 +872,15 @@ def main():
             out["render_chunk512_mpix_per_s"] = out["render_chunk512"]["value"]
         if "roofline" in out:
             out["step_frac_of_fp32_mfma_peak"] = out["roofline"]["frac"]
-        print(json.dumps(out))
+        if "final_stage" in out:
+            if "roofline" in out["final_stage"]:
+                out["final_stage_frac_of_fp32_mfma_peak"] = out["final_stage"]["roofline"]["frac"]
+            if "render" in out["final_stage"]:
+                out["render_final_stage_mpix_per_s"] = out["final_stage"]["render"]["value"]
+        out["schema"] = SCHEMA
+        write_detail(out)
+        sys.stdout.flush()
+        print(compact_line(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

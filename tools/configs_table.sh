@@ -11,7 +11,7 @@ try:
     d = json.loads(open("gpurun_out/cfgt.log").read().strip().splitlines()[-1])
     c = d["config"]
     print(sys.argv[1], sys.argv[2], "grid", c.get("grid"), "S", c.get("samples_per_ray"), "rays", c.get("global_batch"), "ms/step", round(d["ms_per_step"], 2), "rays/s", round(d["value"]),
-          "liveness_exploited", round(d.get("liveness_exploited", {}).get("value", 0)))
+          "liveness_exploited", round(d.get("liveness_exploited_value", 0)))
 except Exception as e:
     print(sys.argv[1:], "ERR", e, open("gpurun_out/cfgt.log").read()[-600:])
 PY
