@@ -2271,6 +2271,138 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_dw3 (round 6): the same plan as k_dw2 on HALF stages with LDS-DMA.  k_dw2 stages a whole tile
+// (32 samples x all rows, 108-120 KB of the 160 KB LDS) through registers: barrier, ten ds_write_b128 per thread, barrier, the
+// products -- the matrix pipes wait during the write pass and both barriers (3 x (64 MFMA + 4 VALU cycles) account for 0.66
+// of its wave cycles), and nothing can be double-buffered.  Here a stage is 16 samples x all rows (64 bytes of every row,
+// 54-60 KB), there are two of them, and `buffer_load_dwordx4 ... lds` moves a half stage straight from HBM into the buffer
+// that is not being read: step s = barrier; issue the DMA of step s + 1; the products of step s (8 MFMAs each, K = 16
+// samples).  One barrier per half stage, no staging registers, no LDS write instructions.
+//   LDS image of a block (32 rows x 16 samples = 2 KB): float4 position p = row * 4 + (chunk ^ ((row >> 2) & 3)); a DMA
+//   instruction fills 1 KB in lane order (base + lane * 16 -- the hardware's layout), so the swizzle sits on the SOURCE
+//   address of lane l (row = 16 sub + (l >> 2), chunk = (l & 3) ^ ((row >> 2) & 3)) and on the read (cdna guide, rule 21);
+//   the 16 lanes of a ds_read_b128 group then cover all 64 banks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * DW2_WAVES) void k_dw3(Dw2Plan P) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 dw3_stage[];   // 2 buffers x nblk x 128 float4
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = P.count ? ((*P.count + 31) >> 5) : P.ntiles;
+  static_assert(DW2_MAX_SEG == 2 && (DW2_WAVES & 1) == 0, "segment select below; a wave's pieces share their parity");
+  const int sb1 = P.nseg > 1 ? P.seg_blk0[1] : 1 << 20;
+  const int s1 = P.nseg > 1 ? 1 : 0;
+  const float* seg0a = (P.seg_src[0] ? P.B : P.A) + (size_t)P.seg_row0[0] * 32;
+  const float* seg0b = (P.seg_src[s1] ? P.B : P.A) + (size_t)P.seg_row0[s1] * 32 - (size_t)P.seg_blk0[s1] * 1024;
+  const size_t st0 = (size_t)(P.seg_src[0] ? P.B_stride : P.A_stride) * 32,
+               st1 = (size_t)(P.seg_src[s1] ? P.B_stride : P.A_stride) * 32;
+  const int npieces = 2 * P.nblk;   // 1 KB pieces (16 rows x 64 B) of a half stage
+  constexpr int NPW = (2 * DW2_MAX_BLK + DW2_WAVES - 1) / DW2_WAVES;   // pieces per wave: 5
+  // the lane's source offset inside a piece (bytes): row (l >> 2) of the piece's 16, chunk swizzled by the row
+  // (a wave's pieces wave, wave + 12, ... all have the parity of the wave: one offset register)
+  const int prow_ = 16 * (wave & 1) + (lane >> 2);
+  const unsigned voff = (unsigned)(prow_ * 128 + (((lane & 3) ^ ((prow_ >> 2) & 3)) << 4));
+  const int hbuf = P.nblk * 128;   // float4 per buffer
+  auto dma = [&](int t, int hf, int buf) {
+    const float* g0 = seg0a + (size_t)t * st0;
+    const float* g1 = seg0b + (size_t)t * st1;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)g0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)g1, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pc = wave + DW2_WAVES * i;   // wave-uniform
+      if (pc < npieces) {
+#ifndef RDRF_ABL_DW_NOLOAD
+        const int blk = pc >> 1;
+        __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(dw3_stage + buf * hbuf + pc * 64);
+        const unsigned soff = (unsigned)(blk * 4096 + hf * 64);
+        if (blk < sb1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, voff, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, voff, soff, 0, 0);
+#endif
+      }
+    }
+  };
+  int rpos[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) rpos[q] = li * 4 + ((2 * h + q) ^ ((li >> 2) & 3));
+  const int np = P.nprod[wave];
+  int pa[DW2_MAX_PROD], pb[DW2_MAX_PROD];   // staged block offsets (float4) of each product, bias flag in bit 30 of pa (scalars)
+#pragma unroll
+  for (int p = 0; p < DW2_MAX_PROD; ++p) {
+    pa[p] = __builtin_amdgcn_readfirstlane(P.prod[wave][p].a * 128 | (P.prod[wave][p].bias << 30));
+    pb[p] = __builtin_amdgcn_readfirstlane(P.prod[wave][p].b * 128);
+  }
+  f32x16 acc[DW2_MAX_PROD];
+  float bsum[DW2_MAX_PROD];
+#pragma unroll
+  for (int p = 0; p < DW2_MAX_PROD; ++p) {
+    bsum[p] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  }
+  int t = blockIdx.x, hf = 0, buf = 0;
+  if (t < ntiles) dma(t, 0, 0);
+  while (t < ntiles) {
+    // this wave's DMA pieces of the current half stage have landed; behind the barrier everybody's have, and everybody is
+    // done reading the other buffer (the products of the previous step)
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) (expcnt / lgkmcnt untouched)
+    __syncthreads();
+    int tn = t, hn = hf ^ 1;
+    if (hf) tn = t + gridDim.x;
+    if (tn < ntiles) dma(tn, hn, buf ^ 1);   // lands while the MFMAs below run
+#ifndef RDRF_ABL_DW_NOMFMA
+    const f32x4* stage = dw3_stage + buf * hbuf;
+#pragma unroll
+    for (int p = 0; p < DW2_MAX_PROD; ++p) {
+      if (p < np) {
+        int oa = pa[p] & 0xffffff, ob = pb[p];
+        asm volatile("" : "+s"(oa), "+s"(ob));   // (as in k_dw2: keeps the read addresses out of the loop-invariant hoist)
+        const f32x4* sa = stage + oa;
+        const f32x4* sb = stage + ob;
+        f32x4 av4[2], bv4[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { av4[q] = sa[rpos[q]]; bv4[q] = sb[rpos[q]]; }
+        if (pa[p] >> 30) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) bsum[p] += av4[q].x + av4[q].y + av4[q].z + av4[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].x, bv4[q].x, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].y, bv4[q].y, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].z, bv4[q].z, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[q].w, bv4[q].w, acc[p], 0, 0, 0);
+        }
+      }
+    }
+#else
+    if (np > 0) acc[0][0] += dw3_stage[buf * hbuf + (tid & 127)].x;
+#endif
+    t = tn; hf = hn; buf ^= 1;
+  }
+#ifdef RDRF_ABL_DW_NOFLUSH
+  if (ntiles >= 0) return;
+#endif
+#pragma unroll
+  for (int p = 0; p < DW2_MAX_PROD; ++p) {
+    if (p < np) {
+      const Dw2Prod pr = P.prod[wave][p];
+      const DwJob& J = P.job[pr.job];
+      const int col = seg_imap(J.blk_seg[pr.k], J.blk_e0[pr.k] + li, J.in_dim);
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int orow = pr.bo * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h - J.out_row0;
+        if (col >= 0 && orow >= 0 && orow < J.out_dim) grad_add(J.dW + (size_t)orow * J.ld + col, acc[p][rr]);
+      }
+      if (pr.bias && J.db != nullptr) {
+        const float b = bsum[p] + __shfl_xor(bsum[p], 32, 64);
+        const int orow = pr.bo * 32 + li - J.out_row0;
+        if (h == 0 && orow >= 0 && orow < J.out_dim) grad_add(J.db + orow, b);
+      }
+    }
+  }
+}
+
 // one plan per group of jobs that walk the same rows (same dz array, same activation array, same tile
 // space); a group whose products or blocks exceed one plan is cut into several launches
 static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
@@ -2337,8 +2469,15 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
         RDRF_HIP(hipFuncSetAttribute((const void*)k_dw2, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
       int grid = 256;
       if (P.count == nullptr && P.ntiles < grid) grid = P.ntiles < 1 ? 1 : P.ntiles;
+#ifndef RDRF_DW3_DEFAULT
+#define RDRF_DW3_DEFAULT 1
+#endif
+      static const int dw3 = RDRF_ENV("RDRF_DW3") ? atoi(RDRF_ENV("RDRF_DW3")) : RDRF_DW3_DEFAULT;   // 0: k_dw2 (tools build)
+      if (dw3 && lds > 48 * 1024)
+        RDRF_HIP(hipFuncSetAttribute((const void*)k_dw3, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
       rdrf_prof_begin(name, stream);
-      hipLaunchKernelGGL(k_dw2, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
+      if (dw3) hipLaunchKernelGGL(k_dw3, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
+      else hipLaunchKernelGGL(k_dw2, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
       rdrf_prof_end(name, stream);
       RDRF_HIP(hipGetLastError());
       return 0;

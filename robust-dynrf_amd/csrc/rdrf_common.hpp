@@ -111,6 +111,7 @@ enum SegId {
   SEG_SF_X,          // scene flow layer0 (64,36): [xn3, sin12, cos12, t, sin4, cos4]
   SEG_IDENT72,       // the 72 VM features of density/blending layer1 (cols 0..71)
   SEG_VIEW3,         // view-direction columns 128..130 of a (3,131) output layer
+  SEG16_APP_G,       // 16-sample layout: the 72 gathered appearance components, slot (j, c) of lane group g (app16_quad)
   SEG_COUNT
 };
 
@@ -160,6 +161,34 @@ RDRF_HD int seg_imap(int seg, int e, int in_dim) {
     }
   }
   return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-sample tiles on v_mfma_f32_16x16x4_f32 (round 6, k_static_app16): lane l = (g = l>>4, s = l&15) holds a QUARTER of
+// sample s' vector; element e lives in lane group g = (e>>2)&3, slot kk = (e>>4)*4 + (e&3) -- the C/D layout of the
+// 16x16x4 MFMA in the transposed product (row i = 4*(lane>>4) + r of block nb = neuron nb*16 + 4g + r), so that an
+// accumulator is again the B operand of the next layer.  Half the activation registers of the 32-sample layout.
+// ---------------------------------------------------------------------------------------------
+RDRF_HD int elem16_of(int kk, int g) { return ((kk >> 2) << 4) + (g << 2) + (kk & 3); }
+// quad of a {48,12,12}-component set that lane group g gathers into slots 4 j .. 4 j + 3 (16-sample layout): j < 3: XY quad
+// 4 j + g; j = 3: XZ quad g; j = 4: YZ quad g (groups 0..2; group 3 holds zeros there) -- every lane of the wave reads the
+// SAME plane at step j, so no per-lane select between two planes' pointers and strides (which costs 14 VGPRs, spilled).
+// Returned in the natural quad order (0..11 XY, 12..14 XZ, 15..17 YZ); -1 = padding.
+RDRF_HD int app16_quad(int j, int g) { return j < 3 ? 4 * j + g : (g < 3 ? (j == 3 ? 12 : 15) + g : -1); }
+// k-step kk of lane group g -> column of the reference weight matrix for the first-layer segments of the static head
+RDRF_HD int seg_imap16(int seg, int kk, int g, int in_dim) {
+  if (seg == SEG_STAT1_P_FEA || seg == SEG_STAT1_P_TE) {
+    // PE block: slot 4r+m of group g holds (sin f, cos f, sin 2f, cos 2f)[m] of feature w = elem16_of(r, g)
+    const int r = kk >> 2, m = kk & 3, w = elem16_of(r, g);
+    if (r >= 8 || w >= 27) return -1;
+    const int base = (seg == SEG_STAT1_P_FEA) ? 30 : 27;
+    return base + ((m & 1) ? 54 : 0) + w * 2 + (m >> 1);   // reference order: sin(feat*2^k) at d*2+k, then cos
+  }
+  if (seg == SEG16_APP_G) {
+    const int w = (kk >> 2) < 5 ? app16_quad(kk >> 2, g) : -1;
+    return w < 0 ? -1 : 4 * w + (kk & 3);
+  }
+  return seg_imap(seg, elem16_of(kk, g), in_dim);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,6 +342,7 @@ struct Tap1 {
   float w0, w1;
   bool ok0, ok1;
 };
+template <bool UNI = false>
 RDRF_D Tap1 tap1d(float c, int Ls) {
 #pragma clang fp contract(off)
   Tap1 t;
@@ -320,7 +350,10 @@ RDRF_D Tap1 tap1d(float c, int Ls) {
   // (float)(Ls-2) of every (axis, level, factor set) out of the tile loop -- as VECTOR registers (gfx950 has no
   // scalar float ALU) -- and spills them; each reload is a scratch load + `s_waitcnt vmcnt(0)` in the middle of
   // the gather sequence, which also waits for every store and gather in flight.  Opaque here = three v_cvt per call.
-  asm volatile("" : "+v"(Ls));   // ("v": Ls differs between the half-waves of some callers)
+  // UNI (the 128-VGPR kernels): Ls is wave-uniform at the call site and stays in a SCALAR register -- with "+v" the
+  // v_mov from the SGPR is itself hoisted out of the tile loop and spilled (18 of them in k_static_app16)
+  if constexpr (UNI) asm volatile("" : "+s"(Ls));
+  else asm volatile("" : "+v"(Ls));   // ("v": Ls differs between the half-waves of some callers)
   float f = ((c + 1.0f) / 2.0f) * (float)(Ls - 1);
   float fl = floorf(f);
   t.w1 = f - fl;
@@ -430,9 +463,10 @@ struct AxisTap {
   int i0, i1;     // clamped tap indices in level-0 texels (already << level)
   float w0, w1;   // interpolation weights, 0 where the tap is out of range (zero padding)
 };
+template <bool UNI = false>
 RDRF_D AxisTap axis_tap(float c, int L, int lv) {
   const int st = 1 << lv, Ls = (L + st - 1) >> lv;
-  const Tap1 t = tap1d(c, Ls);
+  const Tap1 t = tap1d<UNI>(c, Ls);
   AxisTap a;
   a.i0 = min(max(t.i0, 0), Ls - 1) << lv;
   a.i1 = min(max(t.i0 + 1, 0), Ls - 1) << lv;
@@ -465,11 +499,12 @@ RDRF_D PlaneTaps plane_taps(const RdrfVM& vm, int pi, const AxisTap& ax, const A
 }
 // the three axis taps of the normalised point (x0, x1, x2) at stride level lv (axis sizes: the XY plane and its line)
 struct PointTaps { AxisTap x, y, z; };
+template <bool UNI = false>
 RDRF_D PointTaps point_taps(const RdrfVM& vm, float x0, float x1, float x2, int lv) {
   PointTaps p;
-  p.x = axis_tap(x0, vm.W[0], lv);
-  p.y = axis_tap(x1, vm.H[0], lv);
-  p.z = axis_tap(x2, vm.L[0], lv);
+  p.x = axis_tap<UNI>(x0, vm.W[0], lv);
+  p.y = axis_tap<UNI>(x1, vm.H[0], lv);
+  p.z = axis_tap<UNI>(x2, vm.L[0], lv);
   return p;
 }
 RDRF_D AxisTap select_axis(bool first, const AxisTap& a, const AxisTap& b) {
@@ -648,6 +683,99 @@ RDRF_D void fill_x1(float (&X1)[8], float t, int h) {
   else fill_x1_impl<true>(X1, t, h);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-sample tiles: MFMA layer segment on v_mfma_f32_16x16x4_f32.  Weights: [NBO][KK/2][64 lanes][2] (one ds_read_b64 per
+// block and pair of k-steps); consecutive MFMAs go to DIFFERENT accumulators (32-cycle issue, 40-cycle dependent latency).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NBO, int KK>
+RDRF_D void mfma16_seg(f32x4 (&acc)[NBO], const float (&in)[KK], const float* __restrict__ wp, int lane) {
+  static_assert(KK % 2 == 0, "k-steps come in pairs");
+  constexpr int K2 = KK / 2;
+  f32x2 wc[NBO], wn[NBO];
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) wc[nb] = *(const f32x2*)(wp + (((nb * K2) * 64 + lane) << 1));
+#pragma unroll
+  for (int k2 = 0; k2 < K2; ++k2) {
+    if (k2 + 1 < K2) {
+#pragma unroll
+      for (int nb = 0; nb < NBO; ++nb) wn[nb] = *(const f32x2*)(wp + (((nb * K2 + k2 + 1) * 64 + lane) << 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < NBO; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb].x, in[k2 * 2 + 0], acc[nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NBO; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb].y, in[k2 * 2 + 1], acc[nb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k2 + 1 < K2) {
+#pragma unroll
+      for (int nb = 0; nb < NBO; ++nb) wc[nb] = wn[nb];
+    }
+  }
+}
+// accumulator init from a packed bias ([4 groups][NBO*4]; nullptr = zero)
+template <int NBO>
+RDRF_D void acc16_bias(f32x4 (&acc)[NBO], const float* __restrict__ bpk, int g) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) acc[nb] = bpk != nullptr ? *(const f32x4*)(bpk + g * (NBO * 4) + nb * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <int NBO>
+RDRF_D void acc16_relu(float (&out)[NBO * 4], const f32x4 (&acc)[NBO]) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) {
+    out[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); out[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
+    out[nb * 4 + 2] = fmaxf(acc[nb].z, 0.f); out[nb * 4 + 3] = fmaxf(acc[nb].w, 0.f);
+  }
+}
+// small output layer: sum_e W[o][e] * in[e] over all FOUR lane groups (no bias); ws: [4][KK]
+template <int KK>
+RDRF_D float dot_small16(const float (&in)[KK], const float* __restrict__ ws, int g) {
+  const float* w = ws + g * KK;
+  float a = 0.f;
+#pragma unroll
+  for (int k4 = 0; k4 < KK / 4; ++k4) {
+    const f32x4 v = *(const f32x4*)(w + k4 * 4);
+    a = fmaf(v.x, in[k4 * 4 + 0], a);
+    a = fmaf(v.y, in[k4 * 4 + 1], a);
+    a = fmaf(v.z, in[k4 * 4 + 2], a);
+    a = fmaf(v.w, in[k4 * 4 + 3], a);
+  }
+  a += __shfl_xor(a, 16, 64);
+  return a + __shfl_xor(a, 32, 64);
+}
+// two quads of two (plane, offset) pairs in one batch (12 loads in flight)
+RDRF_D void taps_quads2(const PlaneTaps& ta, const PlaneTaps& tb, f32x4 (&out)[2]) {
+  const f32x4 a00 = ld4(ta.p00), a01 = ld4(ta.p01), a10 = ld4(ta.p10), a11 = ld4(ta.p11), al0 = ld4(ta.l0), al1 = ld4(ta.l1);
+  const f32x4 b00 = ld4(tb.p00), b01 = ld4(tb.p01), b10 = ld4(tb.p10), b11 = ld4(tb.p11), bl0 = ld4(tb.l0), bl1 = ld4(tb.l1);
+  __builtin_amdgcn_sched_barrier(0);
+  out[0] = taps_combine(ta, a00, a01, a10, a11, al0, al1);
+  out[1] = taps_combine(tb, b00, b01, b10, b11, bl0, bl1);
+}
+// lane group g's five quads of a {48,12,12}-component set at stride level 0, 16-sample layout: out[4 j + c] = component c
+// of quad app16_quad(j, g) (zeros where that is padding)
+RDRF_D void gather_level_app16(const RdrfVM& vm, const PointTaps& pt, int g, float (&out_)[20]) {
+  {
+    const PlaneTaps xy = plane_taps(vm, 0, pt.x, pt.y, pt.z, 4 * g);
+    f32x4 v[3];
+    taps_quads<3>(xy, 16, v);   // quads g, g + 4, g + 8: 18 loads in flight
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      out_[4 * j + 0] = v[j].x; out_[4 * j + 1] = v[j].y; out_[4 * j + 2] = v[j].z; out_[4 * j + 3] = v[j].w;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // the second batch's pointers are formed AFTER the first batch's 72 load registers are free
+  const int q = 4 * (g < 3 ? g : 2);   // group 3 reads quad 2 again (a valid address) and drops the result
+  const PlaneTaps t3 = plane_taps(vm, 1, pt.x, pt.z, pt.y, q);
+  const PlaneTaps t4 = plane_taps(vm, 2, pt.y, pt.z, pt.x, q);
+  f32x4 w[2];
+  taps_quads2(t3, t4, w);   // 12 loads in flight
+  if (g == 3) { w[0] = f32x4{0.f, 0.f, 0.f, 0.f}; w[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    out_[12 + 4 * j + 0] = w[j].x; out_[12 + 4 * j + 1] = w[j].y; out_[12 + 4 * j + 2] = w[j].z; out_[12 + 4 * j + 3] = w[j].w;
+  }
+}
+
 // raw2alpha's per-sample factor 1 - alpha + 1e-10 (models/tensorBase.py:28, renderer.py:220)
 RDRF_D float one_minus_alpha_eps(float alpha) {
 #pragma clang fp contract(off)
@@ -740,6 +868,18 @@ constexpr int REG_SF = REG_K3 + K3_SIZE;
 constexpr int REG_DYN_END = REG_SF + SF_SIZE;
 constexpr int REG_S3 = 0;
 constexpr int REG_STAT_END = REG_S3 + S3_SIZE;
+// ---- static field, appearance phase on 16-sample tiles (k_static_app16): 16x16x4 fragments [nb][kk/2][64 lanes][2]
+constexpr int S16_BASIS = 0;                                  // 2 x 20
+constexpr int S16_W1_F = S16_BASIS + 2 * 20 * 64;             // 8 x 8
+constexpr int S16_W1_P = S16_W1_F + 8 * 8 * 64;               // 8 x 32
+constexpr int S16_W2 = S16_W1_P + 8 * 32 * 64;                // 8 x 32
+constexpr int S16_W3 = S16_W2 + 8 * 32 * 64;                  // small 3 x [4 groups][32]
+constexpr int S16_B1 = S16_W3 + 3 * 4 * 32;                   // biases [4 groups][32]
+constexpr int S16_B2 = S16_B1 + 128;
+constexpr int S16_SIZE = S16_B2 + 128;
+constexpr int REG_S16 = REG_STAT_END;                         // follows the 32-sample image in the static pack area
+constexpr int REG_STAT_END16 = REG_S16 + S16_SIZE;
+static_assert(S16_SIZE * 4 <= 160 * 1024, "the 16-sample image must fit the 160 KiB LDS");
 static_assert(K1_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
               "each kernel's weight image must fit the 160 KiB LDS");
 }  // namespace pk

@@ -22,6 +22,12 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app(FieldArgs a, Stat
   static_app_body<HEAD, FEAT, SAVE>(a, w, nullptr, grid_ctx());
 }
 
+#ifdef RDRF_TOOLS
+// 16-sample tiles, sixteen waves per workgroup = four per SIMD (rdrf_fwd_dev.hpp, static_app16_body): tools build only
+template <int HEAD, bool SAVE>
+__global__ __launch_bounds__(1024) void k_static_app16(FieldArgs a, StaticW w) { static_app16_body<HEAD, SAVE>(a, w); }
+#endif
+
 template <bool FEAT, bool SAVE = true>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density(FieldArgs a, DynW w) {
   dyn_density_body<FEAT, SAVE>(a, w, nullptr, grid_ctx());
@@ -190,6 +196,16 @@ void static_pack_jobs_fwd(PackJobs& J, const RdrfStaticParams* P, int head) {
   pack_add(J, P->w3, fea ? 128 : 131, 3, 128, SEG_IDENT, 1, 3, 64, REG_S3 + S3_W3);
   pack_add(J, P->b1, 0, 128, 0, 0, 3, 0, 64, REG_S3 + S3_B1);
   pack_add(J, P->b2, 0, 128, 0, 0, 3, 0, 64, REG_S3 + S3_B2);
+#ifdef RDRF_TOOLS
+  // the same weights as 16x16x4 fragments for the 16-sample-tile kernel (k_static_app16, tools build)
+  pack_add(J, P->basis, 72, 27, 72, SEG16_APP_G, 4, 2, 20, REG_S16 + S16_BASIS);
+  pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 4, 8, 8, REG_S16 + S16_W1_F);
+  pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 4, 8, 32, REG_S16 + S16_W1_P);
+  pack_add(J, P->w2, 128, 128, 128, SEG_IDENT, 4, 8, 32, REG_S16 + S16_W2);
+  pack_add(J, P->w3, fea ? 128 : 131, 3, 128, SEG_IDENT, 5, 3, 32, REG_S16 + S16_W3);
+  pack_add(J, P->b1, 0, 128, 0, 0, 6, 0, 32, REG_S16 + S16_B1);
+  pack_add(J, P->b2, 0, 128, 0, 0, 6, 0, 32, REG_S16 + S16_B2);
+#endif
 }
 
 void fill_static_w(StaticW& w, const RdrfStaticParams* P) {
@@ -304,6 +320,40 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
 #endif
   const Geo g = geo_for_tiles(N, S);
   const bool fea = cfg->static_head == RDRF_HEAD_MLP_FEA;
+#ifndef RDRF_DYNQ_DEFAULT
+#define RDRF_DYNQ_DEFAULT 1
+#endif
+#ifndef RDRF_WPRIO_DEFAULT
+#define RDRF_WPRIO_DEFAULT 0
+#endif
+#ifndef RDRF_STAGGER_DEFAULT
+#define RDRF_STAGGER_DEFAULT 0
+#endif
+  static const int dynq = RDRF_ENV("RDRF_DYNQ") ? atoi(RDRF_ENV("RDRF_DYNQ")) : RDRF_DYNQ_DEFAULT;   // 0: static tile stride (tools build)
+  static const int wprio = RDRF_ENV("RDRF_WPRIO") ? atoi(RDRF_ENV("RDRF_WPRIO")) : RDRF_WPRIO_DEFAULT;   // 1: distinct wave priorities
+  static const int stagger = RDRF_ENV("RDRF_STAGGER") ? atoi(RDRF_ENV("RDRF_STAGGER")) : RDRF_STAGGER_DEFAULT;   // x 8128 cycles per co-resident wave
+  a.dynq = (dynq ? 1 : 0) | (wprio ? 2 : 0) | (stagger << 8);
+#ifdef RDRF_TOOLS
+  // k_static_app16 (16-sample tiles, four waves per SIMD) is an EXPERIMENT of the tools build: 4-11 % slower than the 32-sample
+  // kernel (profiles/r06_ab_static_app16.txt, r06_pmc_static_app16.csv): RDRF_SA16=1 selects it
+  static const int sa16 = RDRF_ENV("RDRF_SA16") ? atoi(RDRF_ENV("RDRF_SA16")) : 0;
+  if (sa16) {
+    // 16-sample tiles: up to sixteen waves per workgroup, one workgroup per CU (its LDS holds the 159 KB image)
+    const long t16 = (((long)N * S + 31) / 32) * 2;
+    int waves = (int)((t16 + 255) / 256);
+    waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+    const long blocks = (t16 + waves - 1) / waves;
+    const dim3 gr((unsigned)(blocks > 256 ? 256 : blocks)), bl(waves * 64);
+    if (saved != nullptr) {
+      if (fea) RDRF_LAUNCH("static_app", (k_static_app16<RDRF_HEAD_MLP_FEA, true>), gr, bl, stream, a, w);
+      else RDRF_LAUNCH("static_app", (k_static_app16<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING, true>), gr, bl, stream, a, w);
+    } else {
+      if (fea) RDRF_LAUNCH("static_app", (k_static_app16<RDRF_HEAD_MLP_FEA, false>), gr, bl, stream, a, w);
+      else RDRF_LAUNCH("static_app", (k_static_app16<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING, false>), gr, bl, stream, a, w);
+    }
+    return 0;
+  }
+#endif
   if (saved != nullptr) {
     if (fea) RDRF_LAUNCH("static_app", (k_static_app<RDRF_HEAD_MLP_FEA, false, true>), dim3(g.grid), dim3(g.block), stream, a, w);
     else RDRF_LAUNCH("static_app", (k_static_app<RDRF_HEAD_MLP_FEA_TIMEEMBEDDING, false, true>), dim3(g.grid), dim3(g.block), stream, a, w);

@@ -40,6 +40,45 @@ RDRF_D int block_append_base(int* counter, int cnt, int* s_cnt, int tid, int nth
   return s_cnt[wave];
 }
 
+// Tile queue of a persistent workgroup (round 6).  Workgroup b owns the tiles b, b + G, b + 2 G, ... (G workgroups); its
+// waves used to walk them with a static stride.  The SIMD's issue arbitration favours the oldest wave, so the waves of a
+// workgroup progress at different speeds: the favoured ones finish their share early and the pipe then runs the
+// stragglers alone (measured: matrix pipe 0.82 busy inside the steady state of k_static_app but 0.745 over the CU's busy
+// time).  With the queue a wave takes the workgroup's next tile whenever it is done: position k = wave for the first
+// tile, then a returning LDS atomic.  s_next must be initialised to the wave count before the first barrier.
+RDRF_D int tile_queue_next(int* s_next, int k, int nwaves, bool dyn) {
+  if (!dyn) return k + nwaves;
+  int v = 0;
+  if ((threadIdx.x & 63) == 0) v = atomicAdd(s_next, 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Distinct static issue priorities for the waves that share a SIMD (round 6).  The waves of a persistent workgroup start
+// together and do identical work per tile, and the SIMD's arbitration is fair between waves of equal priority -- so they stay
+// in LOCKSTEP: all of them gather, then all of them want the matrix pipe.  The measured wave time per tile is exactly
+// (waves per SIMD) x (MFMA cycles of a tile) + (non-MFMA time of ONE tile): 2 x 39.2 k + 17 k = 95.8 k cycles in
+// k_static_app, 4 x 19.7 k + 24 k = 102.5 k in k_static_app16 -- the non-MFMA phase is never hidden.  With a different
+// priority per co-resident wave (waves i, i + 4, i + 8, ... share a SIMD: priority 3 - (wave >> 2)) the favoured wave runs its
+// MFMA chain at full rate and is in its gather phase while the next one computes; the tile queue evens out the tile counts.
+RDRF_D void set_wave_priority(int wave) {
+  switch ((wave >> 2) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+  }
+}
+
+// Start-up stagger (round 6): the k-th wave of a SIMD (k = wave >> 2) sleeps k * n * 8128 cycles once before its first tile.
+// Two waves that share the matrix pipe fairly keep whatever phase difference they start with (the one that entered its
+// MFMA chain first also leaves it first, by the same margin), and they start with none -- so their gather phases coincide
+// for the whole launch (see set_wave_priority; s_setprio does not change the MFMA arbitration, measured twice).  An initial
+// offset of about half a tile puts one wave's gathers under the other's MFMA chain.
+RDRF_D void stagger_start(int wave, int n) {
+  const int k = (wave >> 2) & 3;
+  for (int i = 0; i < k * n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 template <bool FEAT, bool FUSED = false>
 RDRF_D void static_density_body(const FieldArgs a, const StaticW w, const GridCtx gc) {
   __shared__ int s_cnt[16];
@@ -142,13 +181,18 @@ RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused
     __shared__ __attribute__((aligned(16))) float lds_own[pk::S3_SIZE];
     lds = lds_own;
   }
+  __shared__ int s_next;
+  if (GC_TID == 0) s_next = GC_NTHR >> 6;
   lds_fill(lds, a.pk + pk::REG_S3, pk::S3_SIZE);
   const int lane = GC_TID & 63, h = lane >> 5, s = lane & 31;
   const int wave = GC_TID >> 6, nwaves = GC_NTHR >> 6;
   const int count = FEAT ? a.M : *a.counter;
   const int ntiles = (count + 31) >> 5;
   const float* pkw = lds;
-  for (int tile = GC_BID * nwaves + wave; tile < ntiles; tile += GC_NBLK * nwaves) {
+  const bool dynq = !FUSED && (a.dynq & 1) != 0;
+  if (!FUSED && (a.dynq & 2)) set_wave_priority(wave);
+  if (!FUSED) stagger_start(wave, a.dynq >> 8);
+  for (int k = wave, tile; (tile = GC_BID + k * GC_NBLK) < ntiles; k = tile_queue_next(&s_next, k, nwaves, dynq)) {
     const int li = tile * 32 + s;
     const bool act = li < count;
     const int idx = act ? (FEAT ? li : a.list[li]) : 0;
@@ -235,6 +279,148 @@ RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused
       if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING)
         v += w.w3[o * 131 + 128] * vx + w.w3[o * 131 + 129] * vy + w.w3[o * 131 + 130] * vz;
       if (act && h == 0) a.rgb[(size_t)idx * 3 + o] = sigmoidf_(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The static appearance phase on 16-SAMPLE tiles (round 6).  static_app_body holds a 32-sample tile per
+// wave on v_mfma_f32_32x32x2_f32: 64 + 64 + 64 activation / accumulator registers, 256 VGPRs, two waves per SIMD -- which
+// do not cover the gather round trips of a tile (64 % of the wave cycles in SQ_WAIT_INST_ANY).  Here a wave owns 16 samples
+// on v_mfma_f32_16x16x4_f32 (same FLOP per cycle): lane (g = l>>4, s = l&15) holds a quarter of sample s' vector, every
+// activation / accumulator array is half as long, the kernel fits 128 VGPRs and runs sixteen waves per workgroup = four
+// per SIMD.  Same arithmetic per element as static_app_body (the MFMA k order differs: sums of the same products in
+// another order), same saved rows ([32-sample tile][row][32]: tile16 t writes columns 16 (t & 1) .. + 15 of tile t >> 1),
+// so the backward kernels are unchanged.  Ray path only (FEAT / FUSED stay on static_app_body).
+// ------------------------------------------------------------------------------------------------
+// tile_base is WAVE-UNIFORM (a scalar register pair), voff = 128 g + s the lane's float offset inside a row block: every
+// store is `global_store_dword voff, data, s[base] offset:imm` -- no 64-bit per-lane row pointers to keep alive or spill
+template <int KK>
+RDRF_D void save_rows16(float* __restrict__ tile_base, int row0, const float (&v)[KK], unsigned voff) {
+  if (tile_base == nullptr) return;
+#ifdef RDRF_ABL_NOSAVE
+  return;
+#endif
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+    __builtin_nontemporal_store(v[kk], tile_base + (row0 + ((kk >> 2) << 4) + (kk & 3)) * 32 + voff);
+}
+
+template <int HEAD, bool SAVE>
+RDRF_D void static_app16_body(const FieldArgs a, const StaticW w) {
+  __shared__ __attribute__((aligned(16))) float lds[pk::S16_SIZE];
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = blockDim.x >> 6;
+  lds_fill(lds, a.pk + pk::REG_S16, pk::S16_SIZE);
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int count = *a.counter;
+  const int ntiles = ((count + 31) >> 5) * 2;   // both halves of the last 32-sample tile: its saved rows are read whole
+  const float* pkw = lds;
+  const unsigned voff = 128 * g + s;                                 // rows 4 g + r of a 16-row block, column s
+  const unsigned voffP = (32 * (g >> 1) + 4 * (g & 1)) * 32 + s;     // PE rows: the row of element (feature w, m) in the 32-sample order
+  const bool dynq = (a.dynq & 1) != 0;
+  if (a.dynq & 2) set_wave_priority(wave);
+  stagger_start(wave, a.dynq >> 8);
+  for (int k = wave, tile_; (tile_ = blockIdx.x + k * gridDim.x) < ntiles; k = tile_queue_next(&s_next, k, nwaves, dynq)) {
+    const int tile = __builtin_amdgcn_readfirstlane(tile_);   // wave-uniform: the saved-row base stays in scalar registers
+    const int li = tile * 16 + s;
+    const bool act = li < count;
+    const int idx = act ? a.list[li] : 0;
+    const int n = idx / a.S;
+    float* svb = (SAVE && a.act3) ? a.act3 + (size_t)(tile >> 1) * sv::S3_ROWS * 32 + 16 * (tile & 1) : nullptr;
+    float vx, vy, vz;
+    ray_norm(a.rays, n, a.ray_type, vx, vy, vz);
+    const float x0 = norm_c(a.xyz[idx * 3 + 0], a.box.lo[0], a.box.inv[0]);
+    const float x1 = norm_c(a.xyz[idx * 3 + 1], a.box.lo[1], a.box.inv[1]);
+    const float x2 = norm_c(a.xyz[idx * 3 + 2], a.box.lo[2], a.box.inv[2]);
+    float F[8];
+    {
+      float G[20];
+      // g made opaque per tile: left visible, the optimiser hoists every lane-dependent pointer (plane / line base + quad
+      // offset of the lane group, eleven 64-bit values) out of the tile loop and spills them
+      int gq = g;
+      asm volatile("" : "+v"(gq));
+      gather_level_app16(w.app, point_taps<true>(w.app, x0, x1, x2, 0), gq, G);
+      if (!act) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) G[i] = 0.f;
+      }
+      if (svb != nullptr) {   // rows in the natural component order: XY quads 4 j + g, XZ quads 12 + g, YZ quads 15 + g
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk)
+          __builtin_nontemporal_store(G[kk], svb + (sv::S3_G + ((kk >> 2) << 4) + (kk & 3)) * 32 + voff);
+        if (g < 3) {
+#pragma unroll
+          for (int kk = 12; kk < 20; ++kk)
+            __builtin_nontemporal_store(G[kk], svb + (sv::S3_G + (kk < 16 ? 48 : 60) + (kk & 3)) * 32 + voff);
+        }
+      }
+      f32x4 accF[2];
+      acc16_bias<2>(accF, nullptr, g);
+      mfma16_seg<2, 20>(accF, G, pkw + pk::S16_BASIS, lane);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        F[nb * 4 + 0] = accF[nb].x; F[nb * 4 + 1] = accF[nb].y; F[nb * 4 + 2] = accF[nb].z; F[nb * 4 + 3] = accF[nb].w;
+      }
+    }
+    float P[32];
+    {
+      float fmax_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) fmax_ = fmaxf(fmax_, fabsf(F[r]));
+      if (__builtin_expect(__any(!(fmax_ * 2.0f <= RDRF_PE_FAST_MAX)), 0)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float s1, c1, s2, c2;
+          sincosf(F[r], &s1, &c1);
+          sincosf(F[r] * 2.0f, &s2, &c2);
+          P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float s1, c1, s2, c2;
+          sincos_sel<true>(F[r], s1, c1);
+          sincos_sel<true>(F[r] * 2.0f, s2, c2);
+          P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
+        }
+      }
+    }
+    if (HEAD == RDRF_HEAD_MLP_FEA) {  // viewdirs ride in the pad elements 27..29 of the feature block
+      if (g == 2) F[7] = vx;
+      if (g == 3) { F[4] = vy; F[5] = vz; }
+    }
+    if (svb != nullptr) {
+      if (g == 0) {
+        svb[(size_t)(sv::S3_VD + 0) * 32 + s] = vx; svb[(size_t)(sv::S3_VD + 1) * 32 + s] = vy;
+        svb[(size_t)(sv::S3_VD + 2) * 32 + s] = vz;
+      }
+      save_rows16<8>(svb, sv::S3_F, F, voff);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          __builtin_nontemporal_store(P[4 * r + m], svb + (sv::S3_P + 64 * (r >> 2) + 8 * (r & 3) + m) * 32 + voffP);
+    }
+    f32x4 acc[8];
+    float H[32];
+    __builtin_amdgcn_sched_barrier(0);   // the 32 accumulator registers are claimed after the encodings' temporaries are dead
+    acc16_bias<8>(acc, pkw + pk::S16_B1, g);
+    mfma16_seg<8, 8>(acc, F, pkw + pk::S16_W1_F, lane);
+    mfma16_seg<8, 32>(acc, P, pkw + pk::S16_W1_P, lane);
+    acc16_relu<8>(H, acc);
+    save_rows16<32>(svb, sv::S3_H1, H, voff);
+    acc16_bias<8>(acc, pkw + pk::S16_B2, g);
+    mfma16_seg<8, 32>(acc, H, pkw + pk::S16_W2, lane);
+    acc16_relu<8>(H, acc);
+    save_rows16<32>(svb, sv::S3_H2, H, voff);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = dot_small16<32>(H, pkw + pk::S16_W3 + o * 128, g) + w.b3[o];
+      if (HEAD == RDRF_HEAD_MLP_FEA_TIMEEMBEDDING)
+        v += w.w3[o * 131 + 128] * vx + w.w3[o * 131 + 129] * vy + w.w3[o * 131 + 130] * vz;
+      if (act && g == 0) a.rgb[(size_t)idx * 3 + o] = sigmoidf_(v);
     }
   }
 }

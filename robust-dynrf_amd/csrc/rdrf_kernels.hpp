@@ -33,6 +33,7 @@ struct FieldArgs {
   int M;         // number of points
   int in_norm;   // 1: `xyz` holds NORMALISED coordinates (compute_*), 0: un-normalised (warp_coordinate)
   float* feat;   // [M][27] appearance features (basis_mat output) or nullptr
+  int dynq;      // 1: the waves of a persistent workgroup draw their tiles from a queue in LDS (tile_queue_next)
 };
 
 struct StaticW {

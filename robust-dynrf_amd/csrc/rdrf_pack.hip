@@ -112,6 +112,30 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
       }
       dst[J.dst + i] = v;
     }
+  } else if (J.mode == 4) {  // 16x16x4 fragments: [nb][kk/2][64 lanes][2], lane = (g << 4) | neuron
+    const int total = J.nb * J.kk * 64;
+    const int k2n = J.kk >> 1;
+    for (int i = tid; i < total; i += stride) {
+      const int q = i & 1, lane = (i >> 1) & 63, rest = i >> 7;
+      const int k2 = rest % k2n, nb = rest / k2n;
+      const int kk = k2 * 2 + q, g = lane >> 4, o = nb * 16 + (lane & 15);
+      const int col = seg_imap16(J.seg, kk, g, J.in_dim);
+      dst[J.dst + i] = (o < J.out_dim && col >= 0) ? J.src[(size_t)o * J.ld + col] : 0.f;
+    }
+  } else if (J.mode == 5) {  // small layer, 16-sample layout: [OUT][4 groups][kk]
+    const int total = J.nb * 4 * J.kk;
+    for (int i = tid; i < total; i += stride) {
+      const int kk = i % J.kk, g = (i / J.kk) & 3, o = i / (4 * J.kk);
+      const int col = seg_imap16(J.seg, kk, g, J.in_dim);
+      dst[J.dst + i] = (o < J.out_dim && col >= 0) ? J.src[(size_t)o * J.ld + col] : 0.f;
+    }
+  } else if (J.mode == 6) {  // bias, 16-sample layout: [4 groups][kk]
+    const int total = 4 * J.kk;
+    for (int i = tid; i < total; i += stride) {
+      const int kk = i % J.kk, g = i / J.kk;
+      const int o = elem16_of(kk, g);
+      dst[J.dst + i] = (J.src != nullptr && o < J.out_dim) ? J.src[o] : 0.f;
+    }
   } else if (J.mode == 3) {  // bias: [2][kk] canonical
     const int total = 2 * J.kk;
     for (int i = tid; i < total; i += stride) {
