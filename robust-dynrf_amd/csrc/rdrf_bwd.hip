@@ -2279,6 +2279,10 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
 // 54-60 KB), there are two of them, and `buffer_load_dwordx4 ... lds` moves a half stage straight from HBM into the buffer
 // that is not being read: step s = barrier; issue the DMA of step s + 1; the products of step s (8 MFMAs each, K = 16
 // samples).  One barrier per half stage, no staging registers, no LDS write instructions.
+// Measured (profiles/r06_ab_dw3_*.txt): dw launches 2.02 -> 1.91 ms/step at stage 0, 4.40 -> 4.10 at the final stage.  Ablations:
+// MFMAs + barriers alone 1.05 ms (dw_dyn, stage 0), DMA + barriers alone 1.29 -- the memory side binds, and NOT through its
+// latency: a ring of 80 block slots that keeps two half stages in flight (counted vmcnt, raw s_barrier) left the DMA-only time
+// at 1.30 ms and made the kernel slower (1.56); the 64-byte half rows fetch every 128-byte line in two visits a step apart.
 //   LDS image of a block (32 rows x 16 samples = 2 KB): float4 position p = row * 4 + (chunk ^ ((row >> 2) & 3)); a DMA
 //   instruction fills 1 KB in lane order (base + lane * 16 -- the hardware's layout), so the swizzle sits on the SOURCE
 //   address of lane l (row = 16 sub + (l >> 2), chunk = (l & 3) ^ ((row >> 2) & 3)) and on the read (cdna guide, rule 21);
@@ -2350,6 +2354,7 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw3(Dw2Plan P) {
     int tn = t, hn = hf ^ 1;
     if (hf) tn = t + gridDim.x;
     if (tn < ntiles) dma(tn, hn, buf ^ 1);   // lands while the MFMAs below run
+    __builtin_amdgcn_sched_barrier(0);       // (issued BEFORE the products: hipcc is free to sink it below them otherwise)
 #ifndef RDRF_ABL_DW_NOMFMA
     const f32x4* stage = dw3_stage + buf * hbuf;
 #pragma unroll
