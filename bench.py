@@ -581,7 +581,8 @@ def compact_line(out):
                                       "scaling", "vs_baseline", "dtype", "data") if k in out}
     line["schema"] = SCHEMA
     line["config"] = {k: cfg[k] for k in ("workload", "baseline_config_index", "config", "stage", "grid", "samples_per_ray",
-                                          "global_batch", "rays_per_gpu", "parallelism", "backend", "timed_region", "dead_work")
+                                          "global_batch", "rays_per_gpu", "parallelism", "ranks", "backend", "exchange_bytes_per_step", "final_loss",
+                                          "timed_region", "dead_work")
                       if k in cfg}
     rf = out.get("roofline")
     if rf:
@@ -663,6 +664,12 @@ def main():
     ap.add_argument("--no-sparse", action="store_true", help="skip the W-sparse (app mask ~0.10) training / render leg")
     ap.add_argument("--no-cpu-4096", action="store_true", help="skip the single 4096-ray CPU step (about one minute)")
     ap.add_argument("--render-chunk", type=int, default=0, help="rays per render call (default: a whole frame)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the full record (bench_detail.json's content) as the last line instead of the compact one: for "
+                         "the tools/ab_*.sh scripts, which read per-kernel tables from the line -- never for the driver")
+    ap.add_argument("--no-liveness-leg", action="store_true",
+                    help="skip the secondary liveness_exploited leg (profiling runs: every iteration of the process is then the "
+                         "same workload)")
     ap.add_argument("--exploit-liveness", action="store_true",
                     help="skip the work whose results nothing consumes (SURVEY 3.1 liveness table): the dynamic-field forward of "
                          "passes E / P3 / P4 and the colours of both fields in passes B-D / P1-P4; by default it is executed like "
@@ -769,7 +776,7 @@ def main():
                    else "executed (work the reference also computes although nothing consumes it)"},
     }
 
-    if not args.exploit_liveness:
+    if not args.exploit_liveness and not args.no_liveness_leg:
         # secondary figure: the same step without the dead dynamic forwards (identical results)
         trainer.dead_work = False
         dt2, _ = timed_steps(trainer, shard, max(10, args.steps // 4), 2, world, dev)
@@ -880,7 +887,7 @@ def main():
         out["schema"] = SCHEMA
         write_detail(out)
         sys.stdout.flush()
-        print(compact_line(out), flush=True)
+        print(json.dumps(out) if args.full_line else compact_line(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

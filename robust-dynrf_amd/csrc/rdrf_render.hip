@@ -300,6 +300,29 @@ extern "C" int rdrf_render_chunks_fwd(const RdrfStaticParams* PS, const RdrfFiel
   const int ns = nstreams < 1 ? 1 : nstreams;
   const size_t slice = (rdrf_render_workspace_bytes(chunk < N ? chunk : N, S) + 255) & ~(size_t)255;
   RDRF_CHECK(ws_bytes >= slice * ns, -3, "render_chunks: workspace too small: need %zu have %zu", slice * ns, ws_bytes);
+  {
+    // Chunk coalescing (round 6).  The workspace the caller sized for `nstreams` concurrent chunks holds ONE launch sequence
+    // over that many chunks' rays just as well, and a ray's result does not depend on which other rays share its launch
+    // (per-ray scans, per-sample MFMA columns: tests/test_gpu_forward.py compares chunked and whole-batch renders bit for
+    // bit).  A group of g chunks pays the fixed costs of a launch sequence once -- ten launches, two 121-159 KB LDS weight
+    // images per CU and MLP kernel -- instead of g times: the frame time of the 512-ray loop was the SUM of its chunks'
+    // isolated kernel times (profiles/r05_render_chunk512_kernel_stats.csv), streams or not.
+    static const int coalesce = RDRF_ENV("RDRF_CHUNK_COALESCE") ? atoi(RDRF_ENV("RDRF_CHUNK_COALESCE")) : 1;   // 0: one sequence per chunk (tools build)
+    int g = 1;
+    while (coalesce && g < 256 && (long)g * chunk < N && rdrf_render_workspace_bytes((g + 1) * chunk, S) <= ws_bytes &&
+           (size_t)(g + 1) * chunk * S * 3 < (size_t)INT32_MAX)
+      ++g;
+    if (g > 1) {
+      const int super = g * chunk;
+      for (int c0 = 0; c0 < N; c0 += super) {
+        const int n = N - c0 < super ? N - c0 : super;
+        const int rc = rdrf_render_sequence_fwd(PS, cfg_s, PD, cfg_d, rays + (size_t)c0 * 6, ts + c0, n, S, near, far,
+                                                rgb_map + (size_t)c0 * 3, depth_map + c0, ws, ws_bytes, main_stream_);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   hipEvent_t ev_start = nullptr, ev_done[16];
   if (nstreams >= 1) {
     RDRF_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));

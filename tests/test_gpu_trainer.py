@@ -94,7 +94,10 @@ def test_bench_two_ranks_functional(dp):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 1024 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["config"]["ranks"] == 2 and dp in d["config"]["parallelism"]
     assert d["config"]["backend"] == "gloo" and d["config"]["exchange_bytes_per_step"] > 1e6
-    assert "roofline" in d and d["roofline"]["kernel_ms_per_step"]["adam"] > 0
+    assert "roofline" in d and len(line) < 8192
+    detail = json.load(open(os.path.join(root, d["detail"])))   # the per-kernel tables live in the side file (bench.write_detail)
+    assert detail["n_gpus"] == 2 and detail["roofline"]["kernel_ms_per_step"]["adam"] > 0
+    assert detail["config"]["exchange_plan"]["issued"] is True
 
 
 @pytest.mark.parametrize("dp", ["zero1", "allreduce"])

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for cfg in "nvidia_no_poses stage0" "nvidia_no_poses final" "davis stage0" "davis final"; do
   set -- $cfg
   for bp in 0 1; do
-    RDRF_BATCH_PASSES=$bp timeout 300 python bench.py --config $1 --stage $2 --steps 20 --warmup 3 --no-cpu-baseline --no-final-stage --no-render --no-sparse --no-roofline 2>&1 | tail -1 > gpurun_out/abc.log
+    RDRF_BATCH_PASSES=$bp timeout 300 python bench.py --full-line --config $1 --stage $2 --steps 20 --warmup 3 --no-cpu-baseline --no-final-stage --no-render --no-sparse --no-roofline 2>&1 | tail -1 > gpurun_out/abc.log
     python - "$1" "$2" "$bp" <<'PY'
 import json, sys
 try:

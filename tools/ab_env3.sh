@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for r in 1 2; do
   for arm in A B C; do
     case $arm in A) E="$A";; B) E="$B";; C) E="$Cc";; esac
-    env $E timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-final-stage --no-render --no-sparse "$@" 2>&1 | tail -1 > gpurun_out/ab_${arm}_$r.log
+    env $E timeout 300 python bench.py --full-line --steps 40 --warmup 5 --no-cpu-baseline --no-final-stage --no-render --no-sparse "$@" 2>&1 | tail -1 > gpurun_out/ab_${arm}_$r.log
   done
 done
 python - <<'PY'

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
 for lib in "$@"; do
-  RDRF_LIB=$PWD/$lib timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-final-stage --no-render --no-sparse $BENCH_EXTRA 2>&1 | tail -1 > gpurun_out/ablib.log
+  RDRF_LIB=$PWD/$lib timeout 300 python bench.py --full-line --steps 30 --warmup 5 --no-cpu-baseline --no-final-stage --no-render --no-sparse $BENCH_EXTRA 2>&1 | tail -1 > gpurun_out/ablib.log
   python - "$lib" <<'PY'
 import json, sys
 try:

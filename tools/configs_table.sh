@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
 for cfg in "nvidia_no_poses stage0" "nvidia_no_poses final" "davis stage0" "davis final"; do
   set -- $cfg
-  timeout 400 python bench.py --config $1 --stage $2 --steps 20 --warmup 3 --no-cpu-baseline --no-final-stage --no-render --no-sparse --no-roofline 2>&1 | tail -1 > gpurun_out/cfgt.log
+  timeout 400 python bench.py --full-line --config $1 --stage $2 --steps 20 --warmup 3 --no-cpu-baseline --no-final-stage --no-render --no-sparse --no-roofline 2>&1 | tail -1 > gpurun_out/cfgt.log
   python - "$1" "$2" <<'PY'
 import json, sys
 try:
