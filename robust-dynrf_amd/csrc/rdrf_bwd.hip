@@ -118,6 +118,7 @@ struct BwdArgs {
   int M, in_norm;
   const float* g_feat;
   int small_dw;   // ray path: k_dyn_density_bwd forms the weight gradients of layer5 / density_layer2 / blending_layer2
+  int dynq;       // 1: the compacted-tile kernels draw their tiles from the workgroup's queue (tile_queue_next)
 };
 
 struct StaticG {
@@ -823,6 +824,8 @@ RDRF_D void feat_dF(float (&dF)[16], const float* g_feat, int idx, bool act, int
 // REC: d(app features) go out as sample-major records for the sorted scatter (a.dfa) instead of DA rows
 template <bool FEAT, bool REC = false>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = blockDim.x >> 6;   // (before the barrier of lds_fill)
   __shared__ __attribute__((aligned(16))) float lds[pkb::K3_SIZE];
   lds_fill(lds, a.pk + pkb::REG_K3, pkb::K3_SIZE);
   const float* basisT = lds + pkb::K3_BASIST;
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int count = FEAT ? a.M : a.sp.hdr->count;
   const int ntiles = (count + 31) >> 5;
-  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+  for (int k = wave, tile; (tile = blockIdx.x + k * gridDim.x) < ntiles; k = tile_queue_next(&s_next, k, nwaves, a.dynq != 0)) {
     const int li = tile * 32 + s;
     const bool act = li < count;
     const int idx = act ? (FEAT ? li : a.sp.list[li]) : 0;
@@ -934,13 +937,15 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
 
 template <int HEAD, bool FEAT>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, StaticW w, StaticG gw) {
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = blockDim.x >> 6;   // (before the barrier of lds_fill)
   __shared__ __attribute__((aligned(16))) float lds[pkb::S3_SIZE];
   lds_fill(lds, a.pk + pkb::REG_S3, pkb::S3_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int count = FEAT ? a.M : a.sp.hdr->count;
   const int ntiles = (count + 31) >> 5;
-  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+  for (int k = wave, tile; (tile = blockIdx.x + k * gridDim.x) < ntiles; k = tile_queue_next(&s_next, k, nwaves, a.dynq != 0)) {
     const int li = tile * 32 + s;
     const bool act = li < count;
     const int idx = act ? (FEAT ? li : a.sp.list[li]) : 0;
@@ -2588,6 +2593,8 @@ static void fill_bwd_common(BwdArgs& a, const RdrfFieldCfg* cfg, const float* ra
   a.distance_scale = cfg->distance_scale; a.weight_thres = cfg->weight_thres;
   a.density_shift = cfg->density_shift; a.act = cfg->act; a.ray_type = cfg->ray_type;
   a.static_head = cfg->static_head;
+  static const int dynq = RDRF_ENV("RDRF_DYNQ") ? atoi(RDRF_ENV("RDRF_DYNQ")) : 1;   // 0: static tile stride (tools build)
+  a.dynq = dynq;
 }
 
 // forward calls (either field, scene flow): pack area + counter + tout + xw + list -- what an inference-only caller needs

@@ -639,6 +639,19 @@ RDRF_D void sincos_sel(float a, float& s, float& c) {
 #endif
 }
 
+// (sin, cos) of the doubled angle from (sin, cos) of the angle: sin 2a = 2 s c, cos 2a = 1 - 2 s^2 -- three VALU
+// instructions instead of the ~26 of sincos_pe.  Round 6: fp32 MFMAs and VALU instructions of the waves of a SIMD do not
+// overlap (tools/micro/mfma_valu_overlap.hip: the times ADD), so every VALU instruction of the MLP kernels costs its four
+// cycles of the step; the encodings are their largest VALU item.  Used for the static head's feature encoding (sin 2F, cos 2F)
+// only: the absolute error of the doubled pair is <= 2 x that of the exact one + 1.2e-7 (~3e-7 worst,
+// tests/test_abi_cpu.py::test_sincos_double_formula), which the coordinate encodings of the dynamic field did not tolerate
+// (fill_x0_impl).
+RDRF_D void sincos_double(float s, float c, float& s2, float& c2) {
+  const float t = s + s;
+  s2 = t * c;
+  c2 = fmaf(-t, s, 1.0f);
+}
+
 template <bool FAST>
 RDRF_D void fill_x0_impl(float (&X0)[32], float xn0, float xn1, float xn2, float t, int h) {
 #pragma unroll
@@ -646,17 +659,18 @@ RDRF_D void fill_x0_impl(float (&X0)[32], float xn0, float xn1, float xn2, float
     if (o == 0 && h == 0) {
       X0[0] = xn0; X0[1] = xn1; X0[2] = xn2; X0[3] = t;
     } else {
-      const int k = 2 * o + h - 1;  // quad index 0..14
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int j = 2 * k + p;
-        const int d = j / 10, f = j - d * 10;
-        const float x = d == 0 ? xn0 : (d == 1 ? xn1 : xn2);
-        float sv, cv;
-        sincos_sel<FAST>(ldexpf(x, f), sv, cv);
-        X0[o * 4 + 2 * p] = sv;
-        X0[o * 4 + 2 * p + 1] = cv;
-      }
+      const int k = 2 * o + h - 1;  // quad index 0..14: the pair of octaves (f, f + 1), f even, of one coordinate
+      const int j = 2 * k;
+      const int d = j / 10, f = j - d * 10;
+      const float x = d == 0 ? xn0 : (d == 1 ? xn1 : xn2);
+      float sv, cv;
+      sincos_sel<FAST>(ldexpf(x, f), sv, cv);
+      X0[o * 4 + 0] = sv;
+      X0[o * 4 + 1] = cv;
+      // (the odd octave exactly too: with sincos_double here -- 3 VALU instead of 26, -170 per tile -- the app-mask decisions
+      // `weight > 1e-4` of a few samples flipped against the oracle's and test_trainer_step_gradient_matches_oracle_step
+      // [nvidia-30000] moved by 2.6e-3 of the appearance gradients: the coordinates' encodings feed sigma, the features' do not)
+      sincos_sel<FAST>(ldexpf(x, f + 1), X0[o * 4 + 2], X0[o * 4 + 3]);
     }
   }
 }
@@ -668,15 +682,14 @@ RDRF_D void fill_x0(float (&X0)[32], float xn0, float xn1, float xn2, float t, i
 template <bool FAST>
 RDRF_D void fill_x1_impl(float (&X1)[8], float t, int h) {
 #pragma unroll
-  for (int o = 0; o < 2; ++o)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int f = 4 * o + 2 * h + p;
-      float sv, cv;
-      sincos_sel<FAST>(ldexpf(t, f), sv, cv);
-      X1[o * 4 + 2 * p] = sv;
-      X1[o * 4 + 2 * p + 1] = cv;
-    }
+  for (int o = 0; o < 2; ++o) {
+    const int f = 4 * o + 2 * h;   // octaves (f, f + 1), f even
+    float sv, cv;
+    sincos_sel<FAST>(ldexpf(t, f), sv, cv);
+    X1[o * 4 + 0] = sv;
+    X1[o * 4 + 1] = cv;
+    sincos_sel<FAST>(ldexpf(t, f + 1), X1[o * 4 + 2], X1[o * 4 + 3]);
+  }
 }
 RDRF_D void fill_x1(float (&X1)[8], float t, int h) {
   if (__builtin_expect(__any(!(fabsf(t) * 128.0f <= RDRF_PE_FAST_MAX)), 0)) fill_x1_impl<false>(X1, t, h);

@@ -62,6 +62,9 @@ RDRF_D void fill_sf_x(float (&X)[20], float xn0, float xn1, float xn2, float t, 
       X[0] = xn0; X[1] = xn1; X[2] = xn2; X[3] = t;
     } else {
       const int k = 2 * o + h - 1;
+      // (exact sin / cos for every octave here: the scene-flow losses are L1 terms, and with the doubled-angle form of
+      // rdrf_common.hpp sincos_double one sign flip of a ~0 flow component moved the nvidia_late reference-trainer
+      // comparison by 8e-4 of a gradient's max -- the kernel is 0.15 ms of the step, the 60 VALU instructions stay)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int pr = 2 * k + p;
@@ -85,15 +88,17 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_scene_flow(const float* __re
                                                    Box box, const float* __restrict__ pkg, DynW w,
                                                    float* __restrict__ sf_f,
                                                    float* __restrict__ sf_b,
-                                                   float* __restrict__ act_rows) {
+                                                   float* __restrict__ act_rows, int dynq) {
   __shared__ __attribute__((aligned(16))) float lds[pk::SF_SIZE];
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = blockDim.x >> 6;
   lds_fill(lds, pkg + pk::REG_SF, pk::SF_SIZE);
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const float* pkw = lds;
   const int total = N * S;
   const int ntiles = (total + 31) >> 5;
-  for (int tile = blockIdx.x * nwaves + wave; tile < ntiles; tile += gridDim.x * nwaves) {
+  for (int k = wave, tile; (tile = blockIdx.x + k * gridDim.x) < ntiles; k = tile_queue_next(&s_next, k, nwaves, dynq != 0)) {
     const int li = tile * 32 + s;
     const bool act = li < total;
     const int idx = act ? li : 0;
@@ -284,6 +289,25 @@ static Geo geo_for_units(long units) {
 }
 static Geo geo_for_tiles(int N, int S) { return geo_for_units(((long)N * S + 31) / 32); }
 
+#ifndef RDRF_DYNQ_DEFAULT
+#define RDRF_DYNQ_DEFAULT 1
+#endif
+#ifndef RDRF_WPRIO_DEFAULT
+#define RDRF_WPRIO_DEFAULT 0
+#endif
+#ifndef RDRF_STAGGER_DEFAULT
+#define RDRF_STAGGER_DEFAULT 0
+#endif
+// FieldArgs::dynq of the forward launches: bit 0 = per-workgroup tile queue (default on: +1-2 % on the compacted-tile MLP
+// kernels), bit 1 = distinct wave priorities, bits 8.. = start-up stagger -- the last two are recorded negative experiments
+// (profiles/r06_ab_static_app16.txt), reachable in the tools build only
+int fwd_dynq() {
+  static const int dynq = RDRF_ENV("RDRF_DYNQ") ? atoi(RDRF_ENV("RDRF_DYNQ")) : RDRF_DYNQ_DEFAULT;
+  static const int wprio = RDRF_ENV("RDRF_WPRIO") ? atoi(RDRF_ENV("RDRF_WPRIO")) : RDRF_WPRIO_DEFAULT;
+  static const int stagger = RDRF_ENV("RDRF_STAGGER") ? atoi(RDRF_ENV("RDRF_STAGGER")) : RDRF_STAGGER_DEFAULT;
+  return (dynq ? 1 : 0) | (wprio ? 2 : 0) | (stagger << 8);
+}
+
 extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cfg, const float* rays,
                                const float* ts, const float* xyz, const float* z,
                                const uint8_t* valid, int N, int S, float* rgb, float* sigma,
@@ -320,19 +344,7 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
 #endif
   const Geo g = geo_for_tiles(N, S);
   const bool fea = cfg->static_head == RDRF_HEAD_MLP_FEA;
-#ifndef RDRF_DYNQ_DEFAULT
-#define RDRF_DYNQ_DEFAULT 1
-#endif
-#ifndef RDRF_WPRIO_DEFAULT
-#define RDRF_WPRIO_DEFAULT 0
-#endif
-#ifndef RDRF_STAGGER_DEFAULT
-#define RDRF_STAGGER_DEFAULT 0
-#endif
-  static const int dynq = RDRF_ENV("RDRF_DYNQ") ? atoi(RDRF_ENV("RDRF_DYNQ")) : RDRF_DYNQ_DEFAULT;   // 0: static tile stride (tools build)
-  static const int wprio = RDRF_ENV("RDRF_WPRIO") ? atoi(RDRF_ENV("RDRF_WPRIO")) : RDRF_WPRIO_DEFAULT;   // 1: distinct wave priorities
-  static const int stagger = RDRF_ENV("RDRF_STAGGER") ? atoi(RDRF_ENV("RDRF_STAGGER")) : RDRF_STAGGER_DEFAULT;   // x 8128 cycles per co-resident wave
-  a.dynq = (dynq ? 1 : 0) | (wprio ? 2 : 0) | (stagger << 8);
+  a.dynq = fwd_dynq();
 #ifdef RDRF_TOOLS
   // k_static_app16 (16-sample tiles, four waves per SIMD) is an EXPERIMENT of the tools build: 4-11 % slower than the 32-sample
   // kernel (profiles/r06_ab_static_app16.txt, r06_pmc_static_app16.csv): RDRF_SA16=1 selects it
@@ -380,6 +392,7 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   fill_common(a, cfg, rays, ts, xyz, z, valid, N, S);
   a.rgb = rgb; a.sigma = sigma; a.weight = weight; a.dists = dists;
   a.blending = blending; a.xyz_prime = xyz_prime;
+  a.dynq = fwd_dynq();
   int rc = ws_carve_fwd(a, ws, ws_bytes, N, S, saved, saved_bytes, 1);
   if (rc) return rc;
   DynW w;
@@ -536,6 +549,6 @@ extern "C" int rdrf_scene_flow_fwd(const RdrfDynamicParams* P, const RdrfFieldCf
   }
   const Geo g = geo_for_tiles(N, S);
   RDRF_LAUNCH("scene_flow", k_scene_flow, dim3(g.grid), dim3(g.block), stream, pts, ts, N, S,
-              make_box(cfg), a.pk, w, sf_f, sf_b, (float*)saved);
+              make_box(cfg), a.pk, w, sf_f, sf_b, (float*)saved, fwd_dynq());
   return 0;
 }

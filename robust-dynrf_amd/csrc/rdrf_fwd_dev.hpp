@@ -40,19 +40,6 @@ RDRF_D int block_append_base(int* counter, int cnt, int* s_cnt, int tid, int nth
   return s_cnt[wave];
 }
 
-// Tile queue of a persistent workgroup (round 6).  Workgroup b owns the tiles b, b + G, b + 2 G, ... (G workgroups); its
-// waves used to walk them with a static stride.  The SIMD's issue arbitration favours the oldest wave, so the waves of a
-// workgroup progress at different speeds: the favoured ones finish their share early and the pipe then runs the
-// stragglers alone (measured: matrix pipe 0.82 busy inside the steady state of k_static_app but 0.745 over the CU's busy
-// time).  With the queue a wave takes the workgroup's next tile whenever it is done: position k = wave for the first
-// tile, then a returning LDS atomic.  s_next must be initialised to the wave count before the first barrier.
-RDRF_D int tile_queue_next(int* s_next, int k, int nwaves, bool dyn) {
-  if (!dyn) return k + nwaves;
-  int v = 0;
-  if ((threadIdx.x & 63) == 0) v = atomicAdd(s_next, 1);
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
 // Distinct static issue priorities for the waves that share a SIMD (round 6).  The waves of a persistent workgroup start
 // together and do identical work per tile, and the SIMD's arbitration is fair between waves of equal priority -- so they stay
 // in LOCKSTEP: all of them gather, then all of them want the matrix pipe.  The measured wave time per tile is exactly
@@ -246,7 +233,7 @@ RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused
         for (int r = 0; r < 16; ++r) {
           float s1, c1, s2, c2;
           sincos_sel<true>(F[r], s1, c1);
-          sincos_sel<true>(F[r] * 2.0f, s2, c2);
+          sincos_double(s1, c1, s2, c2);   // (sin 2F, cos 2F): rdrf_common.hpp
           P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
         }
       }
@@ -382,7 +369,7 @@ RDRF_D void static_app16_body(const FieldArgs a, const StaticW w) {
         for (int r = 0; r < 8; ++r) {
           float s1, c1, s2, c2;
           sincos_sel<true>(F[r], s1, c1);
-          sincos_sel<true>(F[r] * 2.0f, s2, c2);
+          sincos_double(s1, c1, s2, c2);
           P[4 * r + 0] = s1; P[4 * r + 1] = c1; P[4 * r + 2] = s2; P[4 * r + 3] = c2;
         }
       }
@@ -693,13 +680,16 @@ RDRF_D void dyn_app_body(const FieldArgs a, const DynW w, float* lds_fused, cons
     __shared__ __attribute__((aligned(16))) float lds_own[pk::K3_SIZE];
     lds = lds_own;
   }
+  __shared__ int s_next;
+  if (GC_TID == 0) s_next = GC_NTHR >> 6;
   lds_fill(lds, a.pk + pk::REG_K3, pk::K3_SIZE);
   const int lane = GC_TID & 63, h = lane >> 5, s = lane & 31;
   const int wave = GC_TID >> 6, nwaves = GC_NTHR >> 6;
   const int count = FEAT ? a.M : *a.counter;
   const int ntiles = (count + 31) >> 5;
   const float* pkw = lds;
-  for (int tile = GC_BID * nwaves + wave; tile < ntiles; tile += GC_NBLK * nwaves) {
+  const bool dynq = !FUSED && (a.dynq & 1) != 0;   // tile queue of the workgroup (tile_queue_next)
+  for (int k = wave, tile; (tile = GC_BID + k * GC_NBLK) < ntiles; k = tile_queue_next(&s_next, k, nwaves, dynq)) {
     const int li = tile * 32 + s;
     const bool act = li < count;
     const int idx = act ? (FEAT ? li : a.list[li]) : 0;

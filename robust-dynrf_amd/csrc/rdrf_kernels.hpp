@@ -66,6 +66,19 @@ RDRF_D float ray_norm(const float* rays, int n, int ray_type, float& vx, float& 
 }
 
 
+// Tile queue of a persistent workgroup (round 6).  Workgroup b owns the tiles b, b + G, b + 2 G, ... (G workgroups); its
+// waves used to walk them with a static stride.  The SIMD's issue arbitration favours the oldest wave, so the waves of a
+// workgroup progress at different speeds: the favoured ones finish their share early and the pipe then runs the
+// stragglers alone (measured: matrix pipe 0.82 busy inside the steady state of k_static_app but 0.745 over the CU's busy
+// time).  With the queue a wave takes the workgroup's next tile whenever it is done: position k = wave for the first
+// tile, then a returning LDS atomic.  s_next must be initialised to the wave count before the first barrier.
+RDRF_D int tile_queue_next(int* s_next, int k, int nwaves, bool dyn) {
+  if (!dyn) return k + nwaves;
+  int v = 0;
+  if ((threadIdx.x & 63) == 0) v = atomicAdd(s_next, 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Saved activations (training mode).  Every per-sample vector a backward kernel needs is stored
 // as rows of 32 samples: [tile][row][32].  A lane of the producing wave (sample s, half h) writes

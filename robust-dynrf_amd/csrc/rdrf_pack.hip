@@ -36,8 +36,8 @@ void rdrf_prof_begin(const char* name, hipStream_t s) {
   if (!g_prof_on) return;
   ProfRec r;
   r.name = name;
-  hipEventCreate(&r.a);
-  hipEventCreate(&r.b);
+  (void)hipEventCreate(&r.a);
+  (void)hipEventCreate(&r.b);
   r.closed = false;
   (void)hipEventRecord(r.a, s);
   g_prof.push_back(r);
@@ -55,14 +55,14 @@ void rdrf_prof_end(const char* name, hipStream_t s) {
 static void prof_drain() {
   for (auto& r : g_prof) {
     if (!r.closed) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); continue; }
-    hipEventSynchronize(r.b);
+    (void)hipEventSynchronize(r.b);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
     auto& acc = g_prof_acc[r.name];
     acc.first += ms;
     acc.second += 1;
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
   g_prof.clear();
 }

@@ -126,6 +126,31 @@ def test_reference_written_checkpoint_loads():
         assert m.get_kwargs().keys() == {k for k in ckpt["kwargs"] if k not in ("se3_poses", "focal_ratio_refine")}
 
 
+def _sincos_pe_np(a):
+    """numpy fp32 restatement of csrc/rdrf_common.hpp sincos_pe (fma emulated through fp64)"""
+    import numpy as np
+    f = np.float32
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * np.float64(b) + np.asarray(c, dtype=np.float64)).astype(f)
+
+    a = a.astype(f)
+    n = np.rint(a * f(0.63661977236758134)).astype(f)
+    r = fma(n, f(-1.57079625129699707031e+00), a)
+    r = fma(n, f(-7.54978941586159635335e-08), r)
+    q = n.astype(np.int64)
+    r2 = (r * r).astype(f)
+    sp = fma(r2, f(-1.9515295891e-4), f(8.3321608736e-3))
+    sp = (sp.astype(np.float64) * r2 + np.float64(f(-1.6666654611e-1))).astype(f)
+    sr = ((sp * r2).astype(f).astype(np.float64) * r + r).astype(f)
+    cp = fma(r2, f(2.443315711809948e-5), f(-1.388731625493765e-3))
+    cp = (cp.astype(np.float64) * r2 + np.float64(f(4.166664568298827e-2))).astype(f)
+    cr = ((cp * r2).astype(f).astype(np.float64) * r2 + fma(r2, f(-0.5), f(1.0))).astype(f)
+    sw = (q & 1) == 1
+    S, Cc = np.where(sw, cr, sr), np.where(sw, sr, cr)
+    return np.where((q & 2) == 2, -S, S), np.where(((q + 1) & 2) == 2, -Cc, Cc)
+
+
 def test_sincos_pe_formula():
     """csrc/rdrf_common.hpp sincos_pe (the positional encodings' sin / cos): two-constant Cody-Waite reduction +
     Cephes minimax polynomials, restated here in numpy fp32 (fma emulated through fp64) and bounded against fp64
@@ -133,27 +158,7 @@ def test_sincos_pe_formula():
     max abs error < 1.2e-7 (2 ulp of 1; fp32 libm itself: 7e-8)."""
     import numpy as np
     f = np.float32
-
-    def fma(a, b, c):
-        return (a.astype(np.float64) * np.float64(b) + np.asarray(c, dtype=np.float64)).astype(f)
-
-    def sincos_pe(a):
-        a = a.astype(f)
-        n = np.rint(a * f(0.63661977236758134)).astype(f)
-        r = fma(n, f(-1.57079625129699707031e+00), a)
-        r = fma(n, f(-7.54978941586159635335e-08), r)
-        q = n.astype(np.int64)
-        r2 = (r * r).astype(f)
-        sp = fma(r2, f(-1.9515295891e-4), f(8.3321608736e-3))
-        sp = (sp.astype(np.float64) * r2 + np.float64(f(-1.6666654611e-1))).astype(f)
-        sr = ((sp * r2).astype(f).astype(np.float64) * r + r).astype(f)
-        cp = fma(r2, f(2.443315711809948e-5), f(-1.388731625493765e-3))
-        cp = (cp.astype(np.float64) * r2 + np.float64(f(4.166664568298827e-2))).astype(f)
-        cr = ((cp * r2).astype(f).astype(np.float64) * r2 + fma(r2, f(-0.5), f(1.0))).astype(f)
-        sw = (q & 1) == 1
-        S, Cc = np.where(sw, cr, sr), np.where(sw, sr, cr)
-        return np.where((q & 2) == 2, -S, S), np.where(((q + 1) & 2) == 2, -Cc, Cc)
-
+    sincos_pe = _sincos_pe_np
     rng = np.random.default_rng(0)
     x = rng.uniform(-1.5, 1.5, 100000).astype(f)
     worst = 0.0
@@ -178,3 +183,33 @@ def test_product_library_does_not_read_the_environment():
             pytest.skip(name + " not built")
         syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
         assert "getenv" not in syms, f"{name} imports getenv"
+
+
+def test_sincos_double_formula():
+    """csrc/rdrf_common.hpp sincos_double: the odd octaves of a positional encoding from the even ones,
+    sin 2a = (s + s) c, cos 2a = fma(-(s + s), s, 1) with (s, c) = sincos_pe(a): bounded against fp64 sin / cos of the
+    DOUBLED fp32 argument (what the reference evaluates) over x * 2^k, |x| <= 1.5, even k <= 8: max abs error < 4e-7, and
+    the static head's (F, 2F) pair over |F| <= 50."""
+    import numpy as np
+    f = np.float32
+    rng = np.random.default_rng(1)
+
+    def doubled(a):
+        s, c = _sincos_pe_np(a)
+        s, c = s.astype(f), c.astype(f)
+        t = (s + s).astype(f)
+        s2 = (t * c).astype(f)
+        c2 = (np.float64(1.0) - t.astype(np.float64) * s.astype(np.float64)).astype(f)   # one rounding: the fma
+        return s2, c2
+
+    worst = 0.0
+    x = rng.uniform(-1.5, 1.5, 100000).astype(f)
+    for k in range(0, 10, 2):
+        a = (x * f(2 ** k)).astype(f)
+        s2, c2 = doubled(a)
+        ref = (a * f(2)).astype(np.float64)   # exact in fp32
+        worst = max(worst, np.abs(s2 - np.sin(ref)).max(), np.abs(c2 - np.cos(ref)).max())
+    a = rng.uniform(-50, 50, 100000).astype(f)
+    s2, c2 = doubled(a)
+    worst = max(worst, np.abs(s2 - np.sin((a * f(2)).astype(np.float64))).max(), np.abs(c2 - np.cos((a * f(2)).astype(np.float64))).max())
+    assert worst < 4e-7, worst
