@@ -44,11 +44,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak (~6.3 TB/s achievable)
 PEAK_L2_GBS = 34500.0                      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 L2_ATOMIC_REQ_PER_S = 20.8e9               # tools/ubench/atomics.hip: fp32 atomic requests the L2 retires
-PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r05")
+PROFILE_TAG = os.environ.get("RDRF_PROFILE_TAG", "r06")
 
 
 def _profile_csv(name):
-    for tag in (PROFILE_TAG, "r04", "r03", "r02", "r01"):
+    for tag in (PROFILE_TAG, "r05", "r04", "r03", "r02", "r01"):
         fn = os.path.join(ROOT, "profiles", f"{tag}_{name}.csv")
         if os.path.exists(fn):
             return fn, tag
@@ -94,6 +94,50 @@ def pmc_family_per_step(csv_name, prefixes, counter):
         if parts[0].startswith(prefixes):
             tot += float(parts[3]) * float(parts[2])
     return tot / (adam / 2.0) if adam else None
+
+
+def committed_hbm_roofline(prefix, label):
+    """The dominant kernel of a configuration whose factors exceed the caches, from the committed rocprofv3 passes of
+    tools/profile_r6.sh (profiles/r06_<prefix>kernel_stats.csv + pmc_fetch / pmc_write): time per step from the kernel stats,
+    HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE of the same command -- a TRUE HBM fraction.  Not re-measured
+    by this run: `source` says so.  None if the files are absent."""
+    import csv
+    base = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{prefix}")
+    try:
+        stats, pmc = {}, {}
+        with open(base + "kernel_stats.csv") as f:
+            for r in csv.DictReader(f):
+                k = r["Name"].split("(")[0].replace("void ", "").replace(",", ";").strip()
+                c, t = stats.get(k, (0, 0.0))
+                stats[k] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
+        for fn, ctr in (("pmc_fetch.csv", "FETCH_SIZE"), ("pmc_write.csv", "WRITE_SIZE")):
+            with open(base + fn) as f:
+                for r in csv.DictReader(f):
+                    if r["counter"] == ctr:
+                        pmc.setdefault(r["kernel"].replace("void ", "").strip(), {})[ctr] = (float(r["dispatches"]), float(r["total"]))
+    except OSError:
+        return None
+    steps = stats.get("k_adam", (0, 0))[0] / 2.0
+    psteps = pmc.get("k_adam", {}).get("FETCH_SIZE", (0, 0))[0] / 2.0
+    if not steps or not psteps:
+        return None
+    rows = []
+    for k, (calls, ns) in stats.items():
+        f, w = pmc.get(k, {}).get("FETCH_SIZE"), pmc.get(k, {}).get("WRITE_SIZE")
+        if k.startswith("k_") and f and w:
+            ms, b = ns / 1e6 / steps, (2.0 * f[1] + w[1]) * 1024.0 / psteps
+            rows.append((ms, k, calls / steps, b))
+    if not rows:
+        return None
+    rows.sort(reverse=True)
+    ms, k, n, b = rows[0]
+    tot_ms, tot_b = sum(r[0] for r in rows), sum(r[3] for r in rows)
+    return {"workload": label, "kernel": k, "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": b / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": b / n, "ms_per_step": ms, "launches_per_step": n,
+            "all_kernels_gb_per_step": tot_b / 1e9, "all_kernels_ms_per_step": tot_ms,
+            "all_kernels_frac": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "source": f"profiles/{PROFILE_TAG}_{prefix}kernel_stats.csv / pmc_fetch.csv / pmc_write.csv + {PROFILE_TAG}_{prefix}hbm_table.txt "
+                      "(committed rocprofv3 passes of tools/profile_r6.sh; not re-measured by this run)"}
 
 
 def prof_get(L, name):
@@ -345,13 +389,13 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         dw_ms = sum(table[k]["ms_per_step"] for k in dw_keys)
         dw_b = sum(dw_step_bytes[k] for k in dw_keys)
         dw_f = sum(flops[k] * mult[k] for k in dw_keys)
-        tr = pmc_traffic("k_dw2")
+        tr = pmc_traffic("k_dw3")
         dw_entry = {
             "bound": "hbm", "achieved": dw_b / (dw_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": dw_b / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": tr,
             "hbm_real": None if tr is None else tr / (dw_ms / dw_launch * 1e-3) / 1e9,
             "source": {"traffic / hbm_real": f"profiles/{_profile_csv('pmc_fetch')[1]}_pmc_*.csv (committed, not re-measured here)"},
-            "kernel": "k_dw2 (dw_dyn + dw_static + dw_sf launches)", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
+            "kernel": "k_dw3 (dw_dyn + dw_static + dw_sf launches)", "ms_per_step": dw_ms, "kernel_avg_us": dw_ms / dw_launch * 1e3,
             "launches_per_step": dw_launch, "algorithmic_bytes_per_launch": dw_b / dw_launch,
             "mfma": {"achieved_tflops": dw_f / (dw_ms * 1e-3) / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
                      "frac": dw_f / (dw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
@@ -884,6 +928,15 @@ def main():
                 out["final_stage_frac_of_fp32_mfma_peak"] = out["final_stage"]["roofline"]["frac"]
             if "render" in out["final_stage"]:
                 out["render_final_stage_mpix_per_s"] = out["final_stage"]["render"]["value"]
+        if world == 1:
+            r640 = committed_hbm_roofline("640_", "BASELINE.json configs[4] shape: nvidia_no_poses final, grid [706,786,471], S=578, 4096 rays, 1 GPU "
+                                                  "(421 MB of factors > the 256 MB Infinity Cache: the HBM roof is physical here)")
+            rdav = committed_hbm_roofline("davis_final_", "BASELINE.json configs[3] shape: davis final, grid 256^3, S=221, 8192 rays, 1 GPU")
+            if r640:
+                out["hbm_roofline_640_detail"] = r640
+                out["hbm_roofline_640"] = {k: r640[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_step")}
+            if rdav:
+                out["hbm_roofline_davis_final_detail"] = rdav
         out["schema"] = SCHEMA
         write_detail(out)
         sys.stdout.flush()
