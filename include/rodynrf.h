@@ -40,8 +40,10 @@ extern "C" {
  * 4: rdrf_set_scatter_mode replaces the RDRF_SCATTER / RDRF_RENDER environment switches -- no entry point reads the
  *    caller's environment any more; rdrf_render_chunks_fwd (round 4).  A binding built against another version must refuse to load: the structs
  *    are passed by pointer and read to their full length.
- *    Round 5 added, without changing any struct or signature: rdrf_saved_row_bytes, RDRF_SCATTER_SORTED_PLAIN. */
-#define RDRF_ABI_VERSION 4
+ * 5: rdrf_saved_row_bytes and RDRF_SCATTER_SORTED_PLAIN (added in round 5 under version 4: a stale version-4 library then failed
+ *    on the missing symbol instead of on the version check); rdrf_render_chunks_fwd coalesces the chunks that fit the
+ *    caller's workspace into one launch sequence (same results, round 6). */
+#define RDRF_ABI_VERSION 5
 
 typedef void* rdrf_stream_t; /* hipStream_t */
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DETERMINISTIC = os.environ.get("RDRF_DETERMINISTIC", "0") == "1"
 LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf_det.so" if DETERMINISTIC else "librodynrf.so"))  # RDRF_LIB: A/B builds
 
-ABI_VERSION = 4   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
+ABI_VERSION = 5   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
 
 RAY_TYPES = {"ndc": 0, "contract": 1}
 ACTS = {"relu": 0, "softplus": 1}
@@ -58,6 +58,12 @@ def _load():
             f"{LIB_PATH} not found: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C robust-dynrf_amd/csrc)")
     lib = C.CDLL(LIB_PATH)
+    # the version check comes FIRST: a library of another version may lack symbols bound below, and the caller should see
+    # "version mismatch", not a raw AttributeError
+    if not hasattr(lib, "rdrf_abi_version") or lib.rdrf_abi_version() != ABI_VERSION:
+        got = lib.rdrf_abi_version() if hasattr(lib, "rdrf_abi_version") else None
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, this binding is built against {ABI_VERSION} (include/rodynrf.h): rebuild "
+                          "with make -C robust-dynrf_amd/csrc")
     lib.rdrf_last_error.restype = C.c_char_p
     lib.rdrf_workspace_bytes.restype = C.c_size_t
     lib.rdrf_workspace_bytes.argtypes = [C.c_int, C.c_int]
@@ -93,8 +99,6 @@ def _load():
     lib.rdrf_det_finish.argtypes = [C.c_int, C.c_void_p]
     if DETERMINISTIC and not lib.rdrf_deterministic():
         raise ImportError(f"RDRF_DETERMINISTIC=1 but {LIB_PATH} is the product build")
-    if lib.rdrf_abi_version() != ABI_VERSION:
-        raise ImportError("librodynrf.so ABI version mismatch")
     return lib
 
 

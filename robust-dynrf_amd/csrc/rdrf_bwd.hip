@@ -2803,8 +2803,11 @@ static int launch_scatter_tiled(SortedScatterArgs& sa, const unsigned* keys_sort
   // 70 KB: one workgroup per CU lost more than the windows gained, 3.46 -> 3.97 ms) and for the 16- / 4-component texels
   // of the density / blending sets (the 48-component appearance windows gained nothing: 0.71 -> 0.71 ms)
   static const long max_env = RDRF_ENV("RDRF_SS_TILED_MAXB") ? atol(RDRF_ENV("RDRF_SS_TILED_MAXB")) : 80 * 1024;
-  if (C0Q > 4 && tiled_env < 2) return 0;
-  if (bytes > max_env) {
+  if (C0Q > 4 && tiled_env < 2) return 0;   // (tiled_env >= 2 exists in the tools build only: RDRF_ENV is null in the product)
+  // two workgroups per CU: each needs its dynamic bytes + the kernel's static LDS (s_geo: 96 B), rounded to the 512-byte
+  // allocation granule (at exactly 80 KB of dynamic LDS the second workgroup did not fit)
+  const long per_wg = ((bytes + 96 + 511) / 512) * 512;
+  if (per_wg > max_env) {
     // both factor sets together do not leave room for two workgroups per CU, each alone does (final grids: 35 KB of z
     // line + 20 KB of windows per set).  One tiled launch per set was measured and LOSES to the untiled two-set kernel
     // (final stage, scatter_dyn_density 3.08 -> 3.24 ms / step, profiles/r05_ab_tiled_scatter.txt: every entry's taps and
@@ -2827,7 +2830,7 @@ static int launch_scatter_tiled(SortedScatterArgs& sa, const unsigned* keys_sort
   sa.Wk = sa.vm[0].W[PLANE] + 3;
   if (sa.lds_bytes > 48 * 1024)
     RDRF_HIP(hipFuncSetAttribute((const void*)k_scatter_tiled<PLANE, C0Q, C1Q>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LINES_MAX_BYTES));
-  const int per_cu = sa.lds_bytes > 80 * 1024 ? 1 : 2;   // 512-thread workgroups, 4 waves per SIMD (__launch_bounds__(512, 4): HIP counts waves per SIMD)
+  const int per_cu = per_wg > 80 * 1024 ? 1 : 2;   // 512-thread workgroups, 4 waves per SIMD (__launch_bounds__(512, 4): HIP counts waves per SIMD)
   const long nslices = (max_samples + (long)sa.slice_steps * (PLANE == 0 ? 16 : 32) - 1) / ((long)sa.slice_steps * (PLANE == 0 ? 16 : 32));
   long g = nslices < 256L * per_cu ? nslices : 256L * per_cu;
   g = g < 1 ? 1 : g;
@@ -2887,11 +2890,15 @@ static int scatter_dyn_app_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDy
   for (int p = 0; p < 3; ++p) {
     sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
     const unsigned* ks = b.keys_out + (size_t)p * ns;
-    rc = p == 0 ? launch_scatter_tiled<0, 12, 3>(sa, ks, ka.kb, (long)ns, stream)
-                : (p == 1 ? launch_scatter_tiled<1, 12, 3>(sa, ks, ka.kb, (long)ns, stream)
+#ifdef RDRF_TOOLS   // the 48-component windows gained nothing (0.713 -> 0.695 ms, profiles/r05_ab_tiled_scatter.txt): an experiment of the
+    rc = p == 0 ? launch_scatter_tiled<0, 12, 3>(sa, ks, ka.kb, (long)ns, stream)          // tools build (RDRF_SS_TILED=2), not
+                : (p == 1 ? launch_scatter_tiled<1, 12, 3>(sa, ks, ka.kb, (long)ns, stream)   // compiled into the product
                           : launch_scatter_tiled<2, 12, 3>(sa, ks, ka.kb, (long)ns, stream));
     if (rc < 0) return rc;
     if (rc == 1) continue;
+#else
+    (void)ks;
+#endif
     rc = p == 0 ? launch_scatter_sorted<0, 12, 3>(sa, (long)ns, stream)
                 : (p == 1 ? launch_scatter_sorted<1, 12, 3>(sa, (long)ns, stream) : launch_scatter_sorted<2, 12, 3>(sa, (long)ns, stream));
     if (rc) return rc;

@@ -61,9 +61,13 @@ def test_bench_reads_the_committed_pmc_summaries():
     assert fetch and write and atom
     assert 1e5 < fetch < 1e7 and 1e5 < write < 1e7          # KB per training step
     assert 1e6 < atom < 1e8                                 # memory-side atomic requests per training step (r05: 6.8 M)
-    dw = bench.pmc_traffic("k_dw2")
+    dw = bench.pmc_traffic("k_dw3")
     assert dw and 1e8 < dw < 1e10                           # bytes per launch
     assert bench._profile_csv("pmc_fetch")[1] == bench.PROFILE_TAG
+    # the configuration whose factors exceed the caches: a true HBM fraction of its dominant kernel
+    r = bench.committed_hbm_roofline("640_", "640^3")
+    assert r and r["bound"] == "hbm" and 0.2 < r["frac"] < 1.0 and 0.2 < r["all_kernels_frac"] < 1.0
+    assert r["kernel"].startswith("k_") and r["ms_per_step"] > 1.0
 
 
 def test_bench_selects_the_baseline_config_of_the_gpu_count():
