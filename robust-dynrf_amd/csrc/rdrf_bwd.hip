@@ -2140,6 +2140,7 @@ struct Dw2Plan {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifdef RDRF_TOOLS   // k_dw2 is the A/B partner of k_dw3 (RDRF_DW3=0) in the tools build; the product launches k_dw3 only
 __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dw2_stage[];   // nblk x 256 float4, XOR-swizzled per block
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
@@ -2275,6 +2276,8 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
     }
   }
 }
+
+#endif   // RDRF_TOOLS (k_dw2)
 
 // ------------------------------------------------------------------------------------------------
 // k_dw3 (round 6): the same plan as k_dw2 on HALF stages with LDS-DMA.  k_dw2 stages a whole tile
@@ -2474,20 +2477,24 @@ static int dw_launch(DwJobs& D, hipStream_t stream, const char* name) {
         }
         fprintf(stderr, " strides A %d B %d\n", P.A_stride, P.B_stride);
       }
-      const size_t lds = (size_t)P.nblk * 4096;
-      if (lds > 48 * 1024)
-        RDRF_HIP(hipFuncSetAttribute((const void*)k_dw2, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
+      const size_t lds = (size_t)P.nblk * 4096;   // two half stages of nblk x 2 KB (k_dw2: one whole stage of nblk x 4 KB)
       int grid = 256;
       if (P.count == nullptr && P.ntiles < grid) grid = P.ntiles < 1 ? 1 : P.ntiles;
-#ifndef RDRF_DW3_DEFAULT
-#define RDRF_DW3_DEFAULT 1
-#endif
-      static const int dw3 = RDRF_ENV("RDRF_DW3") ? atoi(RDRF_ENV("RDRF_DW3")) : RDRF_DW3_DEFAULT;   // 0: k_dw2 (tools build)
-      if (dw3 && lds > 48 * 1024)
-        RDRF_HIP(hipFuncSetAttribute((const void*)k_dw3, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
+#ifdef RDRF_TOOLS
+      static const int dw3 = RDRF_ENV("RDRF_DW3") ? atoi(RDRF_ENV("RDRF_DW3")) : 1;   // 0: k_dw2
+      if (lds > 48 * 1024) {
+        if (dw3) RDRF_HIP(hipFuncSetAttribute((const void*)k_dw3, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
+        else RDRF_HIP(hipFuncSetAttribute((const void*)k_dw2, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
+      }
       rdrf_prof_begin(name, stream);
       if (dw3) hipLaunchKernelGGL(k_dw3, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
       else hipLaunchKernelGGL(k_dw2, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
+#else
+      if (lds > 48 * 1024)
+        RDRF_HIP(hipFuncSetAttribute((const void*)k_dw3, hipFuncAttributeMaxDynamicSharedMemorySize, DW2_MAX_BLK * 4096));
+      rdrf_prof_begin(name, stream);
+      hipLaunchKernelGGL(k_dw3, dim3(grid), dim3(64 * DW2_WAVES), lds, stream, P);
+#endif
       rdrf_prof_end(name, stream);
       RDRF_HIP(hipGetLastError());
       return 0;

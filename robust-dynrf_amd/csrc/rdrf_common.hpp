@@ -244,14 +244,13 @@ RDRF_D void mfma_seg(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __r
 template <int NBO>
 RDRF_D void acc_bias(f32x16 (&acc)[NBO], const float* __restrict__ bpk, int h) {
 #pragma unroll
-  for (int nb = 0; nb < NBO; ++nb)
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bpk != nullptr) v = *(const f32x4*)(bpk + h * (NBO * 16) + nb * 16 + r4 * 4);
-      acc[nb][r4 * 4 + 0] = v.x; acc[nb][r4 * 4 + 1] = v.y;
-      acc[nb][r4 * 4 + 2] = v.z; acc[nb][r4 * 4 + 3] = v.w;
-    }
+  for (int nb = 0; nb < NBO; ++nb) {
+    // one 64-byte vector load per block: the four ds_read_b128 write the accumulator's registers directly (element-wise
+    // inserts of four f32x4 compiled to 16 v_mov per block and layer -- and a VALU instruction costs its four cycles of the
+    // SIMD whatever the matrix pipe does, tools/micro/mfma_valu_overlap.hip)
+    if (bpk != nullptr) acc[nb] = *(const f32x16*)(bpk + h * (NBO * 16) + nb * 16);
+    else acc[nb] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // cooperative copy of one kernel's weight image into LDS
@@ -274,12 +273,21 @@ RDRF_D void lds_fill(float* __restrict__ lds, const float* __restrict__ src, int
   __syncthreads();
 }
 
+// max(x, 0) in ONE instruction.  fmaxf(x, 0.0f) compiles to TWO: `v_max_f32 t, x, x` (LLVM canonicalises the operand because
+// it cannot prove the MFMA result is not a signalling NaN) and `v_max_f32 out, 0, t` -- 160 extra VALU instructions per
+// 32-sample tile of k_dyn_density, and VALU time adds to MFMA time on a SIMD (tools/micro/mfma_valu_overlap.hip).  The
+// hardware instruction already implements maxNum (a NaN operand yields the other one), i.e. fmaxf's result bit for bit.
+RDRF_D float relu1(float x) {
+  float o;
+  asm("v_max_f32 %0, 0, %1" : "=v"(o) : "v"(x));
+  return o;
+}
 template <int NBO>
 RDRF_D void acc_relu(float (&out)[NBO * 16], const f32x16 (&acc)[NBO]) {
 #pragma unroll
   for (int nb = 0; nb < NBO; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[nb * 16 + r] = fmaxf(acc[nb][r], 0.0f);
+    for (int r = 0; r < 16; ++r) out[nb * 16 + r] = relu1(acc[nb][r]);
 }
 
 template <int NBO>
@@ -736,8 +744,8 @@ template <int NBO>
 RDRF_D void acc16_relu(float (&out)[NBO * 4], const f32x4 (&acc)[NBO]) {
 #pragma unroll
   for (int nb = 0; nb < NBO; ++nb) {
-    out[nb * 4 + 0] = fmaxf(acc[nb].x, 0.f); out[nb * 4 + 1] = fmaxf(acc[nb].y, 0.f);
-    out[nb * 4 + 2] = fmaxf(acc[nb].z, 0.f); out[nb * 4 + 3] = fmaxf(acc[nb].w, 0.f);
+    out[nb * 4 + 0] = relu1(acc[nb].x); out[nb * 4 + 1] = relu1(acc[nb].y);
+    out[nb * 4 + 2] = relu1(acc[nb].z); out[nb * 4 + 3] = relu1(acc[nb].w);
   }
 }
 // small output layer: sum_e W[o][e] * in[e] over all FOUR lane groups (no bias); ws: [4][KK]

@@ -464,3 +464,54 @@ def test_sorted_scatter_passes_the_same_parity_tests():
             test_fused_grad_accumulation_matches_autograd()
     finally:
         L.set_scatter_mode("auto")
+
+
+def test_tiled_scatter_matches_plain_sorted_scatter_at_benchmark_shape():
+    """the LDS-window form of the sorted density / blending scatter (k_scatter_tiled, doubles in LDS) pinned
+    against the plain sorted kernel it replaced (k_scatter_sorted, global plane atomics) on the benchmark's own launch --
+    4096 rays x 115 samples at grid [141,157,94], both heads live -- instead of only through the cross-path bound of the
+    trainer test: the two paths form the same sums in another order, so their distance must stay within 3 x the
+    run-to-run spread of ONE path (fp32 atomics arrive in a different order every run), floor 2e-6 relative L2."""
+    import importlib
+    import rodynrf
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    L = importlib.import_module("robust-dynrf_amd._lib")
+    RU = importlib.import_module("robust-dynrf_amd.ray_utils")
+    cfg = S_.scene_config("nvidia", "stage0")
+    dev = torch.device("cuda", 0)
+    st, dy = S_.build_fields(cfg, dev)
+    data = S_.SyntheticScene(cfg, dev)
+    ids = data.perm[:4096]
+    rays = RU.generate_rays(ids, data.poses, data.focal, cfg["H"], cfg["W"], ndc=True, near=1.0).detach()
+    ts = data.ts_of(ids)
+    S = cfg["n_samples"]
+    jit = torch.rand(S, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    gen = torch.Generator(device=dev).manual_seed(2)
+    names = ["density_plane", "density_line", "blending_plane", "blending_line"]
+    params = [p for n in names for p in getattr(dy, n)]
+    gw = gb = None
+
+    def grads(mode):
+        nonlocal gw, gb
+        L.set_scatter_mode(mode)
+        for p in dy.parameters():
+            p.grad = None
+        xyz, z, valid = rodynrf.sampleXYZ(dy, rays, S, ray_type="ndc", is_train=True, jitter=jit)
+        o = dy(rays, ts, None, xyz, z, valid, is_train=True, ray_type="ndc")
+        if gw is None:
+            gw, gb = torch.randn(o[4].shape, device=dev, generator=gen), torch.randn(o[2].shape, device=dev, generator=gen)
+        ((o[4] * gw).sum() + (o[2] * gb).sum()).backward()   # weight (density head) and blending: both factor sets scatter
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.detach().flatten().double() for p in params])
+
+    try:
+        plain_a, plain_b = grads("sorted_plain"), grads("sorted_plain")
+        tiled = grads("sorted")
+    finally:
+        L.set_scatter_mode("auto")
+    nrm = float(plain_a.norm())
+    assert nrm > 0
+    spread = float((plain_a - plain_b).norm()) / nrm
+    dist = float((tiled - plain_a).norm()) / nrm
+    record_margin("tiled vs plain sorted scatter (rel. L2 / max(3 spread, 2e-6))", dist / max(3 * spread, 2e-6))
+    assert dist <= max(3 * spread, 2e-6), (dist, spread)
