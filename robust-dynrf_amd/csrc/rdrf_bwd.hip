@@ -1314,8 +1314,10 @@ struct SortKeyArgs {
   int N, S;
   int W[3], H[3];        // level-0 plane sizes
   int kb;                // bits of the cell part of the key
-  unsigned* keys;        // [3][N*S]
+  unsigned* keys;        // [3][N*S]; compact: [3][*count]
   int* counts;           // [3] live entries per plane
+  int compact;           // list mode: the key arrays hold the *count compacted entries of each plane back to back (stride *count
+                         // instead of N*S), so that the sort and the key generation touch live entries only (round 6)
 };
 
 RDRF_D int cell_axis(float c, int L, bool& any) {
@@ -1328,7 +1330,8 @@ RDRF_D int cell_axis(float c, int L, bool& any) {
 __global__ __launch_bounds__(256) void k_sort_keys(SortKeyArgs a) {
   const int NS = a.N * a.S, tpr = (a.S + 31) >> 5;
   const int count = a.list ? *a.count : 0;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NS; e += gridDim.x * blockDim.x) {
+  const int nent = (a.list && a.compact) ? count : NS;   // entries per plane = the stride of the key arrays
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += gridDim.x * blockDim.x) {
     bool live = false;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (a.list) {
@@ -1349,19 +1352,21 @@ __global__ __launch_bounds__(256) void k_sort_keys(SortKeyArgs a) {
       const int ix = cell_axis(cx, a.W[p], ax), iy = cell_axis(cy, a.H[p], ay);
       const bool in = live && ax && ay;
       const unsigned cell = in ? (unsigned)(iy * (a.W[p] + 3) + ix) : ((1u << a.kb) - 1u);
-      a.keys[(size_t)p * NS + e] = ((unsigned)p << a.kb) | cell;
+      a.keys[(size_t)p * nent + e] = ((unsigned)p << a.kb) | cell;
     }
   }
 }
 
 // live entries per plane = position of the first dropped key of the plane in the sorted array (a per-wave atomic
 // counter in k_sort_keys serialised 66 k same-address atomics: 240 us)
-__global__ void k_sort_counts(const unsigned* __restrict__ keys_sorted, int NS, int kb, int* __restrict__ counts) {
+__global__ void k_sort_counts(const unsigned* __restrict__ keys_sorted, int NS, int kb, int* __restrict__ counts,
+                              const int* __restrict__ seg) {
   const int p = threadIdx.x;
   if (p >= 3) return;
+  const int stride = seg ? *seg : NS;   // compact key arrays: the planes' segments are *seg entries long
   const unsigned drop = ((unsigned)p << kb) | ((1u << kb) - 1u);
-  const unsigned* k = keys_sorted + (size_t)p * NS;
-  int lo = 0, hi = NS;
+  const unsigned* k = keys_sorted + (size_t)p * stride;
+  int lo = 0, hi = stride;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (k[mid] < drop) lo = mid + 1; else hi = mid;
@@ -1378,6 +1383,8 @@ struct SortedScatterArgs {
   const unsigned* order;   // [NS] sorted positions of THIS plane (value = plane * NS + entry index)
   const int* count;        // live entries of this plane
   unsigned base;           // plane * NS
+  const int* seg;          // compact key arrays: `order` is the base of the whole array, this plane's positions start at
+                           // PLANE * *seg and carry that base (nullptr: order / base as given)
   const float* dfs;        // records: entry e at dfs + e * rec_floats (+ set * floats per set)
   int rec_floats;
   const int* list;         // appearance: entry e is compacted sample e, its sample id is list[e]; nullptr: entry = sample id
@@ -1406,6 +1413,8 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
   const int lane = threadIdx.x & 63, h = lane >> 5, s = lane & 31, q = lane >> 4, s16 = lane & 15;
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int count = *a.count;
+  const unsigned obase = a.seg ? (unsigned)PLANE * (unsigned)*a.seg : a.base;   // compact key arrays (SortKeyArgs::compact)
+  const unsigned* order = a.seg ? a.order + obase : a.order;
   constexpr int SPT = PLANE == 0 ? 16 : 32;   // samples per wave step
   // record of one set: [XY level 0 | 1 | 2 (XYF floats each)] [XZ: 3 x ZF] [YZ: 3 x ZF]
   constexpr int XYF = 4 * C0Q, ZF = 4 * C1Q, SETF = 3 * XYF + 6 * ZF, QPL = C0Q + 2 * C1Q;
@@ -1413,7 +1422,7 @@ __global__ __launch_bounds__(512, 3) void k_scatter_sorted(SortedScatterArgs a) 
   for (int t = blockIdx.x * nwaves + wave; t < ntiles; t += gridDim.x * nwaves) {
     const int pos = t * SPT + (PLANE == 0 ? s16 : s);
     const bool live = pos < count;
-    const int ent = live ? (int)(a.order[pos] - a.base) : 0;
+    const int ent = live ? (int)(order[pos] - obase) : 0;
     const int idx = a.list ? a.list[ent] : ent;
     const float x0 = a.xw[(size_t)idx * 3 + 0], x1 = a.xw[(size_t)idx * 3 + 1], x2 = a.xw[(size_t)idx * 3 + 2];
     float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
@@ -2871,9 +2880,13 @@ static int sorted_scatter_prepare(SortKeyArgs& ka, const RdrfVM& vm, const BwdAr
     hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)g), dim3(256), 0, stream, ka);
     rdrf_prof_end("sort_keys", stream);
   }
-  int rc = rdrf_sort_positions(b.keys_in, b.keys_out, b.order, (unsigned)(3 * ns), kb + 2, b.sort_tmp, b.sort_tmp_bytes, stream);
+  // compact: the sort covers the 3 x *count live-list entries only (launches sized for 3 N S; the appearance list holds
+  // 35-60 % of the samples)
+  int rc = rdrf_sort_positions(b.keys_in, b.keys_out, b.order, (unsigned)(3 * ns), kb + 2, b.sort_tmp, b.sort_tmp_bytes, stream,
+                               ka.compact ? ka.count : nullptr, 3u);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sort_counts, dim3(1), dim3(64), 0, stream, (const unsigned*)b.keys_out, (int)ns, kb, b.counts);
+  hipLaunchKernelGGL(k_sort_counts, dim3(1), dim3(64), 0, stream, (const unsigned*)b.keys_out, (int)ns, kb, b.counts,
+                     ka.compact ? ka.count : (const int*)nullptr);
   rdrf_prof_end("scatter_sort", stream);
   RDRF_HIP(hipGetLastError());
   return 0;
@@ -2888,6 +2901,12 @@ static int scatter_dyn_app_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDy
   SortKeyArgs ka;
   memset(&ka, 0, sizeof(ka));
   ka.list = a.sp.list; ka.count = &a.sp.hdr->count;
+#ifdef RDRF_TOOLS   // (the windows experiment below addresses the sorted keys with the host-side stride N S)
+  static const int compact_env = RDRF_ENV("RDRF_SORT_COMPACT") ? atoi(RDRF_ENV("RDRF_SORT_COMPACT")) : 1;
+  ka.compact = compact_env && !(RDRF_ENV("RDRF_SS_TILED") && atoi(RDRF_ENV("RDRF_SS_TILED")) >= 2);
+#else
+  ka.compact = 1;
+#endif
   int rc = sorted_scatter_prepare(ka, P->app, a, b, stream);
   if (rc) return rc;
   SortedScatterArgs sa;
@@ -2896,6 +2915,7 @@ static int scatter_dyn_app_sorted(const BwdArgs& a, const BwdWs& b, const RdrfDy
   sa.set_mask = 1; sa.dfs = b.dfa; sa.rec_floats = DFA_FLOATS; sa.list = a.sp.list; sa.xw = a.sp.xw; sa.dxw = b.dxw;
   for (int p = 0; p < 3; ++p) {
     sa.order = b.order + (size_t)p * ns; sa.count = b.counts + p; sa.base = (unsigned)(p * ns);
+    if (ka.compact) { sa.order = b.order; sa.seg = ka.count; }   // device-side segment starts (k_scatter_sorted)
     const unsigned* ks = b.keys_out + (size_t)p * ns;
 #ifdef RDRF_TOOLS   // the 48-component windows gained nothing (0.713 -> 0.695 ms, profiles/r05_ab_tiled_scatter.txt): an experiment of the
     rc = p == 0 ? launch_scatter_tiled<0, 12, 3>(sa, ks, ka.kb, (long)ns, stream)          // tools build (RDRF_SS_TILED=2), not

@@ -89,7 +89,7 @@ static inline bool vm_ok(const RdrfVM& v, int c0, int c1) {
 // device-wide stable key sort (rdrf_sort.hip)
 size_t rdrf_sort_temp_bytes(unsigned n, int bits);
 int rdrf_sort_positions(const unsigned* keys_in, unsigned* keys_out, unsigned* vals_out, unsigned n, int bits, void* temp,
-                        size_t temp_bytes, hipStream_t stream);
+                        size_t temp_bytes, hipStream_t stream, const int* n_dev = nullptr, unsigned n_mul = 0);
 
 int rdrf_sort_ints_inplace(int* data, unsigned n, hipStream_t stream);   // deterministic build only
 

@@ -37,7 +37,14 @@ struct RadixArgs {
   unsigned* totals;          // [nbins]
   unsigned n;
   int ntiles, shift, nbins;
+  const int* n_dev;          // device-side entry count: the sort covers min(n, n_mul * *n_dev) entries (nullptr: n).  The
+  unsigned n_mul;            // launches are sized for n; tiles beyond the device count find nothing to do
 };
+__device__ __forceinline__ unsigned radix_n(const RadixArgs& a) {
+  if (a.n_dev == nullptr) return a.n;
+  const unsigned m = (unsigned)*a.n_dev * a.n_mul;
+  return m < a.n ? m : a.n;
+}
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(RadixArgs a) {
   __shared__ unsigned h[RS_BINS];
@@ -45,9 +52,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(RadixArgs a) {
   __syncthreads();
   const unsigned mask = (unsigned)a.nbins - 1u;
   const size_t base = (size_t)blockIdx.x * RS_TILE;
-  for (int i = threadIdx.x; i < RS_TILE; i += RS_THREADS) {
-    const size_t p = base + i;
-    if (p < a.n) atomicAdd(&h[(a.keys_in[p] >> a.shift) & mask], 1u);
+  const unsigned n = radix_n(a);
+  if (base < n) {
+    for (int i = threadIdx.x; i < RS_TILE; i += RS_THREADS) {
+      const size_t p = base + i;
+      if (p < n) atomicAdd(&h[(a.keys_in[p] >> a.shift) & mask], 1u);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < a.nbins; i += RS_THREADS) a.hist[(size_t)i * a.ntiles + blockIdx.x] = h[i];
@@ -97,6 +107,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(RadixArgs a) {
   __shared__ unsigned wsum[RS_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned mask = (unsigned)a.nbins - 1u;
+  const unsigned n = radix_n(a);
+  if ((size_t)blockIdx.x * RS_TILE >= n) return;   // (uniform: the whole tile lies beyond the device-side count)
   // ---- global base of every digit = exclusive scan of the totals + this tile's entry of the digit's row scan
   {
     unsigned carry = 0;
@@ -117,8 +129,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(RadixArgs a) {
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const size_t p = wbase + (size_t)r * 64 + lane;
-    key[r] = p < a.n ? a.keys_in[p] : 0xffffffffu;
-    if (p < a.n) atomicAdd(&offs[wave][(key[r] >> a.shift) & mask], 1u);
+    key[r] = p < n ? a.keys_in[p] : 0xffffffffu;
+    if (p < n) atomicAdd(&offs[wave][(key[r] >> a.shift) & mask], 1u);
   }
   __syncthreads();
   // ---- counts -> starting offsets: digit base + the counts of the lower waves
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(RadixArgs a) {
 #pragma unroll   // (key[] is a register array: a rolled loop would index it dynamically, i.e. through scratch)
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const size_t p = wbase + (size_t)r * 64 + lane;
-    const bool act = p < a.n;
+    const bool act = p < n;
     const unsigned d = (key[r] >> a.shift) & mask;
     unsigned long long peers = __ballot(act);
 #pragma unroll
@@ -173,7 +185,7 @@ size_t rdrf_sort_temp_bytes(unsigned n, int bits) {
 }
 
 static int radix_sort(const unsigned* keys_in, unsigned* keys_out, unsigned* vals_out, unsigned n, int bits, void* temp,
-                      size_t temp_bytes, hipStream_t stream) {
+                      size_t temp_bytes, hipStream_t stream, const int* n_dev = nullptr, unsigned n_mul = 0) {
   if (n == 0) return 0;
   RDRF_CHECK(temp != nullptr && temp_bytes >= rdrf_sort_temp_bytes(n, bits), -3, "sort: temporary storage too small (%zu < %zu)",
              temp_bytes, rdrf_sort_temp_bytes(n, bits));
@@ -194,7 +206,7 @@ static int radix_sort(const unsigned* keys_in, unsigned* keys_out, unsigned* val
     a.keys_in = kin; a.vals_in = vin;
     a.keys_out = to_out ? keys_out : tk;
     a.vals_out = vals_out ? (to_out ? vals_out : tv) : nullptr;
-    a.hist = hist; a.totals = totals; a.n = n; a.ntiles = ntiles;
+    a.hist = hist; a.totals = totals; a.n = n; a.ntiles = ntiles; a.n_dev = n_dev; a.n_mul = n_mul;
     a.shift = p * db;
     a.nbins = 1 << db;
     rdrf_prof_begin("sort", stream);
@@ -210,10 +222,11 @@ static int radix_sort(const unsigned* keys_in, unsigned* keys_out, unsigned* val
 }
 
 // keys_in [n] -> keys_out [n] ascending (stable), vals_out[i] = original position of keys_out[i]
+// n_dev (optional): the first n_mul * *n_dev entries only (a count that lives on the device: the compacted appearance list)
 int rdrf_sort_positions(const unsigned* keys_in, unsigned* keys_out, unsigned* vals_out, unsigned n, int bits, void* temp,
-                        size_t temp_bytes, hipStream_t stream) {
+                        size_t temp_bytes, hipStream_t stream, const int* n_dev, unsigned n_mul) {
   RDRF_CHECK(keys_in && keys_out && vals_out, -1, "sort: null argument");
-  return radix_sort(keys_in, keys_out, vals_out, n, bits, temp, temp_bytes, stream);
+  return radix_sort(keys_in, keys_out, vals_out, n, bits, temp, temp_bytes, stream, n_dev, n_mul);
 }
 
 // deterministic build: ascending in-place sort of an int list (the app-mask compaction lists, whose append order depends on
