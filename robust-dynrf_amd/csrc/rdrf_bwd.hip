@@ -2299,7 +2299,10 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
 // Measured (profiles/r06_ab_dw3_*.txt): dw launches 2.02 -> 1.91 ms/step at stage 0, 4.40 -> 4.10 at the final stage.  Ablations:
 // MFMAs + barriers alone 1.05 ms (dw_dyn, stage 0), DMA + barriers alone 1.29 -- the memory side binds, and NOT through its
 // latency: a ring of 80 block slots that keeps two half stages in flight (counted vmcnt, raw s_barrier) left the DMA-only time
-// at 1.30 ms and made the kernel slower (1.56); the 64-byte half rows fetch every 128-byte line in two visits a step apart.
+// at 1.30 ms and made the kernel slower (1.56).  Nor through the 64-byte half rows: the same bytes fetched as full 128-byte
+// rows (RDRF_ABL_DW_FULLROW, wrong arithmetic, timing only: profiles/r06_ab_dw3_fullrow_timing.txt) take 1.18 instead of 1.25 ms
+// DMA-only and 1.43 instead of 1.47 ms in the whole kernel.  What is left is the per-step bubble of a 12-wave workgroup:
+// vmcnt(0) -> barrier -> ~5 DMA issues per wave, during which this CU has nothing in flight (~0.5 of each 2.7 us step).
 //   LDS image of a block (32 rows x 16 samples = 2 KB): float4 position p = row * 4 + (chunk ^ ((row >> 2) & 3)); a DMA
 //   instruction fills 1 KB in lane order (base + lane * 16 -- the hardware's layout), so the swizzle sits on the SOURCE
 //   address of lane l (row = 16 sub + (l >> 2), chunk = (l & 3) ^ ((row >> 2) & 3)) and on the read (cdna guide, rule 21);
@@ -2336,9 +2339,16 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw3(Dw2Plan P) {
 #ifndef RDRF_ABL_DW_NOLOAD
         const int blk = pc >> 1;
         __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(dw3_stage + buf * hbuf + pc * 64);
+#ifdef RDRF_ABL_DW_FULLROW   // timing experiment (tools): the same bytes as FULL 128-byte rows (rows 16 hf .. 16 hf + 15 of the block,
+        const unsigned soff = (unsigned)(blk * 4096 + hf * 2048 + (pc & 1) * 1024);   // 1 KB contiguous per piece); WRONG results
+        const unsigned vo = (unsigned)(lane * 16);
+        if (blk < sb1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, vo, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, vo, soff, 0, 0);
+#else
         const unsigned soff = (unsigned)(blk * 4096 + hf * 64);
         if (blk < sb1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, voff, soff, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, voff, soff, 0, 0);
+#endif
 #endif
       }
     }

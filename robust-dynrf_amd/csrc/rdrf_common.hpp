@@ -31,6 +31,7 @@
 #undef RDRF_ABL_DW_NOLOAD
 #undef RDRF_ABL_DW_NOMFMA
 #undef RDRF_ABL_DW_NOFLUSH
+#undef RDRF_ABL_DW_FULLROW
 #undef RDRF_ABL_NOGATHER
 #undef RDRF_ABL_OCML_SINCOS
 #undef RDRF_ABL_NOSAVE
