@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""DESIGN.md = tools/docs/design_head.md (sections 0-8) + design_sec9.md (results; @PLACEHOLDERS@ filled from a bench_detail
-record and the committed hbm tables) + design_sec10.md:   python tools/docs/assemble_design.py profiles/r06_bench_detail_driver_cmd.json"""
+"""Section 9 of DESIGN.md (results) is regenerated from tools/docs/design_sec9.md: its @PLACEHOLDERS@ are filled from a bench_detail
+record and the committed hbm tables; README.md likewise from readme_template.md:   python tools/docs/assemble_design.py profiles/r06_bench_detail_driver_cmd.json"""
 import json
 import os
 import re
@@ -47,7 +47,9 @@ sub = {
 here = os.path.dirname(os.path.abspath(__file__))
 sec9 = open(os.path.join(here, "design_sec9.md")).read()
 sec9 = re.sub(r"@([A-Z0-9_]+)@", lambda m: sub[m.group(1)], sec9)
-out = open(os.path.join(here, "design_head.md")).read() + sec9 + open(os.path.join(here, "design_sec10.md")).read()
+cur = open(os.path.join(ROOT, "DESIGN.md")).read()   # sections 0-8 and 10 are edited in DESIGN.md itself
+i9, i10 = cur.index("## 9. Results"), cur.index("## 10. What comes next")
+out = cur[:i9] + sec9 + cur[i10:]
 open(os.path.join(ROOT, "DESIGN.md"), "w").write(out)
 print("DESIGN.md:", len(out.splitlines()), "lines")
 
