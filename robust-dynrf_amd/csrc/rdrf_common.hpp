@@ -368,7 +368,8 @@ RDRF_D Tap1 tap1d(float c, int Ls) {
   t.w1 = f - fl;
   t.w0 = (fl + 1.0f) - f;
   // clamp before the int conversion so wild coordinates cannot overflow
-  float flc = fminf(fmaxf(fl, -2.0f), (float)Ls + 1.0f);
+  // (one v_med3_f32: fminf(fmaxf(..)) compiled to two canonicalising v_max + max + min; same value, NaN -> -2 as before)
+  float flc = __builtin_amdgcn_fmed3f(fl, -2.0f, (float)Ls + 1.0f);
   t.i0 = (int)flc;
   t.ok0 = (fl >= 0.0f) && (fl <= (float)(Ls - 1));
   t.ok1 = (fl >= -1.0f) && (fl <= (float)(Ls - 2));
