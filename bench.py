@@ -714,11 +714,19 @@ def main():
     ap.add_argument("--no-liveness-leg", action="store_true",
                     help="skip the secondary liveness_exploited leg (profiling runs: every iteration of the process is then the "
                          "same workload)")
+    ap.add_argument("--graph", action="store_true",
+                    help="Trainer(graph=True): batch gather, forward passes and both backward phases of an iteration captured once "
+                         "as a HIP graph and replayed (single process; for the launch-bound S = 13 stages of Nvidia_no_poses.txt / "
+                         "DAVIS.txt).  Implies --no-roofline: the per-kernel HIP events cannot be recorded inside a capture")
     ap.add_argument("--exploit-liveness", action="store_true",
                     help="skip the work whose results nothing consumes (SURVEY 3.1 liveness table): the dynamic-field forward of "
                          "passes E / P3 / P4 and the colours of both fields in passes B-D / P1-P4; by default it is executed like "
                          "the reference does")
     args = ap.parse_args()
+    if args.graph:
+        if args.gpus > 1:
+            raise SystemExit("bench.py --graph is the single-process path")
+        args.no_roofline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
@@ -744,12 +752,12 @@ def main():
     rpg = args.rays_per_gpu or cfg["batch_size"]
     cfg["batch_size"] = rpg * world   # weak scaling: fixed rays per GPU
     trainer = S_.Trainer(cfg, dev, weights=args.weights, dead_work=not args.exploit_liveness, dp_mode=args.dp,
-                         dp_exact_stats=not args.dp_per_shard_stats)
+                         dp_exact_stats=not args.dp_per_shard_stats, graph=args.graph)
     shard = (rank, world)
 
     def make_trainer():
         return S_.Trainer(dict(cfg), dev, weights=args.weights, dead_work=not args.exploit_liveness, dp_mode=args.dp,
-                          dp_exact_stats=not args.dp_per_shard_stats)
+                          dp_exact_stats=not args.dp_per_shard_stats, graph=args.graph)
 
     # Order: the profiled replay FIRST (a fresh trainer with the same seeds runs iterations 0 .. warmup + steps, the last
     # `steps` of them under HIP events), then the timed region on the main trainer.  The replay gives the kernel table of
@@ -794,7 +802,7 @@ def main():
                                     "then the driver's warmup + steps iterations run on the main trainer and `steps` of them are timed"
                                     if not args.no_roofline else "warmup + steps iterations on a fresh trainer"),
                    "config": args.config, "stage": args.stage, "grid": cfg["grid"], "samples_per_ray": cfg["n_samples"],
-                   "global_batch": cfg["batch_size"], "rays_per_gpu": rpg, "weights": args.weights,
+                   "global_batch": cfg["batch_size"], "rays_per_gpu": rpg, "weights": args.weights, "step_graph": bool(args.graph),
                    "parallelism": f"ray-sharded dp{world}" + (f" ({trainer.opt.mode})" if trainer.opt.ex.active else ""),
                    "ranks": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                    "exchange_bytes_per_step": trainer.opt.nbytes_exchanged() if trainer.opt.ex.active else 0,

@@ -42,8 +42,13 @@ extern "C" {
  *    are passed by pointer and read to their full length.
  * 5: rdrf_saved_row_bytes and RDRF_SCATTER_SORTED_PLAIN (added in round 5 under version 4: a stale version-4 library then failed
  *    on the missing symbol instead of on the version check); rdrf_render_chunks_fwd coalesces the chunks that fit the
- *    caller's workspace into one launch sequence (same results, round 6). */
-#define RDRF_ABI_VERSION 5
+ *    caller's workspace into one launch sequence (same results, round 6).
+ * 6: iteration scalars may live on the DEVICE, so that a whole training iteration can be captured in one HIP graph and
+ *    replayed while they change (train.py draws the white-background coin and ramps loss weights every iteration):
+ *    rdrf_composite_fwd / _bwd take `white_dev` (a device float, 0 or 1, that overrides add_white_bg when non-NULL) and
+ *    RdrfLossTerm grew the trailing `coef_dev` (a device float that multiplies `coef` when non-NULL);
+ *    rdrf_rows_scatter_add. */
+#define RDRF_ABI_VERSION 6
 
 typedef void* rdrf_stream_t; /* hipStream_t */
 
@@ -239,21 +244,23 @@ int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* cfg, con
                         void* ws, size_t ws_bytes, rdrf_stream_t stream);
 
 /* ---- renderer.raw2outputs (renderer.py:173-315) ----------------------------------------------
- * add_white_bg: the caller draws the train-time coin (renderer.py:269). out13: pointers to the 13
+ * add_white_bg: the caller draws the train-time coin (renderer.py:269).  white_dev (nullable): the same coin as a DEVICE
+ * float (0.0f or 1.0f) read when the kernel runs -- it overrides add_white_bg, so a launch captured in a HIP graph follows
+ * the coin of each replay.  out13: pointers to the 13
  * outputs in the reference's order: rgb_map_full[N][3], depth_map_full[N], acc_map_full[N],
  * weights_full[N][S], rgb_map_s, depth_map_s, acc_map_s, weights_s, rgb_map_d, depth_map_d,
  * acc_map_d, weights_d, dynamicness_map[N]. */
 int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
                        const float* sigma_d, const float* dists, const float* blending,
                        const float* z, const float* rays, int N, int S, int ray_type,
-                       int add_white_bg, float* const out13[13], rdrf_stream_t stream);
+                       int add_white_bg, const float* white_dev, float* const out13[13], rdrf_stream_t stream);
 /* g_out13: gradients wrt the 13 outputs (entries may be NULL). g_in8: gradient buffers (+=) for
  * rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z, rays (entries may be NULL). */
 int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
                        const float* sigma_d, const float* dists, const float* blending,
                        const float* z, const float* rays, int N, int S, int ray_type,
-                       int add_white_bg, const float* const g_out13[13], float* const g_in8[8],
-                       rdrf_stream_t stream);
+                       int add_white_bg, const float* white_dev, const float* const g_out13[13],
+                       float* const g_in8[8], rdrf_stream_t stream);
 
 /* ---- induced optical flow / disparity of the rendered 3-D point (renderer.py:1334-1392
  * render_3d_point + induce_flow; NDC2world :1266, world2NDC :1276, contract2world :1286).
@@ -269,6 +276,12 @@ int rdrf_induce_flow_bwd(int H, int W, const float* focal, const float* c2w, con
                          const float* pts, const float* rays, int N, int S, int ray_type,
                          const float* g_flow, const float* g_disp, float* g_weights, float* g_pts,
                          float* g_rays, float* g_c2w, float* g_focal, rdrf_stream_t stream);
+
+/* ---- adjoint of a row gather rows[n] = table[idx[n]] (the camera matrices of the neighbour frames,
+ * `allposes_refine[view +- 1]`, train.py:1895-1948, live when the poses are optimised): g_table[idx[n]][c] += g_rows[n][c].
+ * idx [N] int64 in [0, R); g_rows [N][C]; g_table [R][C] accumulates (+=). */
+int rdrf_rows_scatter_add(const int64_t* idx, const float* g_rows, int N, int R, int C, float* g_table,
+                          rdrf_stream_t stream);
 
 /* ---- distortion loss (train.py:1299-1312, 1685-1716, 1840-1856 call flatten_eff_distloss of the
  * un-vendored torch_efficient_distloss with ray_id = tile(arange(N), S), i.e. N rays x S points).
@@ -347,7 +360,7 @@ int rdrf_dynamic_pack(const RdrfDynamicParams* P, int backward, float* image, rd
  * :1341-1365 (dynamicness mask), :1392-1410 (induced flow, masked means), :1421, 1627 (scene flow, weighted by
  * the sample weights in this path), :1522-1524, 1619-1621 (induced disparity), :1828-1832 (static photometric,
  * background-masked), :2293-2299 (disparity smoothness).
- *   term = coef * sum_rows w[row] * sum_cols rho(x + ysign * y) / Z
+ *   term = coef [* *coef_dev] * sum_rows w[row] * sum_cols rho(x + ysign * y) / Z
  *   rho = r^2 | |r| | r ;  Z = rows * cols (NORM_MEAN)  or  sum_rows w + 1e-8 (NORM_WEIGHT, a masked mean)
  * x, y: [rows][cols] contiguous (y nullable); w: [rows] (nullable = 1).  gx / gy (backward only, nullable):
  * d loss / d x, d loss / d y, WRITTEN (not accumulated).
@@ -369,6 +382,9 @@ typedef struct {
   int norm;   /* RDRF_LOSS_NORM_* */
   float ysign;
   float coef;
+  const float* coef_dev; /* nullable: DEVICE float multiplied into coef when the finishing kernel runs (loss weights that
+                            change every iteration -- train.py:1299-1312 distortion ramp, Temp_static :1034-1036 -- inside
+                            a captured HIP graph) */
 } RdrfLossTerm;
 size_t rdrf_loss_terms_workspace_floats(int n);
 int rdrf_loss_terms_fwd(const RdrfLossTerm* terms, int n, float* partial, float* out, rdrf_stream_t stream);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DETERMINISTIC = os.environ.get("RDRF_DETERMINISTIC", "0") == "1"
 LIB_PATH = os.environ.get("RDRF_LIB", os.path.join(_HERE, "librodynrf_det.so" if DETERMINISTIC else "librodynrf.so"))  # RDRF_LIB: A/B builds
 
-ABI_VERSION = 5   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
+ABI_VERSION = 6   # include/rodynrf.h RDRF_ABI_VERSION: the parameter structs below are read to their full length
 
 RAY_TYPES = {"ndc": 0, "contract": 1}
 ACTS = {"relu": 0, "softplus": 1}
@@ -114,7 +114,7 @@ SYMBOLS = [
     "rdrf_static_features_fwd", "rdrf_static_features_bwd", "rdrf_dynamic_features_fwd",
     "rdrf_dynamic_features_bwd",
     "rdrf_scene_flow_fwd", "rdrf_scene_flow_bwd", "rdrf_composite_fwd", "rdrf_composite_bwd",
-    "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
+    "rdrf_induce_flow_fwd", "rdrf_induce_flow_bwd", "rdrf_rows_scatter_add", "rdrf_distloss_fwd", "rdrf_distloss_bwd",
     "rdrf_tv_fwd", "rdrf_tv_bwd", "rdrf_tv_grad", "rdrf_adam_step", "rdrf_upsample_bilinear", "rdrf_dense_l1_fwd",
     "rdrf_dense_l1_bwd", "rdrf_pack_floats", "rdrf_static_pack", "rdrf_dynamic_pack", "rdrf_loss_terms_workspace_floats", "rdrf_loss_terms_fwd", "rdrf_loss_terms_bwd",
     "rdrf_loss_terms_stats", "rdrf_loss_terms_finish", "rdrf_deterministic", "rdrf_det_bind", "rdrf_det_finish",
@@ -146,7 +146,7 @@ TV_MAX = 16
 class RdrfLossTerm(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("w", C.c_void_p), ("gx", C.c_void_p), ("gy", C.c_void_p),
                 ("rows", C.c_longlong), ("cols", C.c_int), ("kind", C.c_int), ("norm", C.c_int),
-                ("ysign", C.c_float), ("coef", C.c_float)]
+                ("ysign", C.c_float), ("coef", C.c_float), ("coef_dev", C.c_void_p)]
 
 
 MAX_LOSS_TERMS = 32

@@ -2757,13 +2757,21 @@ extern "C" int rdrf_set_scatter_mode(int mode) {
   g_scatter_mode = mode;
   return 0;
 }
-static int scatter_mode(size_t ns) {   // 0 ray, 1 sorted
+static int scatter_mode(size_t ns, hipStream_t stream) {   // 0 ray, 1 sorted
   int m = g_scatter_mode;
   if (const char* e = RDRF_ENV("RDRF_SCATTER")) m = !strcmp(e, "sorted") ? RDRF_SCATTER_SORTED : (!strcmp(e, "ray") ? RDRF_SCATTER_RAY : m);
   // auto: with the hand-written radix sort (72 us for 1.4 M keys; rocPRIM took 150) the sorted path wins from the
   // Balloon1 stage-0 pass (4096 x 115 = 471 k samples: 12.57 vs 12.72 ms/step, interleaved A/B on one box) upwards, and
   // sends a tenth of the atomic requests; below ~300 k samples the fixed cost of its seven extra launches dominates
-  if (m == RDRF_SCATTER_AUTO) return ns >= (size_t)300000 ? 1 : 0;
+  // A launch sequence that is being CAPTURED into a HIP graph pays no per-launch host cost at replay, so the grouping wins at
+  // every size there: at the S = 13 stages of Nvidia_no_poses.txt / DAVIS.txt (53 k - 106 k samples per pass into a 17 x 19 x 11 /
+  // 16^3 grid: every plane fits one LDS window) the captured iteration runs 5.44 -> 5.11 / 9.31 -> 8.93 ms
+  // (profiles/r06_graph_scatter_ab.txt).
+  if (m == RDRF_SCATTER_AUTO) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return 1;
+    return ns >= (size_t)300000 ? 1 : 0;
+  }
   return (m == RDRF_SCATTER_SORTED || m == RDRF_SCATTER_SORTED_PLAIN) ? 1 : 0;
 }
 
@@ -3142,14 +3150,14 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
     if (rc) return rc;
   }
   const size_t ns = (size_t)N * S, t3 = (ns + 31) / 32, t1 = (size_t)N * ((S + 31) / 32);
-  RDRF_HIP(hipMemsetAsync(b.dxw, 0, ns * 3 * 4, stream));
-  RDRF_HIP(hipMemsetAsync(b.dxn, 0, ns * 3 * 4, stream));
+  RDRF_FILL(b.dxw, 0, ns * 3 * 4, stream);
+  RDRF_FILL(b.dxn, 0, ns * 3 * 4, stream);
   const int* cnt = &a.sp.hdr->count;
   DwJobs D;
   D.n = 0;
   if (g_rgb != nullptr) {
     const Geo g = geo_for_units((long)t3);
-    const int smode_app = scatter_mode(ns);
+    const int smode_app = scatter_mode(ns, stream);
     a.dfa = smode_app != 0 ? b.dfa : nullptr;   // sorted: k_dyn_app_bwd writes sample-major records instead of DA rows
     if (smode_app != 0) RDRF_LAUNCH("dyn_app_bwd", (k_dyn_app_bwd<false, true>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     else RDRF_LAUNCH("dyn_app_bwd", (k_dyn_app_bwd<false, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
@@ -3186,7 +3194,7 @@ extern "C" int rdrf_dynamic_bwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   }
   {
     const Geo g = geo_for_units(N);
-    const int smode = scatter_mode(ns);
+    const int smode = scatter_mode(ns, stream);
     a.dfs = smode != 0 ? b.dfs : nullptr;
     RDRF_LAUNCH("dyn_heads_bwd", (k_dyn_density_bwd<0, false>), dim3(g.grid), dim3(g.block), stream, a, w, gw);
     if (smode != 0) {
@@ -3272,9 +3280,9 @@ extern "C" int rdrf_static_features_bwd(const RdrfStaticParams* P, const RdrfFie
   a.M = M; a.in_norm = 1; a.g_feat = g_app; a.pk = b.pk; a.grows3 = b.grows3;
   if (saved != nullptr)
     RDRF_CHECK(carve_saved_feat(a.sp, saved, saved_bytes, 0, M), -3, "static_features_bwd: saved buffer too small");
-  RDRF_HIP(hipMemsetAsync(b.valid, 0, mp, stream));
-  RDRF_HIP(hipMemsetAsync(b.valid, 1, (size_t)M, stream));
-  RDRF_HIP(hipMemsetAsync(b.xpad, 0, mp * 3 * 4, stream));
+  RDRF_FILL(b.valid, 0, mp, stream);
+  RDRF_FILL(b.valid, 1, (size_t)M, stream);
+  RDRF_FILL(b.xpad, 0, mp * 3 * 4, stream);
   RDRF_HIP(hipMemcpyAsync(b.xpad, xn, (size_t)M * 3 * 4, hipMemcpyDeviceToDevice, stream));
   ScatterArgs sa0;
   fill_scatter_common(sa0, a);
@@ -3282,7 +3290,7 @@ extern "C" int rdrf_static_features_bwd(const RdrfStaticParams* P, const RdrfFie
   sa0.box.inv[0] = sa0.box.inv[1] = sa0.box.inv[2] = 1.0f;   // g_xn is the gradient wrt the normalised input
   sa0.g_xyz = g_xn;
   if (g_density != nullptr) {            // the feature is the plain sum of the 24 products: broadcast rows
-    RDRF_HIP(hipMemsetAsync(b.gpad, 0, mp * 4, stream));
+    RDRF_FILL(b.gpad, 0, mp * 4, stream);
     RDRF_HIP(hipMemcpyAsync(b.gpad, g_density, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
     ScatterArgs sa = sa0;
     sa.vm[0] = P->density; sa.gvm[0] = G->density; sa.nsets = 1;
@@ -3352,10 +3360,10 @@ extern "C" int rdrf_dynamic_features_bwd(const RdrfDynamicParams* P, const RdrfF
     rc = pack_launch(J, b.pk, stream);
     if (rc) return rc;
   }
-  RDRF_HIP(hipMemsetAsync(b.valid, 0, mp, stream));
-  RDRF_HIP(hipMemsetAsync(b.valid, 1, (size_t)M, stream));
-  RDRF_HIP(hipMemsetAsync(b.dxw, 0, mp * 3 * 4, stream));
-  RDRF_HIP(hipMemsetAsync(b.dxn, 0, mp * 3 * 4, stream));
+  RDRF_FILL(b.valid, 0, mp, stream);
+  RDRF_FILL(b.valid, 1, (size_t)M, stream);
+  RDRF_FILL(b.dxw, 0, mp * 3 * 4, stream);
+  RDRF_FILL(b.dxn, 0, mp * 3 * 4, stream);
   const Geo g = geo_for_units(Np);
   DwJobs D;
   D.n = 0;
@@ -3444,11 +3452,23 @@ extern "C" int rdrf_scene_flow_bwd(const RdrfDynamicParams* P, const RdrfFieldCf
 
 // ------------------------------------------------------------------------------------------------
 // ray generation backward: hand-written adjoint of k_generate_rays (rdrf_misc.hip)
-__global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float* __restrict__ uv, int view_shift,
+// The gradients of a batch land on T x 9 pose entries and ONE focal length: one global atomic per ray and entry was
+// 36 864 atomics on 108 addresses for a 4096-ray launch at T = 12 (109 us; five launches per iteration of the
+// pose-optimising configs).  Each workgroup now accumulates its rays in LDS (ds_add_f32) and issues one global atomic
+// per touched entry: GRB_LDS_POSES pose rows fit (any longer table falls back to global atomics).
+#define GRB_LDS_POSES 448
+__global__ __launch_bounds__(256) void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float* __restrict__ uv, int view_shift,
                                     const float* __restrict__ poses9,
                                     const float* __restrict__ focal_p, int N, int T, int H, int W,
                                     int ndc, float near, const float* __restrict__ g_rays,
                                     float* __restrict__ g_poses, float* __restrict__ g_focal) {
+  __shared__ float s_gp[GRB_LDS_POSES * 9];
+  __shared__ float s_gf[4];
+  const bool in_lds = T <= GRB_LDS_POSES;   // (uniform)
+  if (in_lds) {
+    for (int i = threadIdx.x; i < T * 9; i += blockDim.x) s_gp[i] = 0.f;
+    __syncthreads();
+  }
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   float gf = 0.f;
   if (n < N) {
@@ -3514,7 +3534,7 @@ __global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float
     for (int k = 0; k < 3; ++k) { gp1[k] = gu[k]; g_dt -= gu[k] * b1[k]; gb1[k] -= dt * gu[k]; }
     for (int k = 0; k < 3; ++k) { gb1[k] += g_dt * p[3 + k]; gp1[k] += g_dt * b1[k]; }
     const float dot1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
-    float* gp = g_poses + view * 9;
+    float* gp = in_lds ? s_gp + view * 9 : g_poses + view * 9;
     for (int k = 0; k < 3; ++k) {
       atomicAdd(gp + k, (gb1[k] - dot1 * b1[k]) / n1);
       atomicAdd(gp + 3 + k, gp1[k]);
@@ -3522,7 +3542,15 @@ __global__ void k_generate_rays_bwd(const int64_t* __restrict__ ids, const float
     }
   }
   gf = wave_sum(gf);
-  if ((threadIdx.x & 63) == 0 && gf != 0.f) atomicAdd(g_focal, gf);
+  if ((threadIdx.x & 63) == 0) s_gf[threadIdx.x >> 6] = gf;
+  __syncthreads();
+  if (in_lds)
+    for (int i = threadIdx.x; i < T * 9; i += blockDim.x)
+      if (s_gp[i] != 0.f) atomicAdd(g_poses + i, s_gp[i]);
+  if (threadIdx.x == 0) {
+    const float t = (s_gf[0] + s_gf[1]) + (s_gf[2] + s_gf[3]);
+    if (t != 0.f) atomicAdd(g_focal, t);
+  }
 }
 
 extern "C" int rdrf_generate_rays_uv_bwd(const int64_t* ids, const float* uv, int view_shift, const float* poses9,

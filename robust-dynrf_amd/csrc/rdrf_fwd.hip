@@ -333,9 +333,9 @@ extern "C" int rdrf_static_fwd(const RdrfStaticParams* P, const RdrfFieldCfg* cf
     rc = pack_launch(J, (float*)a.pk, stream);
     if (rc) return rc;
   }
-  RDRF_HIP(hipMemsetAsync(a.counter, 0, 256, stream));   // (the colours are zero-filled by k_static_density)
+  RDRF_FILL(a.counter, 0, 256, stream);   // (the colours are zero-filled by k_static_density)
 #ifdef RDRF_DETERMINISTIC
-  RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
+  RDRF_FILL(a.list, 0x7f, (size_t)N * S * sizeof(int), stream);
 #endif
   RDRF_LAUNCH("static_density", k_static_density<false>, dim3((N + 3) / 4), dim3(256), stream, a, w);   // 4 rays per workgroup: one list append
   if (rgb == nullptr) return 0;   // the caller does not consume the colours: the appearance phase is not run
@@ -409,11 +409,11 @@ extern "C" int rdrf_dynamic_fwd(const RdrfDynamicParams* P, const RdrfFieldCfg* 
   // the backward kernels address by (ray, tile)
   static const int flat_env = RDRF_ENV("RDRF_FLAT") ? atoi(RDRF_ENV("RDRF_FLAT")) : 1;   // 0: wave per ray (tools build)
   const bool flat = saved == nullptr && flat_env != 0;
-  if (!flat && rgb != nullptr) RDRF_HIP(hipMemsetAsync(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream));   // flat: k_ray_scan
+  if (!flat && rgb != nullptr) RDRF_FILL(rgb, 0, (size_t)N * S * 3 * sizeof(float), stream);   // flat: k_ray_scan
   RDRF_LAUNCH("time_branch", k_time_branch, dim3((N + 7) / 8), dim3(256), stream, ts, w, N, a.tout, a.counter);
   const Geo g1 = geo_for_units(N), g3 = geo_for_tiles(N, S);
 #ifdef RDRF_DETERMINISTIC
-  RDRF_HIP(hipMemsetAsync(a.list, 0x7f, (size_t)N * S * sizeof(int), stream));
+  RDRF_FILL(a.list, 0x7f, (size_t)N * S * sizeof(int), stream);
 #endif
   if (saved != nullptr) RDRF_LAUNCH("dyn_density", (k_dyn_density<false, true>), dim3(g1.grid), dim3(g1.block), stream, a, w);
   else if (flat) {

@@ -37,6 +37,15 @@ void rdrf_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// byte fill as a kernel launch (rdrf_pack.hip): the launch sequences use it instead of hipMemsetAsync, whose memset nodes do
+// not replay reliably inside a captured HIP graph
+int rdrf_fill_async(void* p, int byte_value, size_t bytes, hipStream_t stream);
+#define RDRF_FILL(p, v, bytes, stream)                          \
+  do {                                                          \
+    int rc_fill_ = rdrf_fill_async((p), (v), (bytes), (stream)); \
+    if (rc_fill_) return rc_fill_;                              \
+  } while (0)
+
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline figure)
 void rdrf_prof_begin(const char* name, hipStream_t s);
 void rdrf_prof_end(const char* name, hipStream_t s);

@@ -4,7 +4,7 @@
 // 1330-1371, 1391-1413, 1476-1528, 1786-1839 ); with the ray path in kernels those chains were ~250 of the
 // ~550 launches of an iteration, each a few microseconds of launch latency on a few KB of data.
 //
-// A term is   coef * sum_rows w[row] * sum_cols rho(x + ysign * y) / Z
+// A term is   coef [* *coef_dev] * sum_rows w[row] * sum_cols rho(x + ysign * y) / Z
 //   rho  : square | abs | identity            Z : rows * cols (a mean)  |  sum_rows w + 1e-8 (a masked mean)
 // which covers every photometric / mask / flow / disparity / scene-flow term of the step.  The per-frame
 // median depth loss (a sort), the distortion loss and TV have their own kernels.
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_loss_finish(LossTermsK T, const float* _
   if (k < T.n) {
     const RdrfLossTerm& t = T.t[k];
     const float z = t.norm == RDRF_LOSS_NORM_WEIGHT ? global[2 * k + 1] / world + 1e-8f : (float)(t.rows * t.cols);
-    const float scale = t.coef / z;
+    const float scale = (t.coef_dev ? t.coef * t.coef_dev[0] : t.coef) / z;
     val = local[2 * k] * scale;
     out[1 + k] = scale;
     out[1 + T.n + k] = val;
@@ -334,7 +334,7 @@ extern "C" int rdrf_frame_depth_loss_fwd(const float* pred, const float* gt, con
     RDRF_HIP(hipFuncSetAttribute((const void*)k_frame_depth_loss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // rays whose frame id lies outside [0, T) are selected by no workgroup: their gradient is 0, not uninitialised memory
-  RDRF_HIP(hipMemsetAsync(g_raw, 0, (size_t)N * sizeof(float), stream));
+  RDRF_FILL(g_raw, 0, (size_t)N * sizeof(float), stream);
   rdrf_prof_begin("frame_depth_loss", stream);
   hipLaunchKernelGGL(k_frame_depth_loss, dim3(T), dim3(FDL_THREADS), lds, stream, pred, gt, frame, mask, N, g_raw, part);
   hipLaunchKernelGGL(k_frame_depth_finish, dim3(mask ? (N + 255) / 256 : 1), dim3(256), 0, stream, (const float*)part, T, coef,

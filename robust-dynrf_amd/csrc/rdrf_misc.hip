@@ -122,14 +122,15 @@ __global__ __launch_bounds__(64) void k_composite(CompArgs a) { composite_body(a
 extern "C" int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
                                   const float* sigma_d, const float* dists, const float* blending,
                                   const float* z, const float* rays, int N, int S, int ray_type,
-                                  int add_white_bg, float* const out13[13], rdrf_stream_t stream_) {
+                                  int add_white_bg, const float* white_dev, float* const out13[13],
+                                  rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
   RDRF_CHECK(N > 0 && S > 0 && out13, -1, "composite_fwd: bad arguments");
   CompArgs a;
   a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
   a.dists = dists; a.blending = blending; a.z = z; a.rays = rays;
-  a.N = N; a.S = S; a.ray_type = ray_type; a.add_white_bg = add_white_bg;
+  a.N = N; a.S = S; a.ray_type = ray_type; a.add_white_bg = add_white_bg; a.white_dev = white_dev;
   for (int i = 0; i < 13; ++i) {
     RDRF_CHECK(out13[i] != nullptr, -1, "composite_fwd: output %d is NULL", i);
     a.out[i] = out13[i];
@@ -148,6 +149,7 @@ extern "C" int rdrf_composite_fwd(const float* rgb_s, const float* sigma_s, cons
 struct CompBArgs {
   const float *rgb_s, *sigma_s, *rgb_d, *sigma_d, *dists, *blending, *z, *rays;
   int N, S, ray_type, add_white_bg;
+  const float* white_dev;
   const float* g[13];
   float* gi[8];
 };
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
   __syncthreads();
   const float Ue = U + 1e-10f;
   const float acc_d = U / Ue;
-  const float white = a.add_white_bg ? 1.f : 0.f;
+  const float white = (a.white_dev ? (a.white_dev[0] != 0.f) : (a.add_white_bg != 0)) ? 1.f : 0.f;
   const bool rl_on = (1.0f - acc_f) > 0.f;
   const float rl = rl_on ? 1.0f - acc_f : 0.f;
   float far = 0.f;
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBArgs a) {
 extern "C" int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, const float* rgb_d,
                                   const float* sigma_d, const float* dists, const float* blending,
                                   const float* z, const float* rays, int N, int S, int ray_type,
-                                  int add_white_bg, const float* const g_out13[13],
+                                  int add_white_bg, const float* white_dev, const float* const g_out13[13],
                                   float* const g_in8[8], rdrf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N == 0) return 0;   // empty batch: a no-op, like torch ops on empty tensors (their data pointers are null)
@@ -327,7 +329,7 @@ extern "C" int rdrf_composite_bwd(const float* rgb_s, const float* sigma_s, cons
   CompBArgs a;
   a.rgb_s = rgb_s; a.sigma_s = sigma_s; a.rgb_d = rgb_d; a.sigma_d = sigma_d;
   a.dists = dists; a.blending = blending; a.z = z; a.rays = rays;
-  a.N = N; a.S = S; a.ray_type = ray_type; a.add_white_bg = add_white_bg;
+  a.N = N; a.S = S; a.ray_type = ray_type; a.add_white_bg = add_white_bg; a.white_dev = white_dev;
   for (int i = 0; i < 13; ++i) a.g[i] = g_out13[i];
   for (int i = 0; i < 8; ++i) a.gi[i] = g_in8[i];
   RDRF_LAUNCH("composite_bwd", k_composite_bwd, dim3(N), dim3(64), stream, a);
@@ -474,19 +476,13 @@ __global__ __launch_bounds__(64) void k_induce_flow(int H, int W, const float* _
   }
 }
 
-__global__ __launch_bounds__(64) void k_induce_flow_bwd(int H, int W, const float* __restrict__ focal,
-                                                        const float* __restrict__ c2w,
-                                                        const float* __restrict__ weights,
-                                                        const float* __restrict__ pts,
-                                                        const float* __restrict__ rays, int N, int S,
-                                                        int ray_type, const float* __restrict__ g_flow,
-                                                        const float* __restrict__ g_disp,
-                                                        float* __restrict__ g_weights,
-                                                        float* __restrict__ g_pts,
-                                                        float* __restrict__ g_rays,
-                                                        float* __restrict__ g_c2w,
-                                                        float* __restrict__ g_focal) {
-  const int n = blockIdx.x, lane = threadIdx.x;
+// one wave per ray; returns d loss / d focal of the ray (wave-uniform)
+RDRF_D float induce_flow_bwd_ray(const int n, const int lane, int H, int W, const float* __restrict__ focal,
+                                 const float* __restrict__ c2w, const float* __restrict__ weights,
+                                 const float* __restrict__ pts, const float* __restrict__ rays, int S, int ray_type,
+                                 const float* __restrict__ g_flow, const float* __restrict__ g_disp,
+                                 float* __restrict__ g_weights, float* __restrict__ g_pts, float* __restrict__ g_rays,
+                                 float* __restrict__ g_c2w) {
   float acc = 0.f, ps[3] = {0.f, 0.f, 0.f};
   for (int s = lane; s < S; s += 64) {
     const float w = weights[(size_t)n * S + s];
@@ -569,9 +565,39 @@ __global__ __launch_bounds__(64) void k_induce_flow_bwd(int H, int W, const floa
     if (g_c2w)
       for (int i = 0; i < 12; ++i) g_c2w[(size_t)n * 12 + i] += gM[i];
   }
-  if (g_focal) {
-    // one atomic per wave: lanes hold identical gf, only lane 0 contributes
-    if (lane == 0) atomicAdd(g_focal, gf);
+  return gf;
+}
+
+// IFB_WAVES rays per workgroup: the focal length is ONE float that every ray's gradient lands on -- one atomic per ray
+// serialised 4096 same-address atomics per launch (33 us of a 4096-ray launch at S = 13, eight launches per iteration of
+// the pose-optimising configs); the workgroup's rays are summed in LDS first
+#define IFB_WAVES 8
+__global__ __launch_bounds__(64 * IFB_WAVES) void k_induce_flow_bwd(int H, int W, const float* __restrict__ focal,
+                                                                   const float* __restrict__ c2w,
+                                                                   const float* __restrict__ weights,
+                                                                   const float* __restrict__ pts,
+                                                                   const float* __restrict__ rays, int N, int S,
+                                                                   int ray_type, const float* __restrict__ g_flow,
+                                                                   const float* __restrict__ g_disp,
+                                                                   float* __restrict__ g_weights,
+                                                                   float* __restrict__ g_pts,
+                                                                   float* __restrict__ g_rays,
+                                                                   float* __restrict__ g_c2w,
+                                                                   float* __restrict__ g_focal) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * IFB_WAVES + wave;
+  float gf = 0.f;
+  if (n < N) gf = induce_flow_bwd_ray(n, lane, H, W, focal, c2w, weights, pts, rays, S, ray_type, g_flow, g_disp, g_weights,
+                                      g_pts, g_rays, g_c2w);
+  if (g_focal) {   // (uniform)
+    __shared__ float s_gf[IFB_WAVES];
+    if (lane == 0) s_gf[wave] = gf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < IFB_WAVES; ++i) t += s_gf[i];
+      if (t != 0.f) atomicAdd(g_focal, t);
+    }
   }
 }
 
@@ -602,7 +628,7 @@ extern "C" int rdrf_induce_flow_bwd(int H, int W, const float* focal, const floa
   RDRF_CHECK(ray_type == RDRF_RAY_NDC || ray_type == RDRF_RAY_CONTRACT, -1,
              "induce_flow_bwd: ray_type must be ndc or contract");
   RDRF_CHECK(g_flow || g_disp, -1, "induce_flow_bwd: no output gradient given");
-  RDRF_LAUNCH("induce_flow_bwd", k_induce_flow_bwd, dim3(N), dim3(64), stream, H, W, focal, c2w, weights,
+  RDRF_LAUNCH("induce_flow_bwd", k_induce_flow_bwd, dim3((N + IFB_WAVES - 1) / IFB_WAVES), dim3(64 * IFB_WAVES), stream, H, W, focal, c2w, weights,
               pts, rays, N, S, ray_type, g_flow, g_disp, g_weights, g_pts, g_rays, g_c2w, g_focal);
   return 0;
 }
@@ -770,7 +796,7 @@ extern "C" int rdrf_tv_fwd(const RdrfTensor4* t, int n, float* sums, rdrf_stream
   int rc = tv_jobs(J, t, n, false, maxel);
   if (rc) return rc;
   RDRF_CHECK(sums, -1, "tv_fwd: sums is null");
-  RDRF_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * n, stream));
+  RDRF_FILL(sums, 0, sizeof(float) * 2 * n, stream);
   long long gx = (maxel + 256 * 8 - 1) / (256 * 8);
   gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
   RDRF_LAUNCH("tv_fwd", k_tv_fwd, dim3((unsigned)gx, n), dim3(256), stream, J, sums);
@@ -867,5 +893,50 @@ extern "C" int rdrf_tv_grad(const RdrfTensor4* t, int n, const float* coef_host,
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
     RDRF_LAUNCH("tv_grad", k_tv_grad, dim3((unsigned)gx, m), dim3(256), stream, J);
   }
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of a row gather  rows[n] = table[idx[n]]  (the trainer's `allposes_refine[view +- 1]`, train.py:1895-1948: the
+// camera matrices of the neighbour frames, live when the poses are optimised): g_table[idx[n]] += g_rows[n].
+// torch's index backward sorts the indices and runs a segmented scan (270 us for 4096 rows of 12 floats into a 12-row
+// table: two launches per iteration); here each workgroup accumulates in LDS and issues one global atomic per touched
+// entry (tables beyond RSA_LDS_FLOATS fall back to global atomics).
+// ------------------------------------------------------------------------------------------------
+#define RSA_LDS_FLOATS 8192
+__global__ __launch_bounds__(256) void k_rows_scatter_add(const int64_t* __restrict__ idx, const float* __restrict__ g_rows, long N,
+                                                          int R, int C, float* __restrict__ g_table) {
+  __shared__ float s_acc[RSA_LDS_FLOATS];
+  const bool in_lds = (long)R * C <= RSA_LDS_FLOATS;   // (uniform)
+  if (in_lds) {
+    for (int i = threadIdx.x; i < R * C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+  }
+  const long total = N * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long n = e / C;
+    const int c = (int)(e - n * C);
+    const long r = idx[n];
+    if (r < 0 || r >= R) continue;   // (torch raises on such an index in the forward gather)
+    const float g = g_rows[e];
+    if (in_lds) atomicAdd(&s_acc[r * C + c], g);
+    else atomicAdd(g_table + r * C + c, g);
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * C; i += blockDim.x)
+      if (s_acc[i] != 0.f) atomicAdd(g_table + i, s_acc[i]);
+  }
+}
+
+extern "C" int rdrf_rows_scatter_add(const int64_t* idx, const float* g_rows, int N, int R, int C, float* g_table,
+                                     rdrf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N == 0) return 0;
+  RDRF_CHECK(N > 0 && R > 0 && C > 0 && idx && g_rows && g_table, -1, "rows_scatter_add: bad arguments");
+  long blocks = ((long)N * C + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  RDRF_LAUNCH("rows_scatter_add", k_rows_scatter_add, dim3((unsigned)blocks), dim3(256), stream, idx, g_rows, (long)N, R, C, g_table);
   return 0;
 }

@@ -98,6 +98,7 @@ RDRF_D void sample_contract_body(const float* __restrict__ rays, int N, int S, f
 struct CompArgs {
   const float *rgb_s, *sigma_s, *rgb_d, *sigma_d, *dists, *blending, *z, *rays;
   int N, S, ray_type, add_white_bg;
+  const float* white_dev;   // nullable: the coin as a device float (overrides add_white_bg; HIP-graph replays)
   float* out[13];
 };
 
@@ -176,7 +177,7 @@ RDRF_D void composite_body(const CompArgs a, const GridCtx gc) {
   dyn = wave_sum(dyn);
   if (lane == 0) {
     const float rl = fmaxf(1.0f - acc_f, 0.0f);
-    if (a.add_white_bg) {
+    if (a.white_dev ? (a.white_dev[0] != 0.f) : (a.add_white_bg != 0)) {
       for (int c = 0; c < 3; ++c) { rd[c] += 1.0f - acc_d; rs[c] += 1.0f - acc_s; rf[c] += rl; }
     }
     if (a.ray_type == RDRF_RAY_NDC) {

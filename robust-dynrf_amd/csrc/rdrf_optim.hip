@@ -301,7 +301,7 @@ extern "C" int rdrf_dense_l1_fwd(const RdrfVM* vm, int act, float density_shift,
   L1Args a;
   memset(&a, 0, sizeof(a));
   a.vm = *vm; a.act = act; a.shift = density_shift; a.out = sum_out;
-  RDRF_HIP(hipMemsetAsync(sum_out, 0, sizeof(float), stream));
+  RDRF_FILL(sum_out, 0, sizeof(float), stream);
   const int X = vm->W[0], Y = vm->H[0];
   RDRF_LAUNCH("dense_l1", (k_dense_l1<0, 0>), dim3((X + 31) / 32, (Y + 7) / 8), dim3(256), stream, a);
   return 0;

@@ -23,6 +23,31 @@ extern "C" const char* rdrf_last_error(void) { return g_err; }
 extern "C" int rdrf_abi_version(void) { return RDRF_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------
+// byte fill as a KERNEL.  hipMemsetAsync is a memset node in a captured HIP graph, and replays of such nodes were observed
+// not to clear the static field's 256-byte list counter (tools/graph/probe.py: rdrf_static_fwd replayed -> the list
+// overruns its buffer on the second replay); a kernel node replays like every other launch of the sequence.
+__global__ __launch_bounds__(256) void k_fill_bytes(unsigned char* __restrict__ p, unsigned value, size_t bytes) {
+  const unsigned w = value * 0x01010101u;
+  const size_t head = ((16 - ((size_t)p & 15)) & 15) < bytes ? ((16 - ((size_t)p & 15)) & 15) : bytes;   // to 16-byte alignment
+  const size_t nvec = (bytes - head) / 16;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  uint4* v = (uint4*)(p + head);
+  for (size_t i = tid; i < nvec; i += nth) v[i] = make_uint4(w, w, w, w);
+  if (tid < head) p[tid] = (unsigned char)value;
+  const size_t tail0 = head + nvec * 16;
+  if (tail0 + tid < bytes && tid < 16) p[tail0 + tid] = (unsigned char)value;
+}
+int rdrf_fill_async(void* p, int byte_value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return 0;
+  RDRF_CHECK(p != nullptr, -1, "fill: null pointer");
+  size_t blocks = (bytes / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(k_fill_bytes, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned char*)p, (unsigned)(byte_value & 0xff), bytes);
+  RDRF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 struct ProfRec {
   std::string name;
   hipEvent_t a, b;

@@ -197,10 +197,10 @@ extern "C" int rdrf_render_fused_fwd(const RdrfStaticParams* PS, const RdrfField
   }
   r.comp.rgb_s = b.rgb_s; r.comp.sigma_s = b.sigma_s; r.comp.rgb_d = b.rgb_d; r.comp.sigma_d = b.sigma_d;
   r.comp.dists = b.dists_d; r.comp.blending = b.blending; r.comp.z = b.z; r.comp.rays = rays;
-  r.comp.N = N; r.comp.S = S; r.comp.ray_type = cfg_d->ray_type; r.comp.add_white_bg = 0;
+  r.comp.N = N; r.comp.S = S; r.comp.ray_type = cfg_d->ray_type; r.comp.add_white_bg = 0; r.comp.white_dev = nullptr;
   for (int i = 0; i < 13; ++i) r.comp.out[i] = b.out[i];
   r.near = near; r.far = far; r.barrier = b.barrier;
-  RDRF_HIP(hipMemsetAsync(b.barrier, 0, 256, stream));
+  RDRF_FILL(b.barrier, 0, 256, stream);
   // one workgroup per CU at most (its LDS holds a whole weight image); fewer when the chunk has fewer units of work
   const long tiles = ((long)N * S + 31) / 32;
   const long units = tiles > N ? tiles : N;
@@ -248,7 +248,7 @@ extern "C" int rdrf_render_sequence_fwd(const RdrfStaticParams* PS, const RdrfFi
                         b.sigma_d, b.dists_d, nullptr, 0, b.fws_d, fwb, stream);
   if (rc) return rc;
   return rdrf_composite_fwd(b.rgb_s, b.sigma_s, b.rgb_d, b.sigma_d, b.dists_d, b.blending, b.z, rays, N, S,
-                            cfg_d->ray_type, 0, b.out, stream);
+                            cfg_d->ray_type, 0, nullptr, b.out, stream);
 }
 
 // Measured on MI355X (tools/render_bench.py, Balloon1 stage-0 shape, 240 x 135 frame): whole frame 7.7 ms either way (the

@@ -19,7 +19,7 @@ class _LossTermsFn(torch.autograd.Function):
         dev = tensors[0].device
         arr = (L.RdrfLossTerm * n)()
         held = []
-        for k, (kind, norm, ysign, coef, rows, cols) in enumerate(meta):
+        for k, (kind, norm, ysign, coef, rows, cols, cdev) in enumerate(meta):
             x, y, w = tensors[3 * k: 3 * k + 3]
             x = L.f32c(x)
             y = None if y is None else L.f32c(y)
@@ -29,6 +29,7 @@ class _LossTermsFn(torch.autograd.Function):
             t.x, t.y, t.w = x.data_ptr(), (0 if y is None else y.data_ptr()), (0 if w is None else w.data_ptr())
             t.gx = t.gy = 0
             t.rows, t.cols, t.kind, t.norm, t.ysign, t.coef = rows, cols, kind, norm, ysign, coef
+            t.coef_dev = 0 if cdev is None else cdev.data_ptr()
         partial = torch.empty(int(L.lib.rdrf_loss_terms_workspace_floats(n)), device=dev)
         out = torch.empty(1 + 2 * n, device=dev)
         if reducer is None:
@@ -49,7 +50,7 @@ class _LossTermsFn(torch.autograd.Function):
         n = len(meta)
         arr = (L.RdrfLossTerm * n)()
         grads = []
-        for k, (kind, norm, ysign, coef, rows, cols) in enumerate(meta):
+        for k, (kind, norm, ysign, coef, rows, cols, cdev) in enumerate(meta):
             x, y, w = held[3 * k: 3 * k + 3]
             need_x, need_y = ctx.needs_input_grad[2 + 3 * k], ctx.needs_input_grad[3 + 3 * k]
             if ctx.needs_input_grad[4 + 3 * k]:
@@ -60,6 +61,7 @@ class _LossTermsFn(torch.autograd.Function):
             t.x, t.y, t.w = x.data_ptr(), (0 if y is None else y.data_ptr()), (0 if w is None else w.data_ptr())
             t.gx, t.gy = (0 if gx is None else gx.data_ptr()), (0 if gy is None else gy.data_ptr())
             t.rows, t.cols, t.kind, t.norm, t.ysign, t.coef = rows, cols, kind, norm, ysign, coef
+            t.coef_dev = 0 if cdev is None else cdev.data_ptr()   # (backward reads out[1 + k], which already holds it)
             grads += [gx, gy, None]
         g = L.f32c(g_loss.reshape(1))
         L.check(L.lib.rdrf_loss_terms_bwd(arr, n, L.ptr(out), L.ptr(g), L.stream_of(out)), "rdrf_loss_terms_bwd")
@@ -158,6 +160,8 @@ class LossTerms:
 
     def add(self, coef, kind, x, y=None, ysign=-1.0, w=None, norm="mean"):
         """+= coef * sum(rho(x + ysign*y) * w[row]) / Z.   kind: "square" | "abs" | "identity";
+        coef: a float, or (float, tensor): the float times a one-element fp32 DEVICE tensor read when the kernel runs (a
+        weight that changes every iteration inside a captured HIP graph: Trainer(graph=True));
         w: one weight per row (x viewed as [w.numel(), -1]; no w: every element is a row);
         norm: "mean" (Z = x.numel()) or "weight" (Z = w.sum() + 1e-8: the reference's masked mean)."""
         if len(self._meta) >= L.MAX_LOSS_TERMS:
@@ -172,7 +176,12 @@ class LossTerms:
             raise L.RdrfError(f"LossTerms: {x.numel()} elements do not split into {rows} weighted rows")
         if norm == "weight" and w is None:
             raise L.RdrfError("LossTerms: norm='weight' needs row weights")
-        self._meta.append((_KINDS[kind], 1 if norm == "weight" else 0, float(ysign), float(coef), rows, x.numel() // rows))
+        cdev = None
+        if isinstance(coef, tuple):
+            coef, cdev = coef
+            if cdev is not None and (cdev.dtype != torch.float32 or cdev.numel() != 1 or not cdev.is_cuda or cdev.requires_grad):
+                raise L.RdrfError("LossTerms: a device coefficient is one fp32 element on the GPU, not a trained tensor")
+        self._meta.append((_KINDS[kind], 1 if norm == "weight" else 0, float(ysign), float(coef), rows, x.numel() // rows, cdev))
         self._tensors += [x, y, None if w is None else w.detach()]
         return self
 

@@ -52,6 +52,38 @@ def generate_rays(ray_idx, poses9, focal, H, W, ndc=True, near=1.0, uv=None, vie
     return _RayGenFn.apply(ray_idx, poses9, focal, int(H), int(W), bool(ndc), float(near), uv, int(view_shift))
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, idx):
+        L.require_device(table, idx)
+        idx = idx.contiguous().long()
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return table.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        (idx,) = ctx.saved_tensors
+        R = ctx.shape[0]
+        Cc = 1
+        for d in ctx.shape[1:]:
+            Cc *= d
+        g_rows = L.f32c(g_rows)
+        g_table = torch.zeros(ctx.shape, device=g_rows.device)
+        L.check(L.lib.rdrf_rows_scatter_add(L.ptr(idx), L.ptr(g_rows), idx.numel(), R, Cc, L.ptr(g_table), L.stream_of(g_rows)),
+                "rdrf_rows_scatter_add")
+        return g_table, None
+
+
+def gather_rows(table, idx):
+    """table[idx] for a small per-frame table (the [T,3,4] camera matrices of the neighbour frames,
+    `allposes_refine[view +- 1]`, train.py:1895-1948) with a backward that accumulates per workgroup in LDS
+    (rdrf_rows_scatter_add) instead of torch's sort-based index backward; idx [N] int64 in [0, T)."""
+    if not table.requires_grad or not torch.is_grad_enabled():
+        return table[idx]
+    return _GatherRowsFn.apply(table, idx)
+
+
 def ids2pixel(W, H, ids):
     return ids % W, (ids // W) % H, ids // (W * H)
 

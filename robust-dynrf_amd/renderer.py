@@ -92,10 +92,16 @@ class _CompositeFn(torch.autograd.Function):
         shapes = [(N, 3), (N,), (N,), (N, S)] * 3 + [(N,)]
         outs = [torch.empty(s, device=dev) for s in shapes]
         arr = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
+        # the coin as a device float (one element, 0 / 1): read when the kernel runs, so a captured HIP graph of the
+        # iteration follows each replay's coin (step.Trainer(graph=True)); a host bool otherwise
+        white_dev = add_white_bg if torch.is_tensor(add_white_bg) else None
+        if white_dev is not None and (white_dev.dtype != torch.float32 or white_dev.numel() != 1 or not white_dev.is_cuda):
+            raise L.RdrfError("raw2outputs: a device coin is one fp32 element on the GPU")
+        white = 0 if white_dev is not None else int(add_white_bg)
         L.check(L.lib.rdrf_composite_fwd(*[L.ptr(t) for t in ins], N, S, L.RAY_TYPES.get(ray_type, 2),
-                                         int(add_white_bg), arr, L.stream_of(ins[1])),
+                                         white, L.ptr(white_dev), arr, L.stream_of(ins[1])),
                 "rdrf_composite_fwd")
-        ctx.ray_type, ctx.white = ray_type, int(add_white_bg)
+        ctx.ray_type, ctx.white, ctx.white_dev = ray_type, white, white_dev
         ctx.save_for_backward(*ins)
         return tuple(outs)
 
@@ -124,7 +130,7 @@ class _CompositeFn(torch.autograd.Function):
         ga = (C.c_void_p * 13)(*[0 if g is None else g.data_ptr() for g in g_out])
         gi = (C.c_void_p * 8)(*[0 if g is None else g.data_ptr() for g in g_in])
         L.check(L.lib.rdrf_composite_bwd(*[L.ptr(t) for t in ins], N, S,
-                                         L.RAY_TYPES.get(ctx.ray_type, 2), ctx.white, ga, gi,
+                                         L.RAY_TYPES.get(ctx.ray_type, 2), ctx.white, L.ptr(ctx.white_dev), ga, gi,
                                          L.stream_of(ins[1])), "rdrf_composite_bwd")
         return (*g_in, None, None)
 
@@ -132,11 +138,12 @@ class _CompositeFn(torch.autograd.Function):
 def raw2outputs(rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z_vals, rays_chunk, is_train=False,
                 ray_type="ndc", add_white_bg=None):
     """renderer.py:173-315.  The train-time coin (`torch.rand((1,)) < 0.5`, renderer.py:269) is
-    drawn here on the host unless `add_white_bg` is given."""
+    drawn here on the host unless `add_white_bg` is given: a bool, or a one-element fp32 DEVICE tensor (0 / 1) that the
+    kernels read when they run."""
     if add_white_bg is None:
         add_white_bg = bool(is_train and (torch.rand((1,)) < 0.5).item())
     return _CompositeFn.apply(rgb_s, sigma_s, rgb_d, sigma_d, dists, blending, z_vals, rays_chunk,
-                              ray_type, bool(add_white_bg))
+                              ray_type, add_white_bg if torch.is_tensor(add_white_bg) else bool(add_white_bg))
 
 
 def OctreeRender_trilinear_fast(rays, ts, timeembeddings, tensorf, xyz_sampled, z_vals_input,

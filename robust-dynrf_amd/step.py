@@ -31,6 +31,7 @@ per-iteration host sync (``.item()``): losses and the per-frame medians stay on 
 import collections
 import math
 import os
+import types
 
 import torch
 import torch.nn as nn
@@ -38,7 +39,7 @@ import torch.nn as nn
 from .fields import TensorVMSplit, TensorVMSplit_TimeEmbedding
 from .optim import FlatAdam
 from .parallel import require_even_shards
-from .ray_utils import generate_rays, ids2pixel, pose_to_mtx
+from .ray_utils import gather_rows, generate_rays, ids2pixel, pose_to_mtx
 from .regularizers import TVLoss
 from .losses import LossTerms, frame_depth_loss
 from .renderer import distloss_rays, induce_flow, raw2outputs, sampleXYZ
@@ -206,9 +207,10 @@ class SyntheticScene:
     def ts_of(self, ids):
         return self.ts_table[ids]
 
-    def make_batch(self, it, bs, shard=None):
-        """everything one iteration reads, as a dict of device tensors (train.py:1043-1060)"""
-        ids, ids2 = self.batch(it, bs, 0), self.batch(it, bs, 1)
+    def make_batch(self, it, bs, shard=None, ids=None):
+        """everything one iteration reads, as a dict of device tensors (train.py:1043-1060).  ids = (ids, ids2): the two
+        index draws come from the caller's (static) buffers -- a captured iteration gathers from whatever they hold"""
+        ids, ids2 = (self.batch(it, bs, 0), self.batch(it, bs, 1)) if ids is None else ids
         if shard is not None:  # (rank, world): ray-sharded data parallelism
             r, w = shard
             lo, hi = r * bs // w, (r + 1) * bs // w
@@ -247,6 +249,45 @@ class StepRng:
         if ray_type == "ndc":
             return self._take(S, device), None
         return self._take(S - S // 2 + 1, device), self._take(S // 2 + 1, device)
+
+
+class GraphRng:
+    """The draws of StepRng held in STATIC device memory, so that a captured iteration (Trainer(graph=True)) reads fresh
+    ones at every replay: begin() refills the jitter pool with one launch and derives the white-background coins from
+    its head with a second (round(u) of a uniform u is 0 / 1 with probability 1/2 each); jitter() / coin() then hand out
+    fixed slices in call order -- the same slices at capture and at every replay, since the iteration's structure is
+    fixed.  coin() returns a one-element fp32 DEVICE tensor (raw2outputs' `add_white_bg`, rdrf_composite_*'s white_dev).
+    frozen = True keeps the current contents (tests replay fixed draws through the eager and the captured path)."""
+    N_COINS = 16
+
+    def __init__(self, device, pool_floats=1 << 16):
+        self.pool = torch.rand(pool_floats, device=device)
+        self.coins = torch.round(self.pool[: self.N_COINS])
+        self.frozen = False
+        self._cur, self._ncoin = 64, 0
+
+    def begin(self):
+        if not self.frozen:
+            self.pool.uniform_()
+            torch.round(self.pool[: self.N_COINS], out=self.coins)
+        self._cur, self._ncoin = 64, 0
+
+    def coin(self):
+        if self._ncoin >= self.N_COINS:
+            raise RuntimeError("GraphRng: more than N_COINS coins in one iteration")
+        k = self._ncoin
+        self._ncoin += 1
+        return self.coins[k: k + 1]
+
+    def _take(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        if self._cur + n_al > self.pool.numel():
+            raise RuntimeError("GraphRng: the jitter pool is too small for one iteration of this shape")
+        v = self.pool[self._cur: self._cur + n]
+        self._cur += n_al
+        return v
+
+    jitter = StepRng.jitter
 
 
 # ray-passes evaluated since the last reset, by kind (bench.py prices its algorithmic byte / FLOP counts per PASS: a
@@ -372,7 +413,7 @@ def masked_mean(x, m):
 
 class Trainer:
     def __init__(self, cfg, device, weights="dense", lr_init=0.02, lr_basis=1e-3, dead_work=False,
-                 dp_mode="allreduce", lr_pose=3e-3, dp_exact_stats=False, batch_passes=None):
+                 dp_mode="allreduce", lr_pose=3e-3, dp_exact_stats=False, batch_passes=None, graph=False):
         """dead_work: also run what the reference computes although nothing consumes it (SURVEY.md 3.1 liveness table):
         the dynamic-field forward of passes E / P3 / P4, and the appearance phase (colours) of both fields in passes B-D
         and P1-P4, whose rgb maps no loss term reads; off = skipped, losses and gradients identical.
@@ -382,7 +423,14 @@ class Trainer:
         floats per loss group, one all-gather of the per-ray depths), so that an N-rank run optimises exactly the
         single-process objective; off: per-shard statistics.
         batch_passes (default on; RDRF_BATCH_PASSES=0): passes A-D share one static forward and passes of equal gradient
-        liveness one dynamic forward / backward (ray_passes); off = one launch sequence per pass, same arithmetic."""
+        liveness one dynamic forward / backward (ray_passes); off = one launch sequence per pass, same arithmetic.
+        graph (single-process runs): batch gather, every forward pass and both backward phases of an iteration are captured
+        ONCE per shape / gate combination as a HIP graph (torch.cuda.CUDAGraph) and replayed -- the coarse stages of
+        Nvidia_no_poses.txt / DAVIS.txt (S = 13) spend ~9.5 ms per iteration enqueueing ~300 launches of a few
+        microseconds each from Python.  What changes from iteration to iteration reaches the kernels through static
+        device memory: ray indices, sampling jitter and white-background coins (GraphRng), the loss weights that ramp
+        (distortion ramp it / n_iters, Temp_static; LossTerms' device coefficients).  TV, Adam and the pose / focal Adam
+        stay outside the graph (their weights and rates change every iteration; ~10 launches)."""
         self.batch_passes = (os.environ.get("RDRF_BATCH_PASSES", "1") != "0") if batch_passes is None else bool(batch_passes)
         self.dead_work = dead_work
         self.dp_exact_stats = bool(dp_exact_stats)
@@ -409,6 +457,9 @@ class Trainer:
             self.opt_pose = torch.optim.Adam([self.poses], lr=lr_pose)
             self.opt_focal = torch.optim.Adam([self.fov], lr=lr_pose if self.it >= ups[3] else 0.0)
         self.rng = StepRng()
+        self.graph = bool(graph)
+        self._graphs, self._graph_seen, self._gs = {}, None, None
+        self._dyn = None   # name -> one-element device tensor: the iteration scalars of a captured iteration
         self.tv = TVLoss()
         self.grad_flats = self.opt.grad_flats()
         self.last = {}
@@ -440,6 +491,14 @@ class Trainer:
 
     def pose_table(self):
         return self.poses if self.optimize_poses else self.data.poses
+
+    def _coef(self, const, name, value):
+        """const * value as a LossTerms coefficient, for an iteration scalar `value` that changes every iteration:
+        the host product, or -- while the iteration runs on static inputs (graph mode) -- (const, the device scalar
+        `name`, which _graph_inputs() filled with `value`)"""
+        if self._dyn is None:
+            return const * value
+        return (const, self._dyn[name])
 
     def rays_for(self, ids, poses=None, focal=None, uv=None, view_shift=0):
         c = self.cfg
@@ -540,8 +599,9 @@ class Trainer:
                                                  dp=self._dp()))
         # distortion loss of the dynamic weights (train.py:1299-1312, 1685-1716), ramped by iteration / n_iters
         w_dist = c["dist_dynamic"] * (it / c["n_iters"])
+        k_dist = self._coef(c["dist_dynamic"], "ramp", it / c["n_iters"])   # == w_dist (a device scalar in graph mode)
         if w_dist > 0:   # mean over the rays of the per-ray loss (eff_distloss), weighted
-            Ld.add(w_dist, "identity", distloss_rays(outA[11], oA[8].detach(), 1.0 / S))
+            Ld.add(k_dist, "identity", distloss_rays(outA[11], oA[8].detach(), 1.0 / S))
         # ---- pass B (second random time)
         _, oB, outB, _ = batched["B"] if batched else ray_pass(self.st, self.dy, rays_d, b["ts_rand"], S, rt, rng,
                                                                rgb_s=self.dead_work, rgb_d=self.dead_work)
@@ -551,7 +611,7 @@ class Trainer:
         xo, yo, wo = order_terms(outB)
         Ld.add(10.0, "square", xo, yo, w=wo, norm="weight")                             # novel_order_loss, :1277-1291
         if w_dist > 0:
-            Ld.add(w_dist, "identity", distloss_rays(outB[11], oB[8].detach(), 1.0 / S))
+            Ld.add(k_dist, "identity", distloss_rays(outB[11], oB[8].detach(), 1.0 / S))
         # ---- scene flow on pass A's sample points
         sf_f, sf_b = self.dy.get_forward_backward_scene_flow(oA[3], ts)
         Ld.add(c["small_scene_flow_weight"], "abs", sf_f).add(c["small_scene_flow_weight"], "abs", sf_b)   # :1421-1424
@@ -578,14 +638,15 @@ class Trainer:
             _, ind_disp_n = induce_flow(H, W, focal_d, pose_n, outN[11], oN[3], px, rays_n, ray_type=rt)
             Ld.add(0.04 * temp, "abs", ind_disp, ind_disp_n, w=mask_t, norm="weight")   # :1522-1524, 1619-1621
             if w_dist > 0:
-                Ld.add(w_dist, "identity", distloss_rays(outN[11], oN[8].detach(), 1.0 / S))
+                Ld.add(k_dist, "identity", distloss_rays(outN[11], oN[8].detach(), 1.0 / S))
         # ---- pass E: static field with gradient, rays with gradient (pose / focal)
         oE, _, outE, _ = ray_pass(self.st, self.dy, rays, ts, S, rt, rng, static_grad=True, dynamic=self.dead_work)
         m = (1.0 - fg)[:, None]
         Ls = self._loss_terms()
         Ls.add(1.0 / 3.0, "square", outE[4], rgb_t, w=m, norm="weight")                  # :1828-1832
         if c["dist_static"] > 0 and it > 0:       # train.py:1841-1861
-            Ls.add(c["dist_static"] * (it / c["n_iters"]), "identity", distloss_rays(outE[7], oE[8].detach(), 1.0 / S))
+            Ls.add(self._coef(c["dist_static"], "ramp", it / c["n_iters"]), "identity",
+                   distloss_rays(outE[7], oE[8].detach(), 1.0 / S))
         if self.optimize_poses:
             self._pose_block(b, rays, oE, outE, poses, focal, c2w_all, grid, px, view, m, temp_disp_tv, temp_static, gt_depth,
                              to_depth, Ls)
@@ -638,10 +699,10 @@ class Trainer:
                         d_P[k - 2] = o
             batched = (rays_P, smp, coins, o_P, d_P)
         for k, (sgn, flow_t, mask_t) in enumerate(((1, b["flow_f"], b["mask_f"]), (-1, b["flow_b"], b["mask_b"]))):
-            pose_n = c2w_all[(view + sgn).clamp(0, T - 1)]                       # live: allposes_refine_f / _b
+            pose_n = gather_rows(c2w_all, (view + sgn).clamp(0, T - 1))         # live: allposes_refine_f / _b
             mm = mask_t * m
             ind_flow, ind_disp = induce_flow(H, W, focal, pose_n, weights_s, pts_ref_s, px, rays, ray_type=rt)
-            Ls.add(0.01 * temp_static, "abs", ind_flow, flow_t, w=mm, norm="weight")    # :1909-1941 (x 0.02 / 2)
+            Ls.add(self._coef(0.01, "temp_static", temp_static), "abs", ind_flow, flow_t, w=mm, norm="weight")    # :1909-1941 (x 0.02 / 2)
             # P1 / P2: the static field along the flow-displaced ray of the neighbour frame
             if batched:
                 rays_n, o, xyz = batched[0][k], batched[3][k], batched[1][k][0]
@@ -652,10 +713,14 @@ class Trainer:
                 PASSES.update(static=1, static_grad=1)
                 o = self.st(rays_n, ts, None, xyz, z, valid, is_train=True, ray_type=rt, rgb=self.dead_work)
             _, ind_disp_n = induce_flow(H, W, focal, pose_n, o[4], xyz, px, rays_n, ray_type=rt)
-            Ls.add(0.04 * temp_static, "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
+            Ls.add(self._coef(0.04, "temp_static", temp_static), "abs", ind_disp, ind_disp_n, w=mm, norm="weight")  # :2012-2017, 2079-2084
         # per-frame median-normalised monocular depth of the static field on the background rays
-        Ls.add(1.0, "identity", frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5,
-                                                 coef=c["monodepth_static"] * temp_static, dp=self._dp()))
+        if self._dyn is None:
+            Ls.add(1.0, "identity", frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5,
+                                                     coef=c["monodepth_static"] * temp_static, dp=self._dp()))
+        else:   # Temp_static multiplies the term's value instead of the kernel's coefficient (it changes every iteration)
+            Ls.add(self._coef(1.0, "temp_static", temp_static), "identity",
+                   frame_depth_loss(to_depth(depth_s), gt_depth, view, T, mask=fg < 0.5, coef=c["monodepth_static"], dp=self._dp()))
         # P3 / P4: disparity smoothness against the x+1 / y+1 pixel neighbours (train.py:2123-2311)
         inv_d = 1.0 / torch.clamp(depth_s, min=1e-6)
         for k, uv_n in enumerate(uv_P34):
@@ -681,10 +746,37 @@ class Trainer:
         if shard is not None and self.dp_exact_stats:
             # the exact-statistics exchange all-gathers the per-ray depths with all_gather_into_tensor: equal shards only
             require_even_shards(self.cfg["batch_size"], shard[1])
+        if self.graph:
+            if (shard is not None and shard[1] > 1) or self.opt.ex.active:
+                raise RuntimeError("Trainer(graph=True) is the single-process path: the gradient exchange of a data-parallel run "
+                                   "overlaps the backward phases, which a captured iteration cannot expose")
+            return self._step_graph()
         b = self.data.make_batch(self.it, self.cfg["batch_size"], shard)
-        loss_d, loss_s = self.losses(b)
+        loss_d, loss_s = self._forward_backward(b, tv_between=True)
+        return (loss_d + loss_s).detach()
+
+    def _tv_weights(self):
+        # TV_weight_density / TV_weight_app are multiplied by lr_factor every iteration BEFORE use (train.py:1734-1750;
+        # the static terms of the same iteration use the decayed value, :1872-1885)
         c = self.cfg
-        tv = c["tv_density"] > 0 or c["tv_app"] > 0
+        return c["tv_density"] * self.lr_factor ** (self.it + 1), c["tv_app"] * self.lr_factor ** (self.it + 1)
+
+    def _tv(self, which):
+        c = self.cfg
+        if not (c["tv_density"] > 0 or c["tv_app"] > 0):
+            return
+        tv_d, tv_a = self._tv_weights()
+        st, dy = self.st, self.dy
+        if which == 0:
+            self.tv.accumulate_grad_(st, [(st.density_plane, st.density_line), (st.app_plane, st.app_line)], [tv_d, tv_a])
+        else:
+            self.tv.accumulate_grad_(dy, [(dy.density_plane, dy.density_line), (dy.blending_plane, dy.blending_line),
+                                          (dy.app_plane, dy.app_line)], [tv_d, tv_d, tv_a])
+
+    def _forward_backward(self, b, tv_between):
+        """losses + both backward phases on batch b.  tv_between: the TV gradients and the start of each field's gradient
+        exchange sit between the phases (the eager order); a captured iteration leaves them to the caller."""
+        loss_d, loss_s = self.losses(b)
         self.opt.zero_grad()
         if self.optimize_poses:
             self.poses.grad = None
@@ -692,21 +784,87 @@ class Trainer:
         st, dy = self.st, self.dy
         loss_s.backward()
         st.det_fold_()   # RDRF_DETERMINISTIC=1: fixed-point shadow -> fp32 gradients (no-op in the product build)
-        # TV_weight_density / TV_weight_app are multiplied by lr_factor every iteration BEFORE use (train.py:1734-1750;
-        # the static terms of the same iteration use the decayed value, :1872-1885)
-        tv_d, tv_a = (c["tv_density"] * self.lr_factor ** (self.it + 1), c["tv_app"] * self.lr_factor ** (self.it + 1))
-        if tv:
-            self.tv.accumulate_grad_(st, [(st.density_plane, st.density_line), (st.app_plane, st.app_line)],
-                                     [tv_d, tv_a])
-        self.opt.begin_exchange(0)           # static field: complete
+        if tv_between:
+            self._tv(0)
+            self.opt.begin_exchange(0)           # static field: complete
         loss_d.backward()
         dy.det_fold_()
-        if tv:
-            self.tv.accumulate_grad_(dy, [(dy.density_plane, dy.density_line), (dy.blending_plane, dy.blending_line),
-                                          (dy.app_plane, dy.app_line)], [tv_d, tv_d, tv_a])
-        self.opt.begin_exchange(1)
+        if tv_between:
+            self._tv(1)
+            self.opt.begin_exchange(1)
         self.last = dict(loss_dynamic=loss_d.detach(), loss_static=loss_s.detach())
-        return (loss_d + loss_s).detach()
+        return loss_d, loss_s
+
+    # ---- captured iteration (graph=True) -----------------------------------------------------------
+    def _graph_key(self):
+        """everything of an iteration that is baked into the captured launches: shapes, gates, step-function weights"""
+        c, it = self.cfg, self.it
+        ups = c.get("upsamp_list", [0, 0, 0, 0])
+        return (tuple(c["grid"]), c["n_samples"], c["batch_size"], it // 100000, it // 50000, it >= ups[0], it >= ups[3],
+                c["dist_dynamic"] * it > 0, c["dist_static"] > 0 and it > 0, self.dead_work, self.batch_passes,
+                self.opt.state[0]["g"].data_ptr(), self.opt.state[1]["g"].data_ptr())
+
+    def _graph_inputs(self):
+        """refresh the static inputs of the iteration about to run: ray indices, draws, iteration scalars (6 launches)"""
+        c, it, gs = self.cfg, self.it, self._gs
+        bs = c["batch_size"]
+        gs["ids"][0].copy_(self.data.batch(it, bs, 0))
+        gs["ids"][1].copy_(self.data.batch(it, bs, 1))
+        self.rng.begin()
+        self._dyn["ramp"].fill_(it / c["n_iters"])
+        self._dyn["temp_static"].fill_(1.0 / (10 ** (it / 100000.0)))
+
+    def _step_graph(self):
+        from . import _lib as L
+        if L.DETERMINISTIC:
+            raise RuntimeError("Trainer(graph=True): the deterministic build rebinds its shadow buffers from the host every launch")
+        dev, bs = self.device, self.cfg["batch_size"]
+        if self._gs is None:
+            self._gs = dict(ids=(torch.zeros(bs, dtype=torch.long, device=dev), torch.zeros(bs, dtype=torch.long, device=dev)),
+                            stream=torch.cuda.Stream(dev))
+            scal = torch.zeros(2, device=dev)
+            self._dyn = dict(ramp=scal[0:1], temp_static=scal[1:2])
+            if not isinstance(self.rng, GraphRng):
+                self.rng = GraphRng(dev)
+        gs = self._gs
+        key = self._graph_key()
+        self._graph_inputs()
+        body = lambda: self._forward_backward(self.data.make_batch(self.it, bs, ids=gs["ids"]), tv_between=False)
+        entry = self._graphs.get(key)
+        if entry is None and self._graph_seen != key:
+            # first iteration of this shape / gate combination: eager on the static inputs (the warm-up of every launch path
+            # a capture needs: lazily sized workspaces, packed weight images, function attributes)
+            self._graph_seen = key
+            loss_d, loss_s = body()
+            total = (loss_d + loss_s).detach()
+        else:
+            if entry is None:
+                before = collections.Counter(PASSES)
+                # nothing may keep the previous iteration's autograd graph alive: the AccumulateGrad nodes of the pose table
+                # and the field of view would be reused, and they belong to the stream they were created on -- the engine
+                # would then tie that stream into the capture (torch.cuda.graph collects garbage on entry)
+                self.terms, self.last = None, {}
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=gs["stream"]):
+                    loss_d, loss_s = body()
+                    total = (loss_d + loss_s).detach()
+                del loss_d, loss_s
+                delta = collections.Counter(PASSES)
+                delta.subtract(before)
+                PASSES.subtract(delta)   # a capture enqueues nothing: the replay below counts its passes
+                # per-term values only (static memory): the LossTerms objects hold the captured autograd graph
+                terms = tuple(types.SimpleNamespace(values=t.values) for t in self.terms)
+                entry = dict(graph=g, total=total, last=self.last, terms=terms, passes=delta,
+                             pose_grads=(self.poses.grad, self.fov.grad) if self.optimize_poses else None)
+                self._graphs[key] = entry
+            if self.optimize_poses:   # the gradient tensors the captured backward writes
+                self.poses.grad, self.fov.grad = entry["pose_grads"]
+            entry["graph"].replay()
+            PASSES.update(entry["passes"])
+            self.last, self.terms, total = entry["last"], entry["terms"], entry["total"]
+        self._tv(0)
+        self._tv(1)
+        return total
 
     def finish_step(self):
         if self.optimize_poses:
@@ -736,6 +894,7 @@ class Trainer:
         if n_samples is not None:
             self.cfg["n_samples"] = int(n_samples)
         self.opt.rebuild(iteration=self.it)
+        self._graphs, self._graph_seen = {}, None   # captured iterations hold the old factor tensors
         if self.optimize_poses and self.opt.lr_upsample_reset:
             self.opt_pose.param_groups[0]["lr"] = self.lr_pose
             if self.it >= self.cfg.get("upsamp_list", [0, 0, 0, 0])[3]:

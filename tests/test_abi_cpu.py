@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L.lib, sym), f"librodynrf.so does not export {sym}"
     assert set(L.SYMBOLS) == declared
-    assert L.lib.rdrf_abi_version() == L.ABI_VERSION == 5
+    assert L.lib.rdrf_abi_version() == L.ABI_VERSION == 6
 
 
 def test_state_dict_contract_and_layout():

@@ -1,5 +1,6 @@
 """Induced flow / disparity (renderer.py:1266-1392) through the C ABI against the
 vectors generated from the reference and against the oracle at the benchmark shape."""
+import importlib
 import os
 
 import numpy as np
@@ -115,3 +116,25 @@ def test_distortion_loss_vs_bruteforce(N, S):
     with pytest.raises(NotImplementedError):
         rodynrf.flatten_eff_distloss(w.cuda().reshape(-1), m.cuda().reshape(-1), 1.0 / S,
                                      torch.zeros(N * S, dtype=torch.long, device="cuda") + (N - 1))
+
+
+@pytest.mark.parametrize("T,N", [(12, 4096), (50, 8192), (1000, 3000)])
+def test_gather_rows_backward_matches_torch_index_backward(T, N):
+    """ray_utils.gather_rows (the [T,3,4] camera matrices of the neighbour frames, train.py:1895-1948): forward = table[idx]
+    bit for bit, backward (rdrf_rows_scatter_add: LDS accumulation per workgroup; the 1000-row table takes the global-atomic
+    fallback) against torch's index backward."""
+    RU = importlib.import_module("robust-dynrf_amd.ray_utils")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    table = torch.randn(T, 3, 4, generator=g).to(dev)
+    idx = torch.randint(0, T, (N,), generator=g).to(dev)
+    go = torch.randn(N, 3, 4, generator=g).to(dev)
+    t1 = table.clone().requires_grad_(True)
+    t2 = table.clone().requires_grad_(True)
+    o1 = RU.gather_rows(t1, idx)
+    o2 = t2[idx]
+    assert torch.equal(o1, o2)
+    o1.backward(go)
+    o2.backward(go)
+    assert_close(t1.grad, t2.grad, "gather_rows backward", rtol=1e-5)
+    assert torch.equal(RU.gather_rows(table, idx), table[idx])   # no grad: plain indexing

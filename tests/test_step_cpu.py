@@ -118,3 +118,36 @@ def test_resolution_schedule_matches_the_reference_formulas():
         reso = O.N_to_reso(n, aabb)
         assert cfg["grid"] == reso and cfg["n_samples"] == O.cal_n_samples(reso, 2.0), (stage, reso)
         assert cfg["start_iteration"] == (0 if stage == "stage0" else first)
+
+
+def test_graph_rng_hands_out_the_same_static_slices_every_iteration():
+    """GraphRng (Trainer(graph=True)): the draws of an iteration are fixed slices of static memory -- the same storage at
+    capture and at every replay -- refilled by begin(); coins are one-element fp32 tensors holding 0 or 1; frozen keeps
+    the contents (tests replay fixed draws)."""
+    S_ = importlib.import_module("robust-dynrf_amd.step")
+    dev = torch.device("cpu")
+    r = S_.GraphRng(dev, pool_floats=4096)
+    seen = []
+    for it in range(3):
+        r.begin()
+        j = r.jitter(115, "ndc", dev)[0]
+        c0, c1 = r.coin(), r.coin()
+        jo = r.jitter(221, "contract", dev)
+        seen.append((j.data_ptr(), c0.data_ptr(), c1.data_ptr(), jo[0].data_ptr(), jo[1].data_ptr(), j.clone(), float(c0), float(c1)))
+        assert j.shape == (115,) and c0.shape == (1,) and c0.dtype == torch.float32
+        assert float(c0) in (0.0, 1.0) and float(c1) in (0.0, 1.0)
+        assert j.data_ptr() == r.pool[64:].data_ptr()           # the coins' source (pool head) is not handed out as jitter
+        assert jo[0].shape[0] == 221 - 221 // 2 + 1 and jo[1].shape[0] == 221 // 2 + 1
+        assert torch.equal(r.coins, torch.round(r.pool[:r.N_COINS]))
+    assert all(s[:5] == seen[0][:5] for s in seen)             # same addresses every iteration
+    assert not torch.equal(seen[0][5], seen[1][5])             # fresh values
+    r.frozen = True
+    before = r.pool.clone()
+    r.begin()
+    assert torch.equal(r.pool, before)
+    import pytest
+    with pytest.raises(RuntimeError):
+        for _ in range(r.N_COINS + 1):
+            r.coin()
+    with pytest.raises(RuntimeError):
+        r._take(1 << 20, dev)
