@@ -648,7 +648,7 @@ def compact_line(out):
         line["cpu_baseline_4096_value"] = _num(out["cpu_baseline_4096"]["value"])
     for k in ("final_stage_value", "final_stage_ms_per_step", "final_stage_frac_of_fp32_mfma_peak", "schedule_weighted_value",
               "liveness_exploited_value", "render_mpix_per_s", "render_final_stage_mpix_per_s", "render_chunk512_mpix_per_s",
-              "step_frac_of_fp32_mfma_peak", "hbm_roofline_640"):
+              "step_frac_of_fp32_mfma_peak", "s13_stage_eager_ms_per_step", "s13_stage_graph_ms_per_step", "hbm_roofline_640"):
         if k in out:
             line[k] = _num(out[k]) if not isinstance(out[k], dict) else {a: _num(b) for a, b in out[k].items()}
     line["detail"] = "bench_detail.json"
@@ -718,6 +718,8 @@ def main():
                     help="Trainer(graph=True): batch gather, forward passes and both backward phases of an iteration captured once "
                          "as a HIP graph and replayed (single process; for the launch-bound S = 13 stages of Nvidia_no_poses.txt / "
                          "DAVIS.txt).  Implies --no-roofline: the per-kernel HIP events cannot be recorded inside a capture")
+    ap.add_argument("--no-graph-leg", action="store_true",
+                    help="skip the launch-bound-stage leg (nvidia_no_poses stage 0, eager against Trainer(graph=True))")
     ap.add_argument("--exploit-liveness", action="store_true",
                     help="skip the work whose results nothing consumes (SURVEY 3.1 liveness table): the dynamic-field forward of "
                          "passes E / P3 / P4 and the colours of both fields in passes B-D / P1-P4; by default it is executed like "
@@ -899,6 +901,24 @@ def main():
             "note": "rays of a whole 100000-iteration Nvidia.txt run / its time: every stage of the resolution schedule measured "
                     "at its own grid and sample count from reference-initialised weights (stage 0 = the headline window; up1-up3 "
                     "8 timed steps after 3; final = the final_stage leg), weighted by its share of the iterations"}
+    if (rank == 0 and world == 1 and not args.no_graph_leg and not args.graph and not trainer.opt.ex.active
+            and args.config == "nvidia" and args.stage == "stage0"):
+        # the launch-bound coarse stage of configs[2] (configs/Nvidia_no_poses.txt: grid [17,19,11], S = 13, the first 2000
+        # iterations; 7 dynamic + 9 static passes with pose / focal optimisation): one iteration enqueued launch by launch from
+        # Python against the same iteration captured once as a HIP graph and replayed (Trainer(graph=True))
+        cfg_c = S_.scene_config("nvidia_no_poses", "stage0")
+        leg = {"config": "nvidia_no_poses", "stage": "stage0", "grid": cfg_c["grid"], "samples_per_ray": cfg_c["n_samples"],
+               "rays": cfg_c["batch_size"], "steps": 30, "warmup": 6}
+        for mode in ("eager", "graph"):
+            tr_c = S_.Trainer(dict(cfg_c), dev, weights=args.weights, dead_work=not args.exploit_liveness, graph=mode == "graph")
+            dtc, _ = timed_steps(tr_c, None, 30, 6, 1, dev)
+            leg[mode + "_ms_per_step"] = dtc * 1e3
+            leg[mode + "_rays_per_s"] = cfg_c["batch_size"] / dtc
+            if mode == "graph":
+                leg["graphs_captured"] = len(tr_c._graphs)
+            del tr_c
+            torch.cuda.empty_cache()
+        out["launch_bound_stage"] = leg
     if rank == 0 and world == 1 and not args.no_sparse and args.weights == "dense":
         # SURVEY 8d W-sparse: the same step / render with trained-scene-like occupancy (app mask ~0.10 in both fields)
         tr_s = S_.Trainer(dict(cfg), dev, weights="sparse", dead_work=not args.exploit_liveness)
@@ -929,6 +949,9 @@ def main():
         if "render" in out:
             out["render_mpix_per_s"] = out["render"]["value"]
             out["render_chunk512_mpix_per_s"] = out["render_chunk512"]["value"]
+        if "launch_bound_stage" in out:
+            out["s13_stage_eager_ms_per_step"] = out["launch_bound_stage"]["eager_ms_per_step"]
+            out["s13_stage_graph_ms_per_step"] = out["launch_bound_stage"]["graph_ms_per_step"]
         if "roofline" in out:
             out["step_frac_of_fp32_mfma_peak"] = out["roofline"]["frac"]
         if "final_stage" in out:

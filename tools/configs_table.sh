@@ -2,10 +2,10 @@
 # ms/iteration and rays/s of the other shipped configs: tools/configs_table.sh
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
-for cfg in "nvidia_no_poses stage0" "nvidia_no_poses final" "davis stage0" "davis final"; do
+for cfg in "nvidia_no_poses stage0" "nvidia_no_poses stage0 --graph" "nvidia_no_poses final" "davis stage0" "davis stage0 --graph" "davis final"; do
   set -- $cfg
-  timeout 400 python bench.py --full-line --config $1 --stage $2 --steps 20 --warmup 3 --no-cpu-baseline --no-final-stage --no-render --no-sparse --no-roofline 2>&1 | tail -1 > gpurun_out/cfgt.log
-  python - "$1" "$2" <<'PY'
+  timeout 400 python bench.py --full-line --config $1 --stage $2 $3 --steps 20 --warmup 3 --no-cpu-baseline --no-final-stage --no-render --no-sparse --no-roofline 2>&1 | tail -1 > gpurun_out/cfgt.log
+  python - "$1" "$2$3" <<'PY'
 import json, sys
 try:
     d = json.loads(open("gpurun_out/cfgt.log").read().strip().splitlines()[-1])

@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out
 ROOT=$PWD
 for c in nvidia_no_poses davis; do
   RAW=/tmp/raw_s13_$c; rm -rf $RAW; mkdir -p $RAW
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o t -- python $ROOT/bench.py --config $c --stage stage0 --steps 40 --warmup 6 --no-cpu-baseline --no-roofline --no-sparse --no-final-stage --no-render --no-liveness-leg > $OUT/s13_$c.log 2>&1 )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o t -- python $ROOT/bench.py --config $c --stage stage0 --steps 40 --warmup 6 --no-cpu-baseline --no-roofline --no-sparse --no-final-stage --no-render --no-liveness-leg ${S13_EXTRA} > $OUT/s13_$c.log 2>&1 )
   cp $(find $RAW -name "*kernel_stats.csv" | head -1) gpurun_out/s13_${c}_kernel_stats.csv
   python - gpurun_out/s13_${c}_kernel_stats.csv 46 <<'PY'
 import csv, sys
