@@ -241,6 +241,87 @@ RDRF_D void mfma_seg(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __r
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32-grade layer segment on the BF16 matrix pipe (round 6).  x = xh + xm + xl: three bf16 pieces, 8 + 8 + 8 significand
+// bits -- the whole fp32 significand, exact by truncation -- and
+//     W x  ~=  Wl xh + Wh xl + Wm xm + Wm xh + Wh xm + Wh xh           (the six products above 2^-24 relative)
+// on v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD for K = 16, i.e. 192 cycles for the six against 8 x 64 = 512 for the same K on
+// v_mfma_f32_32x32x2_f32.  Activations are split in registers right before their MFMAs -- 44 VALU instructions per K = 16
+// step that issue in the gaps of the twelve MFMAs of the step (tools/micro/bf16x3_layer.hip: 4164 cycles per 160 -> 64 layer and
+// wave against 10 444 for mfma_seg, error 2.1e-7 of sum |w x| against 2.7e-7) --, weights arrive pre-split from the pack
+// kernel: [NBO][KK/8][3 pieces][64 lanes][4 dwords] = one ds_read_b128 per piece (1.5 x the fp32 bytes, which is why only the
+// layers whose image still fits the 160 KB LDS take this form).  The C/D layout of the instruction is that of 32x32x2, and a
+// lane's eight consecutive `in` slots are its eight K values of the step, so the canonical activation layout is unchanged.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+RDRF_HD int pk_b3_size(int nbo, int kk) { return nbo * kk * 96; }
+// hi = the top 16 bits of x; r = x - hi (exact); mid = the top 16 bits of r; lo = r - mid (the instruction reads its top 16 bits)
+RDRF_D void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(hi);
+  mid = __float_as_uint(r) & 0xffff0000u;
+  lo = __float_as_uint(r - __uint_as_float(mid));
+}
+RDRF_D unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (a >> 16) | (b & 0xffff0000)
+template <int NBO, int KK>
+RDRF_D void mfma_seg_b3(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __restrict__ wpf, int lane) {
+  static_assert(KK % 8 == 0, "one K = 16 step takes eight slots per lane half");
+  constexpr int K8 = KK / 8;
+  const unsigned* __restrict__ wp = reinterpret_cast<const unsigned*>(wpf);
+#pragma unroll
+  for (int k8 = 0; k8 < K8; ++k8) {
+    // the step's weight pieces are requested first: the ~44 VALU instructions of the split below cover the LDS latency, so no
+    // step-ahead copy of the fragments is kept (24 registers at NBO = 2).  The scheduling barriers stop hipcc from hoisting
+    // every split of the fully unrolled layer to the top (148 spilled registers in the microbenchmark).
+    // NO inline asm in this function: hipcc counts an `asm` statement as an instruction when it pads the VALU-write ->
+    // MFMA-read wait states, an empty one (used to defeat common-subexpression elimination) left the last piece register
+    // short of them -- one sample in ~15 000 came out with a stale lo piece (tools/graph/det_fwd.py).
+    u32x4 wc[NBO][3];
+#pragma unroll
+    for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wc[nb][p] = *(const u32x4*)(wp + ((size_t)((nb * K8 + k8) * 3 + p) * 64 + lane) * 4);
+    // The loads stay FIRST after the previous step's MFMAs: the split below reuses the registers of the previous step's pieces,
+    // and a v_sub_f32 that overwrote the B operand two instructions after the last MFMA of the step (the fused render kernel's
+    // schedule) gave one ray in ~700 a stale piece, run to run -- a write-after-read window on the 4-register operands of
+    // v_mfma_f32_32x32x16_bf16 that hipcc does not pad.  3 NBO ds_read_b128 issue slots sit between the two now.
+    __builtin_amdgcn_sched_barrier(0);
+    // Split in three sweeps -- hi pieces, mid pieces, lo pieces -- and consume them in that order: the MFMAs that read a
+    // piece then sit as far behind the VALU instructions that wrote it as the step allows.  With the lo pieces packed last
+    // and read by the THIRD MFMA of the step (small terms first), the fused render kernel returned a stale lo piece for one
+    // ray in a few hundred, run to run (tools/graph/fused_diff.py; a full s_waitcnt before the MFMAs did not change it, the
+    // order below did: 80 of 80 runs identical): independent MFMAs issue a few cycles apart, and hipcc's wait-state
+    // accounting between a v_perm_b32 and the MFMA that reads its result does not hold across them.
+    unsigned hi[8], r1[8], mid[8];
+    u32x4 bh, bm, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = __float_as_uint(in[k8 * 8 + e]) & 0xffff0000u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bh[q] = pack_hi16(hi[2 * q], hi[2 * q + 1]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r1[e] = __float_as_uint(in[k8 * 8 + e] - __uint_as_float(hi[e]));   // exact
+      mid[e] = r1[e] & 0xffff0000u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bm[q] = pack_hi16(mid[2 * q], mid[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)   // the instruction reads the top 16 bits of r1 - mid
+      bl[q] = pack_hi16(__float_as_uint(__uint_as_float(r1[2 * q]) - __uint_as_float(mid[2 * q])),
+                        __float_as_uint(__uint_as_float(r1[2 * q + 1]) - __uint_as_float(mid[2 * q + 1])));
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xm = __builtin_bit_cast(bf16x8, bm), xl = __builtin_bit_cast(bf16x8, bl);
+    __builtin_amdgcn_sched_barrier(0);
+    // consecutive MFMAs alternate between the accumulators; pieces in the order they were produced (hi, mid, lo last)
+#define RDRF_B3_STEP(WP, XP)                                                                                              \
+    _Pragma("unroll") for (int nb = 0; nb < NBO; ++nb)                                                                    \
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wc[nb][WP]), XP, acc[nb], 0, 0, 0);
+    RDRF_B3_STEP(0, xh) RDRF_B3_STEP(1, xh) RDRF_B3_STEP(2, xh) RDRF_B3_STEP(0, xm) RDRF_B3_STEP(1, xm) RDRF_B3_STEP(0, xl)
+#undef RDRF_B3_STEP
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // accumulator init from a PACKED bias ([2 halves][NBO*16] in canonical order; nullptr = zero)
 template <int NBO>
 RDRF_D void acc_bias(f32x16 (&acc)[NBO], const float* __restrict__ bpk, int h) {
@@ -843,6 +924,7 @@ constexpr int K1_W3_X0 = 0;                                   // 2 x 32
 constexpr int K1_W3_T = K1_W3_X0 + 2 * 32 * 64;               // 2 x 16
 constexpr int K1_W4 = K1_W3_T + 2 * 16 * 64;                  // 2 x 32
 constexpr int K1_W5 = K1_W4 + 2 * 32 * 64;                    // small 3 x 32
+#ifdef RDRF_HEADS_F32   // A/B builds (tools/build_variant.sh): the heads' first layers on the fp32 matrix pipe, as up to round 5
 constexpr int K1_DEN1_F = K1_W5 + 3 * 2 * 32;                 // 2 x 36
 constexpr int K1_DEN1_X0 = K1_DEN1_F + 2 * 36 * 64;           // 2 x 32
 constexpr int K1_DEN1_X1 = K1_DEN1_X0 + 2 * 32 * 64;          // 2 x 8
@@ -851,6 +933,18 @@ constexpr int K1_BLE1_F = K1_DEN2 + 1 * 2 * 32;
 constexpr int K1_BLE1_X0 = K1_BLE1_F + 2 * 36 * 64;
 constexpr int K1_BLE1_X1 = K1_BLE1_X0 + 2 * 32 * 64;
 constexpr int K1_BLE2 = K1_BLE1_X1 + 2 * 8 * 64;
+#else
+// the heads' first layers (152 -> 64 each, two thirds of the kernel's matrix work) as bf16 x 3 fragments (mfma_seg_b3): slots
+// 0..35 = the 72 VM features, 36..67 = X0, 68..71 = X1[0..3] -> nine K = 16 steps; X1[4..7] stays an fp32 segment (a tenth
+// step would be half padding, and 2 x 80 x 96 dwords per head would not fit the LDS next to the warp MLP)
+constexpr int K1_HEAD_KK = 72;
+constexpr int K1_DEN1 = K1_W5 + 3 * 2 * 32;                   // b3 2 x 72
+constexpr int K1_DEN1_X1T = K1_DEN1 + 2 * K1_HEAD_KK * 96;    // fp32 2 x 4
+constexpr int K1_DEN2 = K1_DEN1_X1T + 2 * 4 * 64;             // small 1 x 32
+constexpr int K1_BLE1 = K1_DEN2 + 1 * 2 * 32;
+constexpr int K1_BLE1_X1T = K1_BLE1 + 2 * K1_HEAD_KK * 96;
+constexpr int K1_BLE2 = K1_BLE1_X1T + 2 * 4 * 64;
+#endif
 constexpr int K1_B3 = K1_BLE2 + 1 * 2 * 32;                   // biases [2][32]
 constexpr int K1_B4 = K1_B3 + 64;
 constexpr int K1_BD1 = K1_B4 + 64;
@@ -912,10 +1006,12 @@ struct PackJob {
   const float* src;  // natural [out_dim][ld]
   int ld, out_dim, in_dim;
   int seg;    // SegId of the input segment
-  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias
+  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 = bf16 x 3 MFMA forward
   int nb;     // NBO (mode 0) / OUT (mode 1) / NBI (mode 2)
   int kk;     // k-steps of the segment (mode 0/1) or of the OUT dimension (mode 2)
   int dst;    // float offset into the pack buffer
+  int seg_kk0;  // modes 0 / 7: first slot of the segment this job covers (a segment may be cut between two images)
+  int kk_off, kk_tot;   // mode 7 (bf16 x 3 fragments): the job's first slot inside the image, the image's slots per lane half
 };
 #define RDRF_MAX_PACK_JOBS 48
 struct PackJobs {

@@ -160,13 +160,24 @@ void dyn_pack_jobs_fwd(PackJobs& J, const RdrfDynamicParams* P) {
   pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, 0, 2, 16, k1 + K1_W3_T);
   pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, 0, 2, 32, k1 + K1_W4);
   pack_add(J, P->l5w, 64, 3, 64, SEG_IDENT, 1, 3, 32, k1 + K1_W5);
+#ifdef RDRF_HEADS_F32
   pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, 0, 2, 36, k1 + K1_DEN1_F);
   pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, 0, 2, 32, k1 + K1_DEN1_X0);
   pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X1, 0, 2, 8, k1 + K1_DEN1_X1);
-  pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_DEN2);
   pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, 0, 2, 36, k1 + K1_BLE1_F);
   pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, 0, 2, 32, k1 + K1_BLE1_X0);
   pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X1, 0, 2, 8, k1 + K1_BLE1_X1);
+#else
+  for (int head = 0; head < 2; ++head) {   // bf16 x 3 image [F 36 | X0 32 | X1 0..3] + the fp32 tail X1 4..7 (pk::K1_DEN1)
+    const float* w1 = head == 0 ? P->dw1 : P->bw1;
+    const int img = k1 + (head == 0 ? K1_DEN1 : K1_BLE1), tail = k1 + (head == 0 ? K1_DEN1_X1T : K1_BLE1_X1T);
+    pack_add_b3(J, w1, 152, 64, 72, SEG_IDENT, 2, 36, 0, 0, K1_HEAD_KK, img);
+    pack_add_b3(J, w1, 152, 64, 152, SEG_DEN1_X0, 2, 32, 0, 36, K1_HEAD_KK, img);
+    pack_add_b3(J, w1, 152, 64, 152, SEG_DEN1_X1, 2, 4, 0, 68, K1_HEAD_KK, img);
+    pack_add_from(J, w1, 152, 64, 152, SEG_DEN1_X1, 2, 4, 4, tail);
+  }
+#endif
+  pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_DEN2);
   pack_add(J, P->bw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, k1 + K1_BLE2);
   pack_add(J, P->l3b, 0, 64, 0, 0, 3, 0, 32, k1 + K1_B3);
   pack_add(J, P->l4b, 0, 64, 0, 0, 3, 0, 32, k1 + K1_B4);

@@ -412,6 +412,24 @@ RDRF_D void static_app16_body(const FieldArgs a, const StaticW w) {
   }
 }
 
+#ifndef RDRF_HEADS_F32
+// first layer of the density / blending head (152 -> 64) on the bf16 matrix pipe: [features 36 | X0 32 | X1 0..3] as nine
+// K = 16 steps of mfma_seg_b3, X1[4..7] as an fp32 segment (pk::K1_DEN1)
+RDRF_D void head_layer1(f32x16 (&acc)[2], const float (&Fv)[36], const float (&X0)[32], const float (&X1)[8],
+                        const float* __restrict__ wb3, const float* __restrict__ wtail, int lane) {
+  float U[pk::K1_HEAD_KK];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) U[i] = Fv[i];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) U[36 + i] = X0[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) U[68 + i] = X1[i];
+  mfma_seg_b3<2, pk::K1_HEAD_KK>(acc, U, wb3, lane);
+  const float V[4] = {X1[4], X1[5], X1[6], X1[7]};
+  mfma_seg<2, 4>(acc, V, wtail, lane);
+}
+#endif
+
 // FLAT (inference only): the unit of work is a 32-sample tile of the flattened [N * S] sample array instead of a ray, so a
 // 512-ray eval chunk is 1840 tiles for the 2048 resident waves instead of 512 rays, and no tile is padded to the ray's
 // end (S = 115: 3.6 tiles per ray instead of 4).  The per-ray constants (time, tout, PE8(t)) are fetched per lane through
@@ -527,9 +545,13 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
       }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BD1, h);
+#ifdef RDRF_HEADS_F32
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_DEN1_F, lane);
       mfma_seg<2, 32>(acc, X0, pkw + pk::K1_DEN1_X0, lane);
       mfma_seg<2, 8>(acc, X1, pkw + pk::K1_DEN1_X1, lane);
+#else
+      head_layer1(acc, Fv, X0, X1, pkw + pk::K1_DEN1, pkw + pk::K1_DEN1_X1T, lane);
+#endif
       float Hd[32];
       acc_relu<2>(Hd, acc);
       save_rows<36>(svb, sv::K1_FD, Fv, s, h);
@@ -547,9 +569,13 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
       }
       f32x16 acc[2];
       acc_bias<2>(acc, pkw + pk::K1_BB1, h);
+#ifdef RDRF_HEADS_F32
       mfma_seg<2, 36>(acc, Fv, pkw + pk::K1_BLE1_F, lane);
       mfma_seg<2, 32>(acc, X0, pkw + pk::K1_BLE1_X0, lane);
       mfma_seg<2, 8>(acc, X1, pkw + pk::K1_BLE1_X1, lane);
+#else
+      head_layer1(acc, Fv, X0, X1, pkw + pk::K1_BLE1, pkw + pk::K1_BLE1_X1T, lane);
+#endif
       float Hd[32];
       acc_relu<2>(Hd, acc);
       save_rows<36>(svb, sv::K1_FB, Fv, s, h);

@@ -105,4 +105,7 @@ int rdrf_sort_ints_inplace(int* data, unsigned n, hipStream_t stream);   // dete
 // pack-job builders (rdrf_pack.hip)
 void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int mode,
               int nb, int kk, int dst);
+void pack_add_b3(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int kk_off,
+                 int kk_tot, int dst);
+void pack_add_from(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int dst);
 int pack_launch(const PackJobs& J, float* dst, hipStream_t stream);

@@ -128,7 +128,7 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
       float v = 0.f;
       if (J.mode == 0) {
         const int o = nb * 32 + li;
-        const int col = seg_imap(J.seg, elem_of(kk, h), J.in_dim);
+        const int col = seg_imap(J.seg, elem_of(kk + J.seg_kk0, h), J.in_dim);
         if (o < J.out_dim && col >= 0) v = J.src[(size_t)o * J.ld + col];
       } else {
         const int o = elem_of(kk, h);
@@ -136,6 +136,30 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
         if (o < J.out_dim && col >= 0) v = J.src[(size_t)o * J.ld + col];
       }
       dst[J.dst + i] = v;
+    }
+  } else if (J.mode == 7) {  // bf16 x 3 fragments (mfma_seg_b3): [nb][kk_tot/8][3 pieces][64 lanes][4 dwords]; this job fills the
+    // dwords of its slots kk_off .. kk_off + kk - 1 (two slots per dword: kk_off and kk are even)
+    const int pairs = J.kk >> 1, k8n = J.kk_tot >> 3;
+    const int total = J.nb * pairs * 3 * 64;
+    unsigned* out = reinterpret_cast<unsigned*>(dst) + J.dst;
+    for (int i = tid; i < total; i += stride) {
+      const int lane = i & 63;
+      int r = i >> 6;
+      const int p = r % 3; r /= 3;
+      const int pr = r % pairs, nb = r / pairs;
+      const int h = lane >> 5, o = nb * 32 + (lane & 31);
+      unsigned d = 0;
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int col = seg_imap(J.seg, elem_of(J.seg_kk0 + 2 * pr + e2, h), J.in_dim);
+        const float v = (o < J.out_dim && col >= 0) ? J.src[(size_t)o * J.ld + col] : 0.f;
+        unsigned ph, pm, pl;
+        split3(v, ph, pm, pl);
+        const unsigned piece = (p == 0 ? ph : (p == 1 ? pm : pl)) >> 16;
+        d |= piece << (16 * e2);
+      }
+      const int kk = J.kk_off + 2 * pr;
+      out[((size_t)((nb * k8n + (kk >> 3)) * 3 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
     }
   } else if (J.mode == 4) {  // 16x16x4 fragments: [nb][kk/2][64 lanes][2], lane = (g << 4) | neuron
     const int total = J.nb * J.kk * 64;
@@ -190,6 +214,23 @@ void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, in
   j.nb = nb;
   j.kk = kk;
   j.dst = dst;
+  j.seg_kk0 = 0;
+  j.kk_off = 0;
+  j.kk_tot = 0;
+}
+// one segment (slots seg_kk0 .. seg_kk0 + kk - 1 of `seg`) of a bf16 x 3 image of kk_tot slots, at slot kk_off of the image
+void pack_add_b3(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int kk_off,
+                 int kk_tot, int dst) {
+  pack_add(J, src, ld, out_dim, in_dim, seg, 7, nb, kk, dst);
+  PackJob& j = J.j[J.n - 1];
+  j.seg_kk0 = seg_kk0;
+  j.kk_off = kk_off;
+  j.kk_tot = kk_tot;
+}
+// an fp32 MFMA segment that starts at slot seg_kk0 of `seg`
+void pack_add_from(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int dst) {
+  pack_add(J, src, ld, out_dim, in_dim, seg, 0, nb, kk, dst);
+  J.j[J.n - 1].seg_kk0 = seg_kk0;
 }
 
 int pack_launch(const PackJobs& J, float* dst, hipStream_t stream) {

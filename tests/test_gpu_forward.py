@@ -345,3 +345,28 @@ def test_c_abi_error_paths():
     # the good path still works afterwards (no sticky error state)
     o = st(rays, ts, None, xyz, z, valid, ray_type="ndc")
     assert torch.isfinite(o[6]).all()
+
+
+@pytest.mark.parametrize("case,N,S", [("contract_relu_te", 2100, 37), ("ndc_relu", 777, 115)])
+def test_dynamic_forward_is_bit_reproducible(case, N, S):
+    """The forward kernels do no atomics: repeated calls must return the same bits, in the inference (flat-tile) and the
+    training (wave-per-ray, saved rows) instantiation.  Pins the operand hazards found when the heads' first layers moved to
+    the bf16 matrix pipe (rdrf_common.hpp mfma_seg_b3: an `asm` statement inside the split, and lo pieces consumed by the
+    third MFMA after the v_perm_b32 that packed them, each returned a stale piece for one sample in ~15 000, run to run)."""
+    import rodynrf
+    from _gpu_util import fields_from_case, make_rays
+    g, st, dy, _ = fields_from_case(case)
+    rt = str(g["meta.ray_type"])
+    rays, ts = (t.cuda() for t in make_rays(N, 3, rt))
+    xyz, z, valid = rodynrf.sampleXYZ(dy, rays, S, ray_type=rt, is_train=False)
+    for grad in (False, True):
+        ref = None
+        for rep in range(25):
+            with torch.set_grad_enabled(grad):
+                o = dy(rays, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
+            got = [o[k].detach().clone() for k in (2, 4, 6, 7)]   # blending, weight, rgb, sigma
+            if ref is None:
+                ref = got
+            else:
+                for a, b in zip(ref, got):
+                    assert torch.equal(a, b), (grad, rep)
