@@ -27,17 +27,32 @@ namespace pkb {
 // dynamic density phase, heads kernel image
 constexpr int K1H_DEN2 = 0;                           // small 1 x [2][32]
 constexpr int K1H_BLE2 = K1H_DEN2 + 64;
+#ifdef RDRF_HEADS_BWD_F32   // A/B builds: the transposed first layers of the heads on the fp32 matrix pipe
 constexpr int K1H_DEN1T_F = K1H_BLE2 + 64;            // NBI 3 x KK 32
 constexpr int K1H_DEN1T_X0 = K1H_DEN1T_F + 3 * 32 * 64;
 constexpr int K1H_BLE1T_F = K1H_DEN1T_X0 + 2 * 32 * 64;
 constexpr int K1H_BLE1T_X0 = K1H_BLE1T_F + 3 * 32 * 64;
 constexpr int K1H_SIZE = K1H_BLE1T_X0 + 2 * 32 * 64;
+#else                       // bf16 x 3 fragments (mfma_seg_b3_pair): 96 dwords per block and slot
+constexpr int K1H_DEN1T_F = K1H_BLE2 + 64;            // NBI 3 x KK 32
+constexpr int K1H_DEN1T_X0 = K1H_DEN1T_F + 3 * 32 * 96;
+constexpr int K1H_BLE1T_F = K1H_DEN1T_X0 + 2 * 32 * 96;
+constexpr int K1H_BLE1T_X0 = K1H_BLE1T_F + 3 * 32 * 96;
+constexpr int K1H_SIZE = K1H_BLE1T_X0 + 2 * 32 * 96;
+#endif
 // dynamic density phase, warp kernel image
 constexpr int K1W_W5 = 0;                             // small 3 x [2][32]
+#ifdef RDRF_HEADS_BWD_F32
 constexpr int K1W_W4T = K1W_W5 + 3 * 64;              // NBI 2 x KK 32
 constexpr int K1W_W3T_X0 = K1W_W4T + 2 * 32 * 64;     // NBI 2
 constexpr int K1W_W3T_T = K1W_W3T_X0 + 2 * 32 * 64;   // NBI 1
 constexpr int K1W_SIZE = K1W_W3T_T + 1 * 32 * 64;
+#else                       // bf16 x 3 fragments
+constexpr int K1W_W4T = K1W_W5 + 3 * 64;              // NBI 2 x KK 32
+constexpr int K1W_W3T_X0 = K1W_W4T + 2 * 32 * 96;     // NBI 2
+constexpr int K1W_W3T_T = K1W_W3T_X0 + 2 * 32 * 96;   // NBI 1
+constexpr int K1W_SIZE = K1W_W3T_T + 1 * 32 * 96;
+#endif
 // dynamic appearance phase
 constexpr int K3_RGBV = 0;                        // small 3 x [2][64]
 constexpr int K3_RGB2T = K3_RGBV + 3 * 128;       // NBI 4 x KK 64
@@ -1744,8 +1759,13 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
           }
           f32x16 accF[3];
           acc_zero<3>(accF);
+#ifdef RDRF_HEADS_BWD_F32
           mfma_seg<3, 32>(accF, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_F : pkb::K1H_BLE1T_F), lane);
           mfma_seg<2, 32>(accX, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_X0 : pkb::K1H_BLE1T_X0), lane);
+#else
+          mfma_seg_b3_pair<3, 2, 32>(accF, accX, dzh, lds + (head == 0 ? pkb::K1H_DEN1T_F : pkb::K1H_BLE1T_F),
+                                     lds + (head == 0 ? pkb::K1H_DEN1T_X0 : pkb::K1H_BLE1T_X0), lane);
+#endif
           float dFh[48];
           acc_copy<3>(dFh, accF);
           if (!FEAT && a.dfs != nullptr) {
@@ -1824,7 +1844,11 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
         {
           f32x16 acc[2];
           acc_zero<2>(acc);
+#ifdef RDRF_HEADS_BWD_F32
           mfma_seg<2, 32>(acc, dz4, lds + pkb::K1W_W4T, lane);
+#else
+          mfma_seg_b3<2, 32>(acc, dz4, lds + pkb::K1W_W4T, lane);
+#endif
           float H3[32];
           load_rows<32>(svb, sv::K1_H3, H3, s, h);
 #pragma unroll
@@ -1838,11 +1862,17 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_density_bwd(BwdArgs a, D
 #pragma unroll
           for (int kk = 0; kk < 32; ++kk) accX[kk >> 4][kk & 15] = dXh[kk];
         }
+#ifdef RDRF_HEADS_BWD_F32
         mfma_seg<2, 32>(accX, dz3, lds + pkb::K1W_W3T_X0, lane);
+#endif
         {
           f32x16 accT[1];
           acc_zero<1>(accT);
+#ifdef RDRF_HEADS_BWD_F32
           mfma_seg<1, 32>(accT, dz3, lds + pkb::K1W_W3T_T, lane);
+#else
+          mfma_seg_b3_pair<2, 1, 32>(accX, accT, dz3, lds + pkb::K1W_W3T_X0, lds + pkb::K1W_W3T_T, lane);
+#endif
 #pragma unroll
           for (int i = 0; i < 16; ++i) dTacc[i] += accT[0][i];
         }
@@ -2563,15 +2593,25 @@ static void dyn_pack_jobs_bwd(PackJobs& J, const RdrfDynamicParams* P) {
   J.n = 0;
   const int kh = REG_K1H, kw = REG_K1W, k3 = REG_K3, sf = REG_SF;
   pack_add(J, P->l5w, 64, 3, 64, SEG_IDENT, 1, 3, 32, kw + K1W_W5);
-  pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, 2, 2, 32, kw + K1W_W4T);
-  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_X0, 2, 2, 32, kw + K1W_W3T_X0);
-  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, 2, 1, 32, kw + K1W_W3T_T);
+#ifdef RDRF_HEADS_BWD_F32
+  const int wm = 2;
+#else
+  const int wm = 8;   // bf16 x 3 transposed fragments
+#endif
+  pack_add(J, P->l4w, 64, 64, 64, SEG_IDENT, wm, 2, 32, kw + K1W_W4T);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_X0, wm, 2, 32, kw + K1W_W3T_X0);
+  pack_add(J, P->l3w, 93, 64, 93, SEG_WARP3_T, wm, 1, 32, kw + K1W_W3T_T);
   pack_add(J, P->dw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, kh + K1H_DEN2);
   pack_add(J, P->bw2, 64, 1, 64, SEG_IDENT, 1, 1, 32, kh + K1H_BLE2);
-  pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, kh + K1H_DEN1T_F);
-  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, kh + K1H_DEN1T_X0);
-  pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, 2, 3, 32, kh + K1H_BLE1T_F);
-  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, 2, 2, 32, kh + K1H_BLE1T_X0);
+#ifdef RDRF_HEADS_BWD_F32
+  const int hm = 2;
+#else
+  const int hm = 8;   // bf16 x 3 transposed fragments
+#endif
+  pack_add(J, P->dw1, 152, 64, 72, SEG_IDENT, hm, 3, 32, kh + K1H_DEN1T_F);
+  pack_add(J, P->dw1, 152, 64, 152, SEG_DEN1_X0, hm, 2, 32, kh + K1H_DEN1T_X0);
+  pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, hm, 3, 32, kh + K1H_BLE1T_F);
+  pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, hm, 2, 32, kh + K1H_BLE1T_X0);
   pack_add(J, P->rwv, 131, 3, 128, SEG_IDENT, 1, 3, 64, k3 + K3_RGBV);
   pack_add(J, P->rw2, 128, 128, 128, SEG_IDENT, 2, 4, 64, k3 + K3_RGB2T);
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 2, 1, 64, k3 + K3_RGB1T_F);

@@ -322,6 +322,60 @@ RDRF_D void mfma_seg_b3(f32x16 (&acc)[NBO], const float (&in)[KK], const float* 
   }
 }
 
+// Two groups of output blocks that consume ONE input vector (the backward of a layer with two input segments: d(features) and
+// d(X0) from the same dz): the split of a step is done once, group A's MFMAs run while group B's weight pieces arrive.
+// Same rules as mfma_seg_b3: loads first, pieces produced and consumed in the order hi, mid, lo, no inline asm.
+template <int NA, int NB, int KK>
+RDRF_D void mfma_seg_b3_pair(f32x16 (&accA)[NA], f32x16 (&accB)[NB], const float (&in)[KK], const float* __restrict__ wpfA,
+                             const float* __restrict__ wpfB, int lane) {
+  static_assert(KK % 8 == 0, "one K = 16 step takes eight slots per lane half");
+  constexpr int K8 = KK / 8;
+  const unsigned* __restrict__ wpA = reinterpret_cast<const unsigned*>(wpfA);
+  const unsigned* __restrict__ wpB = reinterpret_cast<const unsigned*>(wpfB);
+#pragma unroll
+  for (int k8 = 0; k8 < K8; ++k8) {
+    u32x4 wa[NA][3], wb[NB][3];
+#pragma unroll
+    for (int nb = 0; nb < NA; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wa[nb][p] = *(const u32x4*)(wpA + ((size_t)((nb * K8 + k8) * 3 + p) * 64 + lane) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned hi[8], r1[8], mid[8];
+    u32x4 bh, bm, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = __float_as_uint(in[k8 * 8 + e]) & 0xffff0000u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bh[q] = pack_hi16(hi[2 * q], hi[2 * q + 1]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r1[e] = __float_as_uint(in[k8 * 8 + e] - __uint_as_float(hi[e]));
+      mid[e] = r1[e] & 0xffff0000u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bm[q] = pack_hi16(mid[2 * q], mid[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bl[q] = pack_hi16(__float_as_uint(__uint_as_float(r1[2 * q]) - __uint_as_float(mid[2 * q])),
+                        __float_as_uint(__uint_as_float(r1[2 * q + 1]) - __uint_as_float(mid[2 * q + 1])));
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xm = __builtin_bit_cast(bf16x8, bm), xl = __builtin_bit_cast(bf16x8, bl);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wb[nb][p] = *(const u32x4*)(wpB + ((size_t)((nb * K8 + k8) * 3 + p) * 64 + lane) * 4);
+#define RDRF_B3_STEP(ACC, W, N, WP, XP)                                                                                   \
+    _Pragma("unroll") for (int nb = 0; nb < N; ++nb)                                                                      \
+      ACC[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[nb][WP]), XP, ACC[nb], 0, 0, 0);
+    RDRF_B3_STEP(accA, wa, NA, 0, xh) RDRF_B3_STEP(accA, wa, NA, 1, xh) RDRF_B3_STEP(accA, wa, NA, 2, xh)
+    RDRF_B3_STEP(accA, wa, NA, 0, xm) RDRF_B3_STEP(accA, wa, NA, 1, xm) RDRF_B3_STEP(accA, wa, NA, 0, xl)
+    __builtin_amdgcn_sched_barrier(0);
+    RDRF_B3_STEP(accB, wb, NB, 0, xh) RDRF_B3_STEP(accB, wb, NB, 1, xh) RDRF_B3_STEP(accB, wb, NB, 2, xh)
+    RDRF_B3_STEP(accB, wb, NB, 0, xm) RDRF_B3_STEP(accB, wb, NB, 1, xm) RDRF_B3_STEP(accB, wb, NB, 0, xl)
+#undef RDRF_B3_STEP
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // accumulator init from a PACKED bias ([2 halves][NBO*16] in canonical order; nullptr = zero)
 template <int NBO>
 RDRF_D void acc_bias(f32x16 (&acc)[NBO], const float* __restrict__ bpk, int h) {
@@ -1006,7 +1060,7 @@ struct PackJob {
   const float* src;  // natural [out_dim][ld]
   int ld, out_dim, in_dim;
   int seg;    // SegId of the input segment
-  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 = bf16 x 3 MFMA forward
+  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 / 8 = bf16 x 3 MFMA forward / transposed
   int nb;     // NBO (mode 0) / OUT (mode 1) / NBI (mode 2)
   int kk;     // k-steps of the segment (mode 0/1) or of the OUT dimension (mode 2)
   int dst;    // float offset into the pack buffer

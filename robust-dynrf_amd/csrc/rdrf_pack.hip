@@ -161,6 +161,31 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
       const int kk = J.kk_off + 2 * pr;
       out[((size_t)((nb * k8n + (kk >> 3)) * 3 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
     }
+  } else if (J.mode == 8) {  // bf16 x 3 fragments of a TRANSPOSED layer (backward data, as mode 2): [nb][kk/8][3][64 lanes][4 dwords];
+    // K = the forward layer's outputs (slot kk of lane half h = neuron elem_of(kk, h)), rows = the segment's input elements
+    const int pairs = J.kk >> 1, k8n = J.kk >> 3;
+    const int total = J.nb * pairs * 3 * 64;
+    unsigned* out = reinterpret_cast<unsigned*>(dst) + J.dst;
+    for (int i = tid; i < total; i += stride) {
+      const int lane = i & 63;
+      int r = i >> 6;
+      const int p = r % 3; r /= 3;
+      const int pr = r % pairs, nb = r / pairs;
+      const int h = lane >> 5;
+      const int col = seg_imap(J.seg, nb * 32 + (lane & 31), J.in_dim);
+      unsigned d = 0;
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int o = elem_of(2 * pr + e2, h);
+        const float v = (o < J.out_dim && col >= 0) ? J.src[(size_t)o * J.ld + col] : 0.f;
+        unsigned ph, pm, pl;
+        split3(v, ph, pm, pl);
+        const unsigned piece = (p == 0 ? ph : (p == 1 ? pm : pl)) >> 16;
+        d |= piece << (16 * e2);
+      }
+      const int kk = 2 * pr;
+      out[((size_t)((nb * k8n + (kk >> 3)) * 3 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
+    }
   } else if (J.mode == 4) {  // 16x16x4 fragments: [nb][kk/2][64 lanes][2], lane = (g << 4) | neuron
     const int total = J.nb * J.kk * 64;
     const int k2n = J.kk >> 1;
