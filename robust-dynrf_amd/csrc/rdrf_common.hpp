@@ -376,6 +376,96 @@ RDRF_D void mfma_seg_b3_pair(f32x16 (&accA)[NA], f32x16 (&accB)[NB], const float
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 x 3 with SPLIT STORAGE (round 6): the appearance kernels' images fill the LDS in fp32 already, so their weights cannot
+// grow 1.5 x.  The hi and mid pieces (4 bytes per weight -- the fp32 footprint) stay in the LDS image,
+// [NBO][KK/8][2 pieces][64 lanes][4 dwords]; the lo pieces -- read by ONE of the six products of a step -- are streamed from
+// the pack buffer in global memory, [NBO][KK/8][64 lanes][4 dwords] (L2-resident: every wave of the launch reads the same
+// 70 KB), one global_load_dwordx4 per output block and step, requested one step ahead: `lo` holds the pieces of this call's
+// step 0 on entry and those of `glo_next`'s step 0 on return (the stream runs across the segments and layers of a tile).
+// Same piece order (hi, mid, lo), same no-asm / loads-first rules as mfma_seg_b3.
+// ---------------------------------------------------------------------------------------------
+RDRF_HD int pk_b3s_size(int nbo, int kk) { return nbo * kk * 64; }      // LDS dwords (hi + mid)
+RDRF_HD int pk_b3s_lo_size(int nbo, int kk) { return nbo * kk * 32; }   // global dwords (lo)
+// The stream is read with buffer loads: one scalar descriptor for the whole lo region, the lane's byte offset (16 lane) in ONE
+// register, the fragment's offset as the scalar operand -- with flat 64-bit addresses hipcc kept a register pair per
+// fragment address alive across the tile loop (96 spilled registers in k_static_app).
+struct B3sLo {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff;   // 16 * lane
+};
+RDRF_D B3sLo b3s_lo_stream(const float* __restrict__ base, int lane) {
+  return B3sLo{__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000), (unsigned)lane * 16u};
+}
+// fragment (nb, k8) of the lo image that starts `off` dwords into the region
+RDRF_D u32x4 b3s_lo_frag(const B3sLo& st, int off, int k8n, int nb, int k8) {
+  return __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, st.voff, (off + (nb * k8n + k8) * 256) * 4, 0);
+}
+template <int NBO>
+RDRF_D void b3s_lo_load(u32x4 (&lo)[NBO], const B3sLo& st, int off, int k8n, int k8) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) lo[nb] = b3s_lo_frag(st, off, k8n, nb, k8);
+}
+template <int NBO, int KK, int KK_NEXT>
+RDRF_D void mfma_seg_b3s(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __restrict__ wpf, const B3sLo& st, int off,
+                         int off_next, u32x4 (&lo)[NBO], int lane) {
+  static_assert(KK % 8 == 0, "one K = 16 step takes eight slots per lane half");
+  static_assert(NBO % 2 == 0, "output blocks are processed in two groups");
+  constexpr int K8 = KK / 8, NG = NBO / 2;
+  const unsigned* __restrict__ wp = reinterpret_cast<const unsigned*>(wpf);
+#pragma unroll
+  for (int k8 = 0; k8 < K8; ++k8) {
+    // The step follows mfma_seg_b3_pair (the form the reproducibility tests pin): group A's hi / mid fragments are requested
+    // FIRST -- with the lo requests that end the previous step, NG * 2 + NBO load issue slots separate the previous step's
+    // last MFMA from the VALU instructions of the split, which reuse its operand registers --, the split is done once, group
+    // B's fragments arrive while group A's MFMAs run.  The product that reads the streamed lo pieces comes LAST in its group:
+    // a whole step lies between their request and their use.
+    u32x4 wa[NG][2], wb[NG][2];
+#pragma unroll
+    for (int nb = 0; nb < NG; ++nb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) wa[nb][p] = *(const u32x4*)(wp + ((size_t)((nb * K8 + k8) * 2 + p) * 64 + lane) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned hi[8], r1[8], mid[8];
+    u32x4 bh, bm, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = __float_as_uint(in[k8 * 8 + e]) & 0xffff0000u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bh[q] = pack_hi16(hi[2 * q], hi[2 * q + 1]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      r1[e] = __float_as_uint(in[k8 * 8 + e] - __uint_as_float(hi[e]));   // exact
+      mid[e] = r1[e] & 0xffff0000u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bm[q] = pack_hi16(mid[2 * q], mid[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bl[q] = pack_hi16(__float_as_uint(__uint_as_float(r1[2 * q]) - __uint_as_float(mid[2 * q])),
+                        __float_as_uint(__uint_as_float(r1[2 * q + 1]) - __uint_as_float(mid[2 * q + 1])));
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xm = __builtin_bit_cast(bf16x8, bm), xl = __builtin_bit_cast(bf16x8, bl);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < NG; ++nb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) wb[nb][p] = *(const u32x4*)(wp + ((size_t)(((NG + nb) * K8 + k8) * 2 + p) * 64 + lane) * 4);
+#define RDRF_B3S_STEP(NB0, WV, XP)                                                                                        \
+    _Pragma("unroll") for (int nb = 0; nb < NG; ++nb)                                                                     \
+      acc[NB0 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WV), XP, acc[NB0 + nb], 0, 0, 0);
+    RDRF_B3S_STEP(0, wa[nb][0], xh) RDRF_B3S_STEP(0, wa[nb][1], xh) RDRF_B3S_STEP(0, wa[nb][0], xm)
+    RDRF_B3S_STEP(0, wa[nb][1], xm) RDRF_B3S_STEP(0, wa[nb][0], xl) RDRF_B3S_STEP(0, lo[nb], xh)
+    __builtin_amdgcn_sched_barrier(0);
+    RDRF_B3S_STEP(NG, wb[nb][0], xh) RDRF_B3S_STEP(NG, wb[nb][1], xh) RDRF_B3S_STEP(NG, wb[nb][0], xm)
+    RDRF_B3S_STEP(NG, wb[nb][1], xm) RDRF_B3S_STEP(NG, wb[nb][0], xl) RDRF_B3S_STEP(NG, lo[NG + nb], xh)
+#undef RDRF_B3S_STEP
+    __builtin_amdgcn_sched_barrier(0);
+    // the lo pieces are consumed: request the next step's (this segment's, or step 0 of the segment that follows in the tile)
+    if (k8 + 1 < K8) b3s_lo_load<NBO>(lo, st, off, K8, k8 + 1);
+    else if (KK_NEXT > 0) b3s_lo_load<NBO>(lo, st, off_next, KK_NEXT / 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // accumulator init from a PACKED bias ([2 halves][NBO*16] in canonical order; nullptr = zero)
 template <int NBO>
 RDRF_D void acc_bias(f32x16 (&acc)[NBO], const float* __restrict__ bpk, int h) {
@@ -1039,6 +1129,14 @@ constexpr int REG_SF = REG_K3 + K3_SIZE;
 constexpr int REG_DYN_END = REG_SF + SF_SIZE;
 constexpr int REG_S3 = 0;
 constexpr int REG_STAT_END = REG_S3 + S3_SIZE;
+// lo pieces of k_dyn_app's bf16 x 3 layers with split storage (mfma_seg_b3s): behind the dynamic images, never copied to LDS
+constexpr int K3_LO_RGB1_F = 0;                               // 4 x 16 slots
+constexpr int K3_LO_RGB1_X0 = K3_LO_RGB1_F + 4 * 16 * 32;     // 4 x 32
+constexpr int K3_LO_RGB1_X1 = K3_LO_RGB1_X0 + 4 * 32 * 32;    // 4 x 8
+constexpr int K3_LO_RGB2 = K3_LO_RGB1_X1 + 4 * 8 * 32;        // 4 x 64
+constexpr int K3_LO_SIZE = K3_LO_RGB2 + 4 * 64 * 32;
+constexpr int REG_K3_LO = REG_DYN_END;
+constexpr int REG_DYN_END_LO = REG_K3_LO + K3_LO_SIZE;
 // ---- static field, appearance phase on 16-sample tiles (k_static_app16): 16x16x4 fragments [nb][kk/2][64 lanes][2]
 constexpr int S16_BASIS = 0;                                  // 2 x 20
 constexpr int S16_W1_F = S16_BASIS + 2 * 20 * 64;             // 8 x 8
@@ -1050,6 +1148,13 @@ constexpr int S16_B2 = S16_B1 + 128;
 constexpr int S16_SIZE = S16_B2 + 128;
 constexpr int REG_S16 = REG_STAT_END;                         // follows the 32-sample image in the static pack area
 constexpr int REG_STAT_END16 = REG_S16 + S16_SIZE;
+// ---- lo pieces of the bf16 x 3 layers with split storage (mfma_seg_b3s): streamed from the pack buffer, never copied to LDS
+constexpr int S3_LO_W1_F = 0;                                 // 4 x 16 slots
+constexpr int S3_LO_W1_P = S3_LO_W1_F + 4 * 16 * 32;          // 4 x 64
+constexpr int S3_LO_W2 = S3_LO_W1_P + 4 * 64 * 32;            // 4 x 64
+constexpr int S3_LO_SIZE = S3_LO_W2 + 4 * 64 * 32;
+constexpr int REG_S3_LO = REG_STAT_END16;
+constexpr int REG_STAT_END_LO = REG_S3_LO + S3_LO_SIZE;
 static_assert(S16_SIZE * 4 <= 160 * 1024, "the 16-sample image must fit the 160 KiB LDS");
 static_assert(K1_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
               "each kernel's weight image must fit the 160 KiB LDS");
@@ -1060,12 +1165,13 @@ struct PackJob {
   const float* src;  // natural [out_dim][ld]
   int ld, out_dim, in_dim;
   int seg;    // SegId of the input segment
-  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 / 8 = bf16 x 3 MFMA forward / transposed
+  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 / 8 = bf16 x 3 MFMA forward / transposed, 9 = 7 with split storage
   int nb;     // NBO (mode 0) / OUT (mode 1) / NBI (mode 2)
   int kk;     // k-steps of the segment (mode 0/1) or of the OUT dimension (mode 2)
   int dst;    // float offset into the pack buffer
   int seg_kk0;  // modes 0 / 7: first slot of the segment this job covers (a segment may be cut between two images)
-  int kk_off, kk_tot;   // mode 7 (bf16 x 3 fragments): the job's first slot inside the image, the image's slots per lane half
+  int kk_off, kk_tot;   // modes 7 / 9 (bf16 x 3 fragments): the job's first slot inside the image, the image's slots per lane half
+  int dst2;             // mode 9 (bf16 x 3, split storage): float offset of the lo pieces (outside the LDS image); dst = hi + mid
 };
 #define RDRF_MAX_PACK_JOBS 48
 struct PackJobs {

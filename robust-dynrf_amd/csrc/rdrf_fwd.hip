@@ -184,10 +184,17 @@ void dyn_pack_jobs_fwd(PackJobs& J, const RdrfDynamicParams* P) {
   pack_add(J, P->db1, 0, 64, 0, 0, 3, 0, 32, k1 + K1_BD1);
   pack_add(J, P->bb1, 0, 64, 0, 0, 3, 0, 32, k1 + K1_BB1);
   pack_add(J, P->basis, 216, 27, 216, SEG_IDENT, 0, 1, 108, k3 + K3_BASIS);
+#ifdef RDRF_APP_F32   // A/B builds: the hidden layers on the fp32 matrix pipe, as up to round 5
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 0, 4, 16, k3 + K3_RGB1_F);
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_X0, 0, 4, 32, k3 + K3_RGB1_X0);
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_X1, 0, 4, 8, k3 + K3_RGB1_X1);
   pack_add(J, P->rw2, 128, 128, 128, SEG_IDENT, 0, 4, 64, k3 + K3_RGB2);
+#else                 // bf16 x 3 with split storage (same image offsets and sizes; lo pieces behind the images)
+  pack_add_b3s(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 4, 16, 0, 0, 16, k3 + K3_RGB1_F, REG_K3_LO + K3_LO_RGB1_F);
+  pack_add_b3s(J, P->rw1, 107, 128, 107, SEG_RGB1_X0, 4, 32, 0, 0, 32, k3 + K3_RGB1_X0, REG_K3_LO + K3_LO_RGB1_X0);
+  pack_add_b3s(J, P->rw1, 107, 128, 107, SEG_RGB1_X1, 4, 8, 0, 0, 8, k3 + K3_RGB1_X1, REG_K3_LO + K3_LO_RGB1_X1);
+  pack_add_b3s(J, P->rw2, 128, 128, 128, SEG_IDENT, 4, 64, 0, 0, 64, k3 + K3_RGB2, REG_K3_LO + K3_LO_RGB2);
+#endif
   pack_add(J, P->rwv, 131, 3, 128, SEG_IDENT, 1, 3, 64, k3 + K3_RGBV);
   pack_add(J, P->rb1, 0, 128, 0, 0, 3, 0, 64, k3 + K3_B1);
   pack_add(J, P->rb2, 0, 128, 0, 0, 3, 0, 64, k3 + K3_B2);
@@ -206,9 +213,15 @@ void static_pack_jobs_fwd(PackJobs& J, const RdrfStaticParams* P, int head) {
   const bool fea = head == RDRF_HEAD_MLP_FEA;
   const int in1 = fea ? 138 : 135;
   pack_add(J, P->basis, 72, 27, 72, SEG_IDENT, 0, 1, 36, REG_S3 + S3_BASIS);
+#ifdef RDRF_APP_F32   // A/B builds: the hidden layers on the fp32 matrix pipe, as up to round 5
   pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 0, 4, 16, REG_S3 + S3_W1_F);
   pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 0, 4, 64, REG_S3 + S3_W1_P);
   pack_add(J, P->w2, 128, 128, 128, SEG_IDENT, 0, 4, 64, REG_S3 + S3_W2);
+#else                 // bf16 x 3 with split storage: hi + mid pieces in the image (same offsets and sizes), lo pieces streamed
+  pack_add_b3s(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 4, 16, 0, 0, 16, REG_S3 + S3_W1_F, REG_S3_LO + S3_LO_W1_F);
+  pack_add_b3s(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 4, 64, 0, 0, 64, REG_S3 + S3_W1_P, REG_S3_LO + S3_LO_W1_P);
+  pack_add_b3s(J, P->w2, 128, 128, 128, SEG_IDENT, 4, 64, 0, 0, 64, REG_S3 + S3_W2, REG_S3_LO + S3_LO_W2);
+#endif
   pack_add(J, P->w3, fea ? 128 : 131, 3, 128, SEG_IDENT, 1, 3, 64, REG_S3 + S3_W3);
   pack_add(J, P->b1, 0, 128, 0, 0, 3, 0, 64, REG_S3 + S3_B1);
   pack_add(J, P->b2, 0, 128, 0, 0, 3, 0, 64, REG_S3 + S3_B2);

@@ -251,13 +251,27 @@ RDRF_D void static_app_body(const FieldArgs a, const StaticW w, float* lds_fused
     save_rows<64>(svb, sv::S3_P, P, s, h);
     f32x16 acc[4];
     acc_bias<4>(acc, pkw + pk::S3_B1, h);
+    float H1[64];
+#ifdef RDRF_APP_F32
     mfma_seg<4, 16>(acc, F, pkw + pk::S3_W1_F, lane);
     mfma_seg<4, 64>(acc, P, pkw + pk::S3_W1_P, lane);
-    float H1[64];
     acc_relu<4>(H1, acc);
     save_rows<64>(svb, sv::S3_H1, H1, s, h);
     acc_bias<4>(acc, pkw + pk::S3_B2, h);
     mfma_seg<4, 64>(acc, H1, pkw + pk::S3_W2, lane);
+#else
+    {  // the two hidden layers on the bf16 matrix pipe (fp32-grade bf16 x 3, lo pieces streamed from the pack buffer)
+      const B3sLo st = b3s_lo_stream(a.pk + pk::REG_S3_LO, lane);
+      u32x4 lo[4];
+      b3s_lo_load<4>(lo, st, pk::S3_LO_W1_F, 2, 0);
+      mfma_seg_b3s<4, 16, 64>(acc, F, pkw + pk::S3_W1_F, st, pk::S3_LO_W1_F, pk::S3_LO_W1_P, lo, lane);
+      mfma_seg_b3s<4, 64, 64>(acc, P, pkw + pk::S3_W1_P, st, pk::S3_LO_W1_P, pk::S3_LO_W2, lo, lane);
+      acc_relu<4>(H1, acc);
+      save_rows<64>(svb, sv::S3_H1, H1, s, h);
+      acc_bias<4>(acc, pkw + pk::S3_B2, h);
+      mfma_seg_b3s<4, 64, 0>(acc, H1, pkw + pk::S3_W2, st, pk::S3_LO_W2, 0, lo, lane);
+    }
+#endif
     acc_relu<4>(H1, acc);
     save_rows<64>(svb, sv::S3_H2, H1, s, h);
 #pragma unroll
@@ -796,14 +810,29 @@ RDRF_D void dyn_app_body(const FieldArgs a, const DynW w, float* lds_fused, cons
     save_rows<8>(svb, sv::K3_X1, X1, s, h);
     f32x16 acc[4];
     acc_bias<4>(acc, pkw + pk::K3_B1, h);
+    float H1[64];
+#ifdef RDRF_APP_F32
     mfma_seg<4, 16>(acc, F, pkw + pk::K3_RGB1_F, lane);
     mfma_seg<4, 32>(acc, X0, pkw + pk::K3_RGB1_X0, lane);
     mfma_seg<4, 8>(acc, X1, pkw + pk::K3_RGB1_X1, lane);
-    float H1[64];
     acc_relu<4>(H1, acc);
     save_rows<64>(svb, sv::K3_H1, H1, s, h);
     acc_bias<4>(acc, pkw + pk::K3_B2, h);
     mfma_seg<4, 64>(acc, H1, pkw + pk::K3_RGB2, lane);
+#else
+    {  // the two hidden layers on the bf16 matrix pipe (fp32-grade bf16 x 3, lo pieces streamed from the pack buffer)
+      const B3sLo st = b3s_lo_stream(a.pk + pk::REG_K3_LO, lane);
+      u32x4 lo[4];
+      b3s_lo_load<4>(lo, st, pk::K3_LO_RGB1_F, 2, 0);
+      mfma_seg_b3s<4, 16, 32>(acc, F, pkw + pk::K3_RGB1_F, st, pk::K3_LO_RGB1_F, pk::K3_LO_RGB1_X0, lo, lane);
+      mfma_seg_b3s<4, 32, 8>(acc, X0, pkw + pk::K3_RGB1_X0, st, pk::K3_LO_RGB1_X0, pk::K3_LO_RGB1_X1, lo, lane);
+      mfma_seg_b3s<4, 8, 64>(acc, X1, pkw + pk::K3_RGB1_X1, st, pk::K3_LO_RGB1_X1, pk::K3_LO_RGB2, lo, lane);
+      acc_relu<4>(H1, acc);
+      save_rows<64>(svb, sv::K3_H1, H1, s, h);
+      acc_bias<4>(acc, pkw + pk::K3_B2, h);
+      mfma_seg_b3s<4, 64, 0>(acc, H1, pkw + pk::K3_RGB2, st, pk::K3_LO_RGB2, 0, lo, lane);
+    }
+#endif
     acc_relu<4>(H1, acc);
     save_rows<64>(svb, sv::K3_H2, H1, s, h);
 #pragma unroll

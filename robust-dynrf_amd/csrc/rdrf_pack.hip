@@ -161,6 +161,32 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
       const int kk = J.kk_off + 2 * pr;
       out[((size_t)((nb * k8n + (kk >> 3)) * 3 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
     }
+  } else if (J.mode == 9) {  // bf16 x 3 fragments, split storage (mfma_seg_b3s): hi and mid pieces [nb][kk_tot/8][2][64 lanes][4 dwords]
+    // at dst (the LDS image: the fp32 footprint), lo pieces [nb][kk_tot/8][64 lanes][4 dwords] at dst2 (streamed from L2)
+    const int pairs = J.kk >> 1, k8n = J.kk_tot >> 3;
+    const int total = J.nb * pairs * 3 * 64;
+    unsigned* out = reinterpret_cast<unsigned*>(dst) + J.dst;
+    unsigned* out_lo = reinterpret_cast<unsigned*>(dst) + J.dst2;
+    for (int i = tid; i < total; i += stride) {
+      const int lane = i & 63;
+      int r = i >> 6;
+      const int p = r % 3; r /= 3;
+      const int pr = r % pairs, nb = r / pairs;
+      const int h = lane >> 5, o = nb * 32 + (lane & 31);
+      unsigned d = 0;
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int col = seg_imap(J.seg, elem_of(J.seg_kk0 + 2 * pr + e2, h), J.in_dim);
+        const float v = (o < J.out_dim && col >= 0) ? J.src[(size_t)o * J.ld + col] : 0.f;
+        unsigned ph, pm, pl;
+        split3(v, ph, pm, pl);
+        const unsigned piece = (p == 0 ? ph : (p == 1 ? pm : pl)) >> 16;
+        d |= piece << (16 * e2);
+      }
+      const int kk = J.kk_off + 2 * pr;
+      if (p < 2) out[((size_t)((nb * k8n + (kk >> 3)) * 2 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
+      else out_lo[((size_t)(nb * k8n + (kk >> 3)) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
+    }
   } else if (J.mode == 8) {  // bf16 x 3 fragments of a TRANSPOSED layer (backward data, as mode 2): [nb][kk/8][3][64 lanes][4 dwords];
     // K = the forward layer's outputs (slot kk of lane half h = neuron elem_of(kk, h)), rows = the segment's input elements
     const int pairs = J.kk >> 1, k8n = J.kk >> 3;
@@ -242,6 +268,17 @@ void pack_add(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, in
   j.seg_kk0 = 0;
   j.kk_off = 0;
   j.kk_tot = 0;
+  j.dst2 = 0;
+}
+// as pack_add_b3 with split storage: hi + mid pieces at dst (LDS image), lo pieces at dst_lo (streamed)
+void pack_add_b3s(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int kk_off,
+                  int kk_tot, int dst, int dst_lo) {
+  pack_add(J, src, ld, out_dim, in_dim, seg, 9, nb, kk, dst);
+  PackJob& j = J.j[J.n - 1];
+  j.seg_kk0 = seg_kk0;
+  j.kk_off = kk_off;
+  j.kk_tot = kk_tot;
+  j.dst2 = dst_lo;
 }
 // one segment (slots seg_kk0 .. seg_kk0 + kk - 1 of `seg`) of a bf16 x 3 image of kk_tot slots, at slot kk_off of the image
 void pack_add_b3(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int kk_off,

@@ -348,6 +348,29 @@ def test_c_abi_error_paths():
 
 
 @pytest.mark.parametrize("case,N,S", [("contract_relu_te", 2100, 37), ("ndc_relu", 777, 115)])
+def test_static_forward_is_bit_reproducible(case, N, S):
+    """As below for the static field, whose hidden layers run on the bf16 matrix pipe with split storage (mfma_seg_b3s: hi + mid
+    pieces in LDS, lo pieces streamed from the pack buffer): no atomics, so repeated calls must return the same bits."""
+    import rodynrf
+    from _gpu_util import fields_from_case, make_rays
+    g, st, dy, _ = fields_from_case(case)
+    rt = str(g["meta.ray_type"])
+    rays, ts = (t.cuda() for t in make_rays(N, 3, rt))
+    xyz, z, valid = rodynrf.sampleXYZ(st, rays, S, ray_type=rt, is_train=False)
+    for grad in (False, True):
+        ref = None
+        for rep in range(25):
+            with torch.set_grad_enabled(grad):
+                o = st(rays, ts, None, xyz, z, valid, is_train=True, ray_type=rt)
+            got = [t.detach().clone() for t in o if isinstance(t, torch.Tensor) and t.is_floating_point()]
+            if ref is None:
+                ref = got
+            else:
+                for a, b in zip(ref, got):
+                    assert torch.equal(a, b), (grad, rep)
+
+
+@pytest.mark.parametrize("case,N,S", [("contract_relu_te", 2100, 37), ("ndc_relu", 777, 115)])
 def test_dynamic_forward_is_bit_reproducible(case, N, S):
     """The forward kernels do no atomics: repeated calls must return the same bits, in the inference (flat-tile) and the
     training (wave-per-ray, saved rows) instantiation.  Pins the operand hazards found when the heads' first layers moved to
