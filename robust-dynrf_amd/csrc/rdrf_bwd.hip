@@ -76,6 +76,17 @@ constexpr int SF_SIZE = SF_W0T + 2 * 32 * 64;
 constexpr int REG_K1H = 0, REG_K1W = REG_K1H + K1H_SIZE, REG_K3 = REG_K1W + K1W_SIZE,
               REG_SF = REG_K3 + K3_SIZE, REG_DYN_END = REG_SF + SF_SIZE;
 constexpr int REG_S3 = 0, REG_STAT_END = S3_SIZE;
+// lo pieces of the appearance backward kernels' bf16 x 3 layers with split storage (mfma_seg_b3s): streamed, never in LDS
+constexpr int K3_LO_RGB2T = 0;                                // 4 x 64 slots
+constexpr int K3_LO_RGB1T = K3_LO_RGB2T + 4 * 64 * 32;        // (1 + 2) x 64: the F block, then the two X0 blocks
+constexpr int K3_LO_BASIST = K3_LO_RGB1T + 3 * 64 * 32;       // 7 x 16
+constexpr int K3_LO_SIZE = K3_LO_BASIST + 7 * 16 * 32;
+constexpr int S3_LO_W2T = 0;                                  // 4 x 64
+constexpr int S3_LO_W1T = S3_LO_W2T + 4 * 64 * 32;            // (1 + 4) x 64: the F block, then the four PE blocks
+constexpr int S3_LO_BASIST = S3_LO_W1T + 5 * 64 * 32;         // 3 x 16
+constexpr int S3_LO_SIZE = S3_LO_BASIST + 3 * 16 * 32;
+constexpr int REG_K3_LO = REG_DYN_END, REG_S3_LO = REG_STAT_END;
+static_assert(K3_RGB1T_X0 == K3_RGB1T_F + 64 * 64 && S3_W1T_P == S3_W1T_F + 64 * 64, "layer-1 blocks form one image");
 static_assert(K1H_SIZE * 4 <= 160 * 1024 && K3_SIZE * 4 <= 160 * 1024 && S3_SIZE * 4 <= 160 * 1024,
               "backward weight images must fit the LDS");
 }  // namespace pkb
@@ -837,6 +848,21 @@ RDRF_D void feat_dF(float (&dF)[16], const float* g_feat, int idx, bool act, int
 }
 
 // REC: d(app features) go out as sample-major records for the sorted scatter (a.dfa) instead of DA rows
+
+// one backward-data layer of the appearance phases: NBI input blocks from one dz vector, fp32 pipe (A/B builds) or split-storage
+// bf16 x 3 (the lo pieces of step 0 are requested here: callers place the call so that row loads / VALU work follow the request)
+template <int NBI, int KK>
+RDRF_D void app_bwd_seg(f32x16 (&acc)[NBI], const float (&dz)[KK], const float* __restrict__ whm, const float* __restrict__ pk,
+                        int lo_reg, int lo_off, int lane) {
+#ifdef RDRF_APP_F32
+  mfma_seg<NBI, KK>(acc, dz, whm, lane);
+#else
+  const B3sLo st = b3s_lo_stream(pk + lo_reg, lane);
+  u32x4 lo[NBI];
+  b3s_lo_load<NBI>(lo, st, lo_off, KK / 8, 0);
+  mfma_seg_b3s<NBI, KK, 0>(acc, dz, whm, st, lo_off, 0, lo, lane);
+#endif
+}
 template <bool FEAT, bool REC = false>
 __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW w, DynG gw) {
   __shared__ int s_next;
@@ -861,7 +887,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
       save_rows<16>(gb, sv::K3G_DF, dF, s, h);
       f32x16 acc[7];
       acc_zero<7>(acc);
-      mfma_seg<7, 16>(acc, dF, basisT, lane);
+      app_bwd_seg<7, 16>(acc, dF, basisT, a.pk, pkb::REG_K3_LO, pkb::K3_LO_BASIST, lane);
       float dA[112];
       acc_copy<7>(dA, acc);
       save_rows<112>(gb, sv::K3G_DA, dA, s, h);
@@ -890,7 +916,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
     {
       f32x16 acc[4];
       acc_zero<4>(acc);
-      mfma_seg<4, 64>(acc, dz2, lds + pkb::K3_RGB2T, lane);
+      app_bwd_seg<4, 64>(acc, dz2, lds + pkb::K3_RGB2T, a.pk, pkb::REG_K3_LO, pkb::K3_LO_RGB2T, lane);
       float H1[64];
       load_rows<64>(svb, sv::K3_H1, H1, s, h);
 #pragma unroll
@@ -900,6 +926,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
     // ---- layer 1 backward: feature block and X0 block (t / PE(t) carry no gradient)
     float dF[16], dX0[32];
     {
+#ifdef RDRF_APP_F32
       f32x16 acc[1];
       acc_zero<1>(acc);
       mfma_seg<1, 64>(acc, dz1, lds + pkb::K3_RGB1T_F, lane);
@@ -908,6 +935,15 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
       acc_zero<2>(acc2);
       mfma_seg<2, 64>(acc2, dz1, lds + pkb::K3_RGB1T_X0, lane);
       acc_copy<2>(dX0, acc2);
+#else   // the F block and the two X0 blocks are one three-block image: one split of dz1
+      f32x16 acc[3];
+      acc_zero<3>(acc);
+      app_bwd_seg<3, 64>(acc, dz1, lds + pkb::K3_RGB1T_F, a.pk, pkb::REG_K3_LO, pkb::K3_LO_RGB1T, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dF[i] = acc[0][i];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) dX0[i] = acc[1 + (i >> 4)][i & 15];
+#endif
     }
     save_rows<16>(gb, sv::K3G_DF, dF, s, h);
     float dn0 = 0.f, dn1 = 0.f, dn2 = 0.f;
@@ -921,7 +957,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_dyn_app_bwd(BwdArgs a, DynW 
     {
       f32x16 acc[7];
       acc_zero<7>(acc);
-      mfma_seg<7, 16>(acc, dF, basisT, lane);
+      app_bwd_seg<7, 16>(acc, dF, basisT, a.pk, pkb::REG_K3_LO, pkb::K3_LO_BASIST, lane);
       float dA[112];
       acc_copy<7>(dA, acc);
       if constexpr (REC) {
@@ -973,7 +1009,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
       save_rows<16>(gb, sv::K3G_DF, dF, s, h);
       f32x16 acc[3];
       acc_zero<3>(acc);
-      mfma_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, lane);
+      app_bwd_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, a.pk, pkb::REG_S3_LO, pkb::S3_LO_BASIST, lane);
       float dG[48];
       acc_copy<3>(dG, acc);
       save_rows<48>(gb, sv::K3G_DA, dG, s, h);
@@ -1001,7 +1037,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
     {
       f32x16 acc[4];
       acc_zero<4>(acc);
-      mfma_seg<4, 64>(acc, dz2, lds + pkb::S3_W2T, lane);
+      app_bwd_seg<4, 64>(acc, dz2, lds + pkb::S3_W2T, a.pk, pkb::REG_S3_LO, pkb::S3_LO_W2T, lane);
       float H1[64];
       load_rows<64>(svb, sv::S3_H1, H1, s, h);
 #pragma unroll
@@ -1010,6 +1046,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
     save_rows<64>(gb, sv::K3G_DZ1, dz1, s, h);
     float dF[16];
     {
+#ifdef RDRF_APP_F32
       f32x16 acc[1];
       acc_zero<1>(acc);
       mfma_seg<1, 64>(acc, dz1, lds + pkb::S3_W1T_F, lane);
@@ -1017,6 +1054,14 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
       f32x16 accp[4];
       acc_zero<4>(accp);
       mfma_seg<4, 64>(accp, dz1, lds + pkb::S3_W1T_P, lane);
+#else   // the F block and the four PE blocks are one five-block image: one split of dz1
+      f32x16 acc5[5];
+      acc_zero<5>(acc5);
+      app_bwd_seg<5, 64>(acc5, dz1, lds + pkb::S3_W1T_F, a.pk, pkb::REG_S3_LO, pkb::S3_LO_W1T, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dF[i] = acc5[0][i];
+      f32x16 (&accp)[4] = *reinterpret_cast<f32x16 (*)[4]>(&acc5[1]);
+#endif
       float P[64];
       load_rows<64>(svb, sv::S3_P, P, s, h);
       // PE2 backward: P[4r..4r+3] = (sin f, cos f, sin 2f, cos 2f) of feature slot r
@@ -1059,7 +1104,7 @@ __global__ __launch_bounds__(64 * RDRF_MAXW) void k_static_app_bwd(BwdArgs a, St
     {
       f32x16 acc[3];
       acc_zero<3>(acc);
-      mfma_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, lane);
+      app_bwd_seg<3, 16>(acc, dF, lds + pkb::S3_BASIST, a.pk, pkb::REG_S3_LO, pkb::S3_LO_BASIST, lane);
       float dG[48];
       acc_copy<3>(dG, acc);
       save_rows<48>(gb, sv::K3G_DA, dG, s, h);
@@ -2613,10 +2658,17 @@ static void dyn_pack_jobs_bwd(PackJobs& J, const RdrfDynamicParams* P) {
   pack_add(J, P->bw1, 152, 64, 72, SEG_IDENT, hm, 3, 32, kh + K1H_BLE1T_F);
   pack_add(J, P->bw1, 152, 64, 152, SEG_DEN1_X0, hm, 2, 32, kh + K1H_BLE1T_X0);
   pack_add(J, P->rwv, 131, 3, 128, SEG_IDENT, 1, 3, 64, k3 + K3_RGBV);
+#ifdef RDRF_APP_F32   // A/B builds: the appearance phases' backward-data products on the fp32 matrix pipe
   pack_add(J, P->rw2, 128, 128, 128, SEG_IDENT, 2, 4, 64, k3 + K3_RGB2T);
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 2, 1, 64, k3 + K3_RGB1T_F);
   pack_add(J, P->rw1, 107, 128, 107, SEG_RGB1_X0, 2, 2, 64, k3 + K3_RGB1T_X0);
   pack_add(J, P->basis, 216, 27, 216, SEG_IDENT, 2, 7, 16, k3 + K3_BASIST);
+#else                 // bf16 x 3 with split storage (same image offsets and sizes)
+  pack_add_b3s_t(J, P->rw2, 128, 128, 128, SEG_IDENT, 4, 64, k3 + K3_RGB2T, REG_K3_LO + K3_LO_RGB2T);
+  pack_add_b3s_t(J, P->rw1, 107, 128, 107, SEG_RGB1_F, 1, 64, k3 + K3_RGB1T_F, REG_K3_LO + K3_LO_RGB1T);
+  pack_add_b3s_t(J, P->rw1, 107, 128, 107, SEG_RGB1_X0, 2, 64, k3 + K3_RGB1T_X0, REG_K3_LO + K3_LO_RGB1T + 64 * 32);
+  pack_add_b3s_t(J, P->basis, 216, 27, 216, SEG_IDENT, 7, 16, k3 + K3_BASIST, REG_K3_LO + K3_LO_BASIST);
+#endif
   pack_add(J, P->sfw[3], 64, 6, 64, SEG_IDENT, 1, 6, 32, sf + SF_W6);
   pack_add(J, P->sfw[2], 64, 64, 64, SEG_IDENT, 2, 2, 32, sf + SF_W4T);
   pack_add(J, P->sfw[1], 64, 64, 64, SEG_IDENT, 2, 2, 32, sf + SF_W2T);
@@ -2629,10 +2681,17 @@ static void static_pack_jobs_bwd(PackJobs& J, const RdrfStaticParams* P, int hea
   const bool fea = head == RDRF_HEAD_MLP_FEA;
   const int in1 = fea ? 138 : 135;
   pack_add(J, P->w3, fea ? 128 : 131, 3, 128, SEG_IDENT, 1, 3, 64, REG_S3 + S3_W3);
+#ifdef RDRF_APP_F32
   pack_add(J, P->w2, 128, 128, 128, SEG_IDENT, 2, 4, 64, REG_S3 + S3_W2T);
   pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 2, 1, 64, REG_S3 + S3_W1T_F);
   pack_add(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 2, 4, 64, REG_S3 + S3_W1T_P);
   pack_add(J, P->basis, 72, 27, 72, SEG_IDENT, 2, 3, 16, REG_S3 + S3_BASIST);
+#else
+  pack_add_b3s_t(J, P->w2, 128, 128, 128, SEG_IDENT, 4, 64, REG_S3 + S3_W2T, REG_S3_LO + S3_LO_W2T);
+  pack_add_b3s_t(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_F_FEA : SEG_STAT1_F_TE, 1, 64, REG_S3 + S3_W1T_F, REG_S3_LO + S3_LO_W1T);
+  pack_add_b3s_t(J, P->w1, in1, 128, in1, fea ? SEG_STAT1_P_FEA : SEG_STAT1_P_TE, 4, 64, REG_S3 + S3_W1T_P, REG_S3_LO + S3_LO_W1T + 64 * 32);
+  pack_add_b3s_t(J, P->basis, 72, 27, 72, SEG_IDENT, 3, 16, REG_S3 + S3_BASIST, REG_S3_LO + S3_LO_BASIST);
+#endif
 }
 
 struct Geo {
@@ -2650,6 +2709,8 @@ static Geo geo_for_units(long units) {
 }
 
 #define PACK_AREA_FLOATS (1 << 20)
+static_assert(pkb::REG_K3_LO + pkb::K3_LO_SIZE <= PACK_AREA_FLOATS && pkb::REG_S3_LO + pkb::S3_LO_SIZE <= PACK_AREA_FLOATS,
+              "the backward images and their streamed lo pieces fit the pack area");
 
 static void fill_bwd_common(BwdArgs& a, const RdrfFieldCfg* cfg, const float* rays, const float* ts,
                             const float* xyz, const float* z, const uint8_t* valid, int N, int S) {

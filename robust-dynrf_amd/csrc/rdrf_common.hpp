@@ -410,21 +410,28 @@ template <int NBO, int KK, int KK_NEXT>
 RDRF_D void mfma_seg_b3s(f32x16 (&acc)[NBO], const float (&in)[KK], const float* __restrict__ wpf, const B3sLo& st, int off,
                          int off_next, u32x4 (&lo)[NBO], int lane) {
   static_assert(KK % 8 == 0, "one K = 16 step takes eight slots per lane half");
-  static_assert(NBO % 2 == 0, "output blocks are processed in two groups");
-  constexpr int K8 = KK / 8, NG = NBO / 2;
+  static_assert(NBO >= 2, "output blocks are processed in two groups");
+  constexpr int K8 = KK / 8, NA = NBO / 2, NB = NBO - NA;
+  // The step follows mfma_seg_b3_pair (the form the reproducibility tests pin): group A's hi / mid fragments are requested
+  // FIRST -- with the lo requests that end the previous step, at least six load issue slots separate the previous step's
+  // last MFMA from the VALU instructions of the split, which reuse its operand registers (narrow layers request group B's
+  // fragments there too) --, the split is done once, group B's fragments arrive while group A's MFMAs run.  The product
+  // that reads the streamed lo pieces comes LAST in its group: a whole step lies between their request and their use.
+  constexpr bool EARLY_B = NA * 2 + NBO < 6;
   const unsigned* __restrict__ wp = reinterpret_cast<const unsigned*>(wpf);
 #pragma unroll
   for (int k8 = 0; k8 < K8; ++k8) {
-    // The step follows mfma_seg_b3_pair (the form the reproducibility tests pin): group A's hi / mid fragments are requested
-    // FIRST -- with the lo requests that end the previous step, NG * 2 + NBO load issue slots separate the previous step's
-    // last MFMA from the VALU instructions of the split, which reuse its operand registers --, the split is done once, group
-    // B's fragments arrive while group A's MFMAs run.  The product that reads the streamed lo pieces comes LAST in its group:
-    // a whole step lies between their request and their use.
-    u32x4 wa[NG][2], wb[NG][2];
+    u32x4 wa[NA][2], wb[NB][2];
 #pragma unroll
-    for (int nb = 0; nb < NG; ++nb)
+    for (int nb = 0; nb < NA; ++nb)
 #pragma unroll
       for (int p = 0; p < 2; ++p) wa[nb][p] = *(const u32x4*)(wp + ((size_t)((nb * K8 + k8) * 2 + p) * 64 + lane) * 4);
+    if (EARLY_B) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wb[nb][p] = *(const u32x4*)(wp + ((size_t)(((NA + nb) * K8 + k8) * 2 + p) * 64 + lane) * 4);
+    }
     __builtin_amdgcn_sched_barrier(0);
     unsigned hi[8], r1[8], mid[8];
     u32x4 bh, bm, bl;
@@ -445,18 +452,20 @@ RDRF_D void mfma_seg_b3s(f32x16 (&acc)[NBO], const float (&in)[KK], const float*
                         __float_as_uint(__uint_as_float(r1[2 * q + 1]) - __uint_as_float(mid[2 * q + 1])));
     const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xm = __builtin_bit_cast(bf16x8, bm), xl = __builtin_bit_cast(bf16x8, bl);
     __builtin_amdgcn_sched_barrier(0);
+    if (!EARLY_B) {
 #pragma unroll
-    for (int nb = 0; nb < NG; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) wb[nb][p] = *(const u32x4*)(wp + ((size_t)(((NG + nb) * K8 + k8) * 2 + p) * 64 + lane) * 4);
-#define RDRF_B3S_STEP(NB0, WV, XP)                                                                                        \
-    _Pragma("unroll") for (int nb = 0; nb < NG; ++nb)                                                                     \
+        for (int p = 0; p < 2; ++p) wb[nb][p] = *(const u32x4*)(wp + ((size_t)(((NA + nb) * K8 + k8) * 2 + p) * 64 + lane) * 4);
+    }
+#define RDRF_B3S_STEP(N, NB0, WV, XP)                                                                                     \
+    _Pragma("unroll") for (int nb = 0; nb < N; ++nb)                                                                      \
       acc[NB0 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WV), XP, acc[NB0 + nb], 0, 0, 0);
-    RDRF_B3S_STEP(0, wa[nb][0], xh) RDRF_B3S_STEP(0, wa[nb][1], xh) RDRF_B3S_STEP(0, wa[nb][0], xm)
-    RDRF_B3S_STEP(0, wa[nb][1], xm) RDRF_B3S_STEP(0, wa[nb][0], xl) RDRF_B3S_STEP(0, lo[nb], xh)
+    RDRF_B3S_STEP(NA, 0, wa[nb][0], xh) RDRF_B3S_STEP(NA, 0, wa[nb][1], xh) RDRF_B3S_STEP(NA, 0, wa[nb][0], xm)
+    RDRF_B3S_STEP(NA, 0, wa[nb][1], xm) RDRF_B3S_STEP(NA, 0, wa[nb][0], xl) RDRF_B3S_STEP(NA, 0, lo[nb], xh)
     __builtin_amdgcn_sched_barrier(0);
-    RDRF_B3S_STEP(NG, wb[nb][0], xh) RDRF_B3S_STEP(NG, wb[nb][1], xh) RDRF_B3S_STEP(NG, wb[nb][0], xm)
-    RDRF_B3S_STEP(NG, wb[nb][1], xm) RDRF_B3S_STEP(NG, wb[nb][0], xl) RDRF_B3S_STEP(NG, lo[NG + nb], xh)
+    RDRF_B3S_STEP(NB, NA, wb[nb][0], xh) RDRF_B3S_STEP(NB, NA, wb[nb][1], xh) RDRF_B3S_STEP(NB, NA, wb[nb][0], xm)
+    RDRF_B3S_STEP(NB, NA, wb[nb][1], xm) RDRF_B3S_STEP(NB, NA, wb[nb][0], xl) RDRF_B3S_STEP(NB, NA, lo[NA + nb], xh)
 #undef RDRF_B3S_STEP
     __builtin_amdgcn_sched_barrier(0);
     // the lo pieces are consumed: request the next step's (this segment's, or step 0 of the segment that follows in the tile)
@@ -1165,13 +1174,13 @@ struct PackJob {
   const float* src;  // natural [out_dim][ld]
   int ld, out_dim, in_dim;
   int seg;    // SegId of the input segment
-  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 / 8 = bf16 x 3 MFMA forward / transposed, 9 = 7 with split storage
+  int mode;   // 0 = MFMA forward, 1 = small forward, 2 = MFMA transposed (backward data), 3 = bias, 7 / 8 = bf16 x 3 MFMA forward / transposed, 9 / 10 = 7 / 8 with split storage
   int nb;     // NBO (mode 0) / OUT (mode 1) / NBI (mode 2)
   int kk;     // k-steps of the segment (mode 0/1) or of the OUT dimension (mode 2)
   int dst;    // float offset into the pack buffer
   int seg_kk0;  // modes 0 / 7: first slot of the segment this job covers (a segment may be cut between two images)
   int kk_off, kk_tot;   // modes 7 / 9 (bf16 x 3 fragments): the job's first slot inside the image, the image's slots per lane half
-  int dst2;             // mode 9 (bf16 x 3, split storage): float offset of the lo pieces (outside the LDS image); dst = hi + mid
+  int dst2;             // modes 9 / 10 (bf16 x 3, split storage): float offset of the lo pieces (outside the LDS image); dst = hi + mid
 };
 #define RDRF_MAX_PACK_JOBS 48
 struct PackJobs {

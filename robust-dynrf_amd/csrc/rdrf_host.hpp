@@ -109,5 +109,6 @@ void pack_add_b3(PackJobs& J, const float* src, int ld, int out_dim, int in_dim,
                  int kk_tot, int dst);
 void pack_add_b3s(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int kk_off,
                   int kk_tot, int dst, int dst_lo);
+void pack_add_b3s_t(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nbi, int kk, int dst, int dst_lo);
 void pack_add_from(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int dst);
 int pack_launch(const PackJobs& J, float* dst, hipStream_t stream);

@@ -187,7 +187,8 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
       if (p < 2) out[((size_t)((nb * k8n + (kk >> 3)) * 2 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
       else out_lo[((size_t)(nb * k8n + (kk >> 3)) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
     }
-  } else if (J.mode == 8) {  // bf16 x 3 fragments of a TRANSPOSED layer (backward data, as mode 2): [nb][kk/8][3][64 lanes][4 dwords];
+  } else if (J.mode == 8 || J.mode == 10) {  // bf16 x 3 fragments of a TRANSPOSED layer (backward data, as mode 2): [nb][kk/8][3][64 lanes][4 dwords]
+    // (mode 10: split storage as mode 9 -- hi + mid at dst, lo at dst2);
     // K = the forward layer's outputs (slot kk of lane half h = neuron elem_of(kk, h)), rows = the segment's input elements
     const int pairs = J.kk >> 1, k8n = J.kk >> 3;
     const int total = J.nb * pairs * 3 * 64;
@@ -210,7 +211,9 @@ __global__ void k_pack(PackJobs jobs, float* __restrict__ dst) {
         d |= piece << (16 * e2);
       }
       const int kk = 2 * pr;
-      out[((size_t)((nb * k8n + (kk >> 3)) * 3 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
+      if (J.mode == 8) out[((size_t)((nb * k8n + (kk >> 3)) * 3 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
+      else if (p < 2) out[((size_t)((nb * k8n + (kk >> 3)) * 2 + p) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;   // split storage
+      else (reinterpret_cast<unsigned*>(dst) + J.dst2)[((size_t)(nb * k8n + (kk >> 3)) * 64 + lane) * 4 + ((kk & 7) >> 1)] = d;
     }
   } else if (J.mode == 4) {  // 16x16x4 fragments: [nb][kk/2][64 lanes][2], lane = (g << 4) | neuron
     const int total = J.nb * J.kk * 64;
@@ -288,6 +291,11 @@ void pack_add_b3(PackJobs& J, const float* src, int ld, int out_dim, int in_dim,
   j.seg_kk0 = seg_kk0;
   j.kk_off = kk_off;
   j.kk_tot = kk_tot;
+}
+// a transposed layer (backward data) as bf16 x 3 fragments with split storage: hi + mid at dst (LDS image), lo at dst_lo
+void pack_add_b3s_t(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nbi, int kk, int dst, int dst_lo) {
+  pack_add(J, src, ld, out_dim, in_dim, seg, 10, nbi, kk, dst);
+  J.j[J.n - 1].dst2 = dst_lo;
 }
 // an fp32 MFMA segment that starts at slot seg_kk0 of `seg`
 void pack_add_from(PackJobs& J, const float* src, int ld, int out_dim, int in_dim, int seg, int nb, int kk, int seg_kk0, int dst) {
