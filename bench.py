@@ -41,6 +41,25 @@ F_DYN_APP = 11664 + 60946                  # basis + late-view head
 F_STAT_APP = 72752                         # basis + MLP_Fea head
 F_SCENE_FLOW = 21760
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_F32_MFMA_TFLOPS   # same guide: the f32 MFMA rate is 1/16 of the bf16 rate (~2.5 PFLOP/s dense)
+# Share of each kernel's algorithmic FLOP whose layers run as bf16 x 3 (csrc mfma_seg_b3 / _b3_pair / _b3s: three bf16 pieces per fp32
+# value, SIX bf16 piece products per fp32 product), from the layer shapes: heads' first layers [72 features | X0 | X1[0..3]] of 152
+# inputs; the appearance phases' two hidden layers (forward) and every backward-data layer but the 3-output one; the backward's
+# first-layer blocks that carry a gradient.  A kernel's matrix-pipe floor is FLOP x ((1 - b) / f32 peak + 6 b / bf16 peak), i.e.
+# (1 - 0.625 b) x its fp32 floor: `mfma_frac` (speed against the fp32 roof) x that factor = the physical pipe occupancy.
+B3_FLOP_SHARE = {
+    "dyn_density": 2 * (2 * 144 * 64) / F_DYN_DENSITY, "dyn_app": (2 * 107 * 128 + 2 * 128 * 128) / F_DYN_APP,
+    "static_app": (2 * 138 * 128 + 2 * 128 * 128) / F_STAT_APP, "dyn_app_bwd": (F_DYN_APP - 2 * 131 * 3) / F_DYN_APP,
+    "static_app_bwd": (F_STAT_APP - 2 * 128 * 3) / F_STAT_APP, "dyn_heads_bwd": (2 * 136 * 64) / 19584.0,
+    "dyn_warp_bwd": (2 * 64 * 64 + 2 * 93 * 64) / 26496.0,
+}
+
+
+def pipe_factor(k):
+    """matrix-pipe floor of kernel k / its fp32-only floor"""
+    return 1.0 - (1.0 - 6.0 * PEAK_F32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS) * B3_FLOP_SHARE.get(k, 0.0)
+
+
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak (~6.3 TB/s achievable)
 PEAK_L2_GBS = 34500.0                      # MI355X_MICROARCH.md: aggregate L2 bandwidth
 L2_ATOMIC_REQ_PER_S = 20.8e9               # tools/ubench/atomics.hip: fp32 atomic requests the L2 retires
@@ -445,6 +464,7 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         fl = sum(flops[k] * mult[k] for k in ks)
         return {"bound": "mfma", "achieved": fl / (ms_f * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": fl / (ms_f * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": name, "ms_per_step": ms_f,
+                "pipe_frac": sum(flops[k] * mult[k] * pipe_factor(k) for k in ks) / (ms_f * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "members_ms_per_step": {k: round(table[k]["ms_per_step"], 4) for k in ks}}
     fwd_entry = mlp_family("forward MLP kernels (k_dyn_density, k_dyn_app, k_static_app, k_scene_flow)",
                            ("dyn_density", "dyn_app", "static_app", "scene_flow"))
@@ -497,6 +517,16 @@ def roofline(L, S_, trainer, cfg, shard, rays_per_gpu, ms, window=None):
         # time / 157.3 TFLOP/s): the physical figure of the kernels that are not atomic-bound
         "mfma_frac": {k: round(flops[k] * mult[k] / (table[k]["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                       for k in table if k in flops and table[k]["ms_per_step"] > 0},
+        # the same kernels' matrix-pipe occupancy: their instruction mix's floor (fp32 MFMAs + six bf16 MFMAs per bf16 x 3 product) /
+        # their time -- physical, <= 1 by construction, where `mfma_frac` is the speed against the fp32 roof
+        "mfma_pipe_frac": {k: round(flops[k] * mult[k] * pipe_factor(k) / (table[k]["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                           for k in table if k in flops and table[k]["ms_per_step"] > 0},
+        "bf16x3_flop_share": {k: round(v, 4) for k, v in B3_FLOP_SHARE.items()},
+        "step_pipe_tflop": sum(flops[k] * mult[k] * pipe_factor(k) for k in table if k in flops) / 1e12,   # -> step_pipe_frac (price_step)
+        "peak_note": ("`frac` / `mfma_frac` = algorithmic fp32 FLOP / time / the fp32-MFMA peak (157.3 TFLOP/s): a speed against the fp32 roof. "
+                      "Layers executed as bf16 x 3 (fp32-grade: 3 bf16 pieces, 6 piece products on v_mfma_f32_32x32x16_bf16, 16 x the fp32 rate) cost "
+                      "6/16 of their fp32 MFMA cycles, so a kernel may pass the fp32 roof; `mfma_pipe_frac` / `pipe_frac` / `step_pipe_frac` price "
+                      "the executed instruction mix instead (the physical matrix-pipe occupancy)"),
         "pmc_profile": _profile_csv("pmc_fetch")[1],
     })
     # SURVEY.md section 8(d) canonical constants: per sample B_fwd(f) = 4032 + 6912 f bytes, F_fwd(f) = 66004 +
@@ -527,6 +557,8 @@ def price_step(rf, ms, rays_per_gpu):
     rf["step_frac_of_peak"] = rf["step_algorithmic_tflop"] / (ms * 1e-3) / PEAK_F32_MFMA_TFLOPS
     rf["achieved"] = rf["step_algorithmic_tflop"] / (ms * 1e-3)
     rf["frac"] = rf["step_frac_of_peak"]
+    if "step_pipe_tflop" in rf:   # matrix-pipe occupancy of the whole step: the executed instruction mix's floor / the timed step
+        rf["step_pipe_frac"] = rf["step_pipe_tflop"] / (ms * 1e-3) / PEAK_F32_MFMA_TFLOPS
     sc = rf["survey_canonical"]
     t_meas = ms * 1e-3 / rays_per_gpu
     sc["frac_flop"] = sc["flop_per_training_ray"] / (PEAK_F32_MFMA_TFLOPS * 1e12 * t_meas)
@@ -585,10 +617,11 @@ def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5, streams=1):
     f_avg = 0.5 * (f_s + f_d)
     flop_survey, bytes_survey = ns * (66004.0 + 145362.0 * f_avg), ns * (4032.0 + 6912.0 * f_avg)   # SURVEY 8(d) constants
     kern_ms = sum(v["ms_per_frame"] for k, v in table.items() if k != "render_fused" or len(table) == 1)
-    mfma = {}
+    mfma, mfma_pipe = {}, {}
     for k, f in (("dyn_density", ns * F_DYN_DENSITY), ("dyn_app", ns * f_d * F_DYN_APP), ("static_app", ns * f_s * F_STAT_APP)):
         if k in table and table[k]["ms_per_frame"] > 0:
             mfma[k] = round(f / (table[k]["ms_per_frame"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            mfma_pipe[k] = round(mfma[k] * pipe_factor(k), 4)
     out["roofline"] = {
         "bound": "mfma", "achieved": flop / dtf / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": flop / dtf / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -600,7 +633,7 @@ def render_leg(L, R, S_, trainer, cfg, dev, chunk, frames=5, streams=1):
         "fractions": {"app_mask_static": f_s, "app_mask_dynamic": f_d},
         "kernel_ms_per_frame": {k: v["ms_per_frame"] for k, v in table.items()},
         "kernel_launches_per_frame": {k: v["launches"] for k, v in table.items()},
-        "sum_kernel_ms_per_frame": kern_ms, "mfma_frac": mfma,
+        "sum_kernel_ms_per_frame": kern_ms, "mfma_frac": mfma, "mfma_pipe_frac": mfma_pipe,
         "source": "HIP events of one frame of this run (rdrf_prof_*); ms_per_frame is the wall clock of the timed frames"}
     return out
 
@@ -637,6 +670,10 @@ def compact_line(out):
                                                                "ms_per_step")}
         r["mfma_frac"] = {k: _num(v) for k, v in rf.get("mfma_frac", {}).items()
                           if k in ("dyn_density", "dyn_app", "static_app", "dw_dyn", "dw_static")}
+        if rf.get("mfma_pipe_frac"):   # matrix-pipe occupancy of the executed instruction mix (bf16 x 3 layers priced at 6/16)
+            r["mfma_pipe_frac"] = {k: _num(v) for k, v in rf["mfma_pipe_frac"].items() if k in ("dyn_density", "dyn_app", "static_app")}
+            r["step_pipe_frac"] = _num(rf.get("step_pipe_frac"))
+            r["peak_note"] = "frac = fp32 FLOP / time / fp32-MFMA peak; bf16 x 3 layers (fp32-grade) cost 6/16 of their fp32 MFMA cycles: *_pipe_frac price the executed mix"
         for k in ("sum_kernel_ms_per_step", "scatter_family_ms_per_step", "forward_mlp_ms_per_step", "dw_ms_per_step",
                   "launches_per_step", "pmc_profile"):
             if k in rf:
@@ -871,7 +908,8 @@ def main():
             rf_f = price_step(rf_f, dtf * 1e3, rpg)
             fin["roofline"] = {k: rf_f[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "step_frac_of_peak",
                                                     "kernel_ms_per_step", "sum_kernel_ms_per_step", "ms_per_step_minus_kernel_sum",
-                                                    "fractions", "mfma_frac", "families", "profiled_window")}
+                                                    "fractions", "mfma_frac", "mfma_pipe_frac", "step_pipe_frac", "families", "profiled_window")
+                               if k in rf_f}
             fin["roofline"]["dominant_kernel"] = {k: rf_f["dominant_kernel"].get(k) for k in ("kernel", "bound", "achieved", "peak",
                                                                                              "unit", "frac", "ms_per_step")}
         if not args.no_render:

@@ -57,6 +57,9 @@ def test_compact_line_fits_and_carries_the_contract(fn):
                 assert 0.0 <= v <= 1.0, (path, v)
         for path, v in _walk(line.get("roofline", {}).get("mfma_frac", {})):
             assert 0.0 <= v <= 1.0, (path, v)
+        for path, v in _walk(line):   # matrix-pipe occupancies (bf16 x 3 layers priced at six bf16 MFMAs per product)
+            if "pipe_frac" in path and isinstance(v, float):
+                assert 0.0 <= v <= 1.0, (path, v)
 
 
 def test_compact_line_multi_gpu_record():

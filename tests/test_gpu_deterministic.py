@@ -67,3 +67,23 @@ def test_render_chunks_on_hip_streams_is_bit_identical_in_the_deterministic_buil
                         "-k", "test_render_chunks_on_hip_streams_is_bit_identical", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("case,N,S", [("ndc_relu", 777, 115), ("contract_relu_te", 2100, 37)])
+def test_appearance_backward_is_bit_reproducible_in_the_deterministic_build(case, N, S):
+    """d(<rgb, g>)/d(xyz_sampled) of both fields runs through every backward-data layer of k_static_app_bwd / k_dyn_app_bwd (bf16 x 3
+    with split storage: transposed images, odd block counts, lo pieces streamed one step ahead) and the feature scatter into the
+    per-sample coordinate gradients.  In the deterministic build nothing depends on arrival order, so repeated backward passes must
+    return the same bits: pins the operand hazards of the bf16 x 3 steps (rdrf_common.hpp mfma_seg_b3s) for the backward images, as
+    test_static_forward_is_bit_reproducible / test_dynamic_forward_is_bit_reproducible do for the forward ones.  (The product build's
+    coordinate gradients vary run to run at this shape with fp32 AND bf16 x 3 layers alike: the order of its fp32 atomics,
+    profiles/r06_det_bwd_app.txt.)"""
+    env = dict(os.environ, RDRF_DETERMINISTIC="1", REPS="12")
+    env.pop("RDRF_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph", "det_bwd_app.py"), case, str(N), str(S)], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if "distinct:" in l]
+    assert len(lines) == 2, r.stdout
+    for l in lines:   # coordinate gradients and the parameter gradients (flat buffer): one signature each over the 12 passes
+        assert l.count("distinct: [12]") == 2 and "nonzero 0 " not in l, l

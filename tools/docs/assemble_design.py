@@ -12,6 +12,11 @@ fs, rf = d["final_stage"], d["roofline"]
 rff = fs["roofline"]
 
 
+sys.path.insert(0, ROOT)
+import bench   # pipe_factor(): the matrix-pipe floor of a kernel's instruction mix / its fp32-only floor
+PF = {n: bench.pipe_factor(n) for n in ("dyn_density", "dyn_app", "static_app")}
+
+
 def k(v):
     return f"{v / 1e3:.0f}"
 
@@ -42,6 +47,9 @@ sub = {
     "FAM_BWD": f"{fam(rf, 'backward'):.2f} / {fam(rff, 'backward'):.2f}", "FAM_DW": f"{fam(rf, 'k_dw'):.2f} / {fam(rff, 'k_dw'):.2f}",
     "MFMA_FWD": " / ".join(f"{rf['mfma_frac'][n]:.2f}" for n in ("dyn_density", "dyn_app", "static_app")) + " at stage 0, " +
                 " / ".join(f"{rff['mfma_frac'][n]:.2f}" for n in ("dyn_density", "dyn_app", "static_app")) + " at the final stage (round 5: 0.54 / 0.46 / 0.59, 0.55 / 0.49 / 0.62)",
+    "MFMA_PIPE": " / ".join(f"{rf['mfma_pipe_frac'][n]:.2f}" for n in ("dyn_density", "dyn_app", "static_app")) + " at stage 0, " +
+                 " / ".join(f"{rff.get('mfma_pipe_frac', {}).get(n, rff['mfma_frac'][n] * PF[n]):.2f}" for n in ("dyn_density", "dyn_app", "static_app")) +
+                 f" at the final stage; whole step (`step_pipe_frac`) {rf['step_pipe_frac']:.2f}",
     "S13_EAGER": f"{d['launch_bound_stage']['eager_ms_per_step']:.1f}" if "launch_bound_stage" in d else "-",
     "S13_GRAPH": f"{d['launch_bound_stage']['graph_ms_per_step']:.2f}" if "launch_bound_stage" in d else "-",
     "HBM_STEP": f"{hbm_total('r06_hbm_table.txt'):.1f}", "HBM_FINAL": f"{hbm_total('r06_final_stage_hbm_table.txt'):.1f}",

@@ -11,7 +11,7 @@ SQ=0; if [ "$1" = "sq" ]; then SQ=1; shift; fi
 OUT=$PWD/gpurun_out/prof6_$TAG
 RAW=/tmp/rawprof6_$TAG
 rm -rf $OUT $RAW; mkdir -p $OUT $RAW
-TRAIN="$PWD/bench.py $* --no-cpu-baseline --no-roofline --no-sparse --no-final-stage --no-render --no-liveness-leg"
+TRAIN="$PWD/bench.py $* --no-cpu-baseline --no-roofline --no-sparse --no-final-stage --no-render --no-liveness-leg --no-graph-leg"
 echo "$TRAIN" > $OUT/command.txt
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/train -o t -- python $TRAIN > $OUT/train.log 2>&1 )
 cp $(find $RAW/train -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
