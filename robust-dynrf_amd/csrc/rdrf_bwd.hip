@@ -13,6 +13,9 @@
 //      already the layout the k-contraction over samples needs, so nothing is transposed.
 // References: autograd of /root/reference/models/tensorBase.py:704-850, models/tensoRF.py:118-196,
 // 446-462, 521-811 (grid_sample backward per SURVEY.md Appendix A).
+#ifdef RDRF_GROWS_TEMPORAL   // A/B: the gradient rows this file's kernels write (read back by k_dw3 within the pass) with plain stores
+#define RDRF_SAVE_TEMPORAL
+#endif
 #include "rdrf_kernels.hpp"
 #ifdef RDRF_NO_BIAS_ATOMICS
 #define BIAS_ATOMIC(p, v) ((void)0)
@@ -2383,6 +2386,9 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw2(Dw2Plan P) {
 //   address of lane l (row = 16 sub + (l >> 2), chunk = (l & 3) ^ ((row >> 2) & 3)) and on the read (cdna guide, rule 21);
 //   the 16 lanes of a ds_read_b128 group then cover all 64 banks.
 // ------------------------------------------------------------------------------------------------
+#ifndef RDRF_DW_AUX
+#define RDRF_DW_AUX 0   // cache policy of the row DMA (2 = nt on gfx950: the rows are read once)
+#endif
 __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw3(Dw2Plan P) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dw3_stage[];   // 2 buffers x nblk x 128 float4
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
@@ -2403,6 +2409,9 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw3(Dw2Plan P) {
   const unsigned voff = (unsigned)(prow_ * 128 + (((lane & 3) ^ ((prow_ >> 2) & 3)) << 4));
   const int hbuf = P.nblk * 128;   // float4 per buffer
   auto dma = [&](int t, int hf, int buf) {
+#ifdef RDRF_DW_REV   // A/B: walk the tiles newest first (the rows the backward-data kernels touched last)
+    t = ntiles - 1 - t;
+#endif
     const float* g0 = seg0a + (size_t)t * st0;
     const float* g1 = seg0b + (size_t)t * st1;
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)g0, 0, 0x7fffffff, 0x00020000);
@@ -2421,8 +2430,8 @@ __global__ __launch_bounds__(64 * DW2_WAVES) void k_dw3(Dw2Plan P) {
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, vo, soff, 0, 0);
 #else
         const unsigned soff = (unsigned)(blk * 4096 + hf * 64);
-        if (blk < sb1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, voff, soff, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, voff, soff, 0, 0);
+        if (blk < sb1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, voff, soff, 0, RDRF_DW_AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, voff, soff, 0, RDRF_DW_AUX);
 #endif
 #endif
       }

@@ -115,7 +115,11 @@ RDRF_D void save_rows(float* __restrict__ tile_base, int row0, const float (&v)[
     // streaming (non-temporal) store: the rows are written once and read back a whole pass later,
     // long after L2 eviction; keeping them out of L2 leaves it to the factor gathers (-15 % on the
     // forward kernels)
+#ifdef RDRF_SAVE_TEMPORAL
+    tile_base[(size_t)(row0 + elem_of(kk, h)) * 32 + s] = v[kk];
+#else
     __builtin_nontemporal_store(v[kk], tile_base + (size_t)(row0 + elem_of(kk, h)) * 32 + s);
+#endif
   }
 }
 template <int KK>
@@ -123,7 +127,11 @@ RDRF_D void load_rows(const float* __restrict__ tile_base, int row0, float (&v)[
 #pragma unroll
   // (non-temporal LOADS were measured too: the dW kernel, whose waves share rows through L2, got
   // 10 % slower, the backward-data kernels 2 % faster -- not adopted)
+#ifdef RDRF_NT_ROWS
+  for (int kk = 0; kk < KK; ++kk) v[kk] = __builtin_nontemporal_load(tile_base + (size_t)(row0 + elem_of(kk, h)) * 32 + s);
+#else
   for (int kk = 0; kk < KK; ++kk) v[kk] = tile_base[(size_t)(row0 + elem_of(kk, h)) * 32 + s];
+#endif
 }
 
 // header of the per-call saved buffer (device memory owned by the caller)
