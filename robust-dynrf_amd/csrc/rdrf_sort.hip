@@ -3,7 +3,7 @@
 // The keys are (plane | level-0 cell) codes of every live sample: 17-19 significant bits, a few million entries, the value
 // of an entry is its position in the key array.  An LSD radix sort over digits of <= 9 bits (two passes for up to 18
 // bits); one pass =
-//   k_radix_hist     a workgroup owns a tile of 8192 consecutive entries; digit histogram of the tile in LDS, written
+//   k_radix_hist     a workgroup owns a tile of 2048 consecutive entries; digit histogram of the tile in LDS, written
 //                    digit-major ([digit][tile]) so that a row-wise exclusive scan orders equal digits by tile
 //   k_radix_scan     one workgroup per digit: exclusive scan of its row + the digit's total
 //   k_radix_scatter  the same tiles again: exclusive scan of the 512 digit totals in LDS, then a STABLE rank of every
@@ -22,7 +22,10 @@
 namespace {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_TILE = 8192;                  // entries per workgroup
+#ifndef RDRF_RS_TILE
+#define RDRF_RS_TILE 2048   // 8192 -> 2048: sort -11 % at stage 0, -12 % at the final stage (profiles/r06_ab_sort_tile.txt)
+#endif
+constexpr int RS_TILE = RDRF_RS_TILE;          // entries per workgroup
 constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES;
 constexpr int RS_ROUNDS = RS_PER_WAVE / 64;    // 64-entry rounds per wave
 constexpr int RS_MAX_DIGIT_BITS = 9;
