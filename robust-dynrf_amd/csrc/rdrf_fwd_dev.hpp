@@ -503,6 +503,19 @@ RDRF_D void dyn_density_body(const FieldArgs a, const DynW w, float* lds_fused, 
       }
       fill_x1(X1, t, h);
     }
+#ifndef RDRF_T_RESIDENT   // the per-ray time-branch outputs are re-read per tile (L1 hits) instead of living in 16 registers across the
+    // tiles: the training instantiation loses its 29 spilled registers (104 B of scratch per lane): kernel -6 % / -7 % (stage 0 / final,
+    // profiles/r06_ab_t_reload.txt; -DRDRF_T_RESIDENT builds the old form).  Same loads, same bits.
+    if constexpr (!FEAT && !FLAT) {
+      int nn = n;
+      asm volatile("" : "+v"(nn));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = ld4(a.tout + nn * 32 + 8 * q + 4 * h);
+        T[q * 4 + 0] = v.x; T[q * 4 + 1] = v.y; T[q * 4 + 2] = v.z; T[q * 4 + 3] = v.w;
+      }
+    }
+#endif
     const float px = a.xyz[idx * 3 + 0], py = a.xyz[idx * 3 + 1], pz = a.xyz[idx * 3 + 2];
     const bool raw_in = FEAT && a.in_norm;   // compute_*: the caller hands normalised coordinates
     const float xn0 = raw_in ? px : norm_c(px, a.box.lo[0], a.box.inv[0]);
