@@ -126,7 +126,8 @@ template <int KK>
 RDRF_D void load_rows(const float* __restrict__ tile_base, int row0, float (&v)[KK], int s, int h) {
 #pragma unroll
   // (non-temporal LOADS were measured too: the dW kernel, whose waves share rows through L2, got
-  // 10 % slower, the backward-data kernels 2 % faster -- not adopted)
+  // 10 % slower, the backward-data kernels 2 % faster -- not adopted; re-measured in round 6 against k_dw3's
+  // row DMA with -DRDRF_NT_ROWS / -DRDRF_SAVE_TEMPORAL: same outcome, profiles/r06_ab_cache_policies.txt)
 #ifdef RDRF_NT_ROWS
   for (int kk = 0; kk < KK; ++kk) v[kk] = __builtin_nontemporal_load(tile_base + (size_t)(row0 + elem_of(kk, h)) * 32 + s);
 #else
